@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X tensorForth backend (contract in the task brief).
+
+One "step" = one CNN training step (copy-in + forward + backprop + SGD, reference words
+`forward backprop 0.01 nn.sgd`) of the LeNet-style `nn_f` network (examples/t4_30e.4th:19-23)
+on a synthetic, HBM-resident 28x28x1 batch of 128 images PER GPU, through libt4hip.so.
+With --gpus N the batch is sharded by sample (N x 128, weak scaling) and the gradient slab is
+all-reduced (SUM) over RCCL before the optimizer kernel.
+
+The same run also times the 1024x1024x1024 fp32 `matmul` kernel (BASELINE config #2) with HIP
+events and reports it against the fp32 MFMA peak in `roofline`; `roofline_step` carries the
+HBM roofline of the CNN step; `cpu_baseline` is the CPU oracle timed on this box's cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
+# algorithmic bytes per image and parameter count (SURVEY.md 8d / BASELINE.md 3)
+NETS = {"nn_f": dict(bytes_per_img=494720, params=101030, flop_per_img=3134160),
+        "nn_c": dict(bytes_per_img=294800, params=197210, flop_per_img=1605360)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--net", default="nn_f", choices=list(NETS))
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-iters", type=int, default=200)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+
+    from tensorforth_amd import pymodel
+    N = args.batch
+    m = pymodel.Model(N, 28, 28, 1, seed=1234, device="cuda:%d" % local)
+    m.k.call("t4k_set_default_stream", None)             # share torch's current (null) stream with RCCL
+    build = pymodel.nn_c if args.net == "nn_c" else pymodel.nn_f
+    build(m).finalize()
+    if world > 1:                                         # identical replicas: broadcast rank 0's weights
+        for L in m.layers:
+            for t in (L.w, L.b):
+                if t is not None:
+                    dist.broadcast(t, 0)
+    # synthetic MNIST-shaped batch, resident in HBM (seed 42; class-dependent blob + noise)
+    rng = np.random.default_rng(42 + rank)
+    lab = rng.integers(0, 10, N).astype(np.uint32)
+    x = rng.random((N, 28, 28, 1)).astype(np.float32) * 0.2
+    for i, l in enumerate(lab):
+        x[i, 2 * l:2 * l + 8, 2 * l:2 * l + 8, 0] += 0.8
+    xd = torch.from_numpy(x).cuda(); labd = torch.from_numpy(lab.view(np.int32)).cuda()
+    m.forward(xd); m.onehot_labels(labd); m.sync()
+
+    def step():
+        m.forward(xd)
+        m.backprop()                                      # against the cached one-hot target
+        if world > 1:
+            dist.all_reduce(m.grad_slab, op=dist.ReduceOp.SUM)
+        m.sgd(0.01, 0.0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.cpu()[0])
+    ms_step = dt / args.steps * 1e3
+    img_s = world * N * args.steps / dt
+
+    out = None
+    if rank == 0:
+        net = NETS[args.net]
+        step_bytes = N * net["bytes_per_img"] + 4 * net["params"] * 7            # k_opt = 7 for SGD
+        out = {
+            "metric": "CNN train images/sec (+ fp32 GEMM TFLOP/s vs MI355X MFMA peak in `roofline`)",
+            "value": round(img_s, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
+                                   "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
+                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "python->C-ABI (pymodel)"},
+            "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                              "unit": "GB/s", "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                              "traffic": None, "algorithmic_bytes_per_step": step_bytes},
+        }
+        # ---- GEMM 1024^3 fp32 (word `matmul`), HIP events on the launch stream
+        k = m.k
+        g = torch.Generator(device="cuda"); g.manual_seed(1234)
+        A = torch.rand(1024, 1024, device="cuda", generator=g); B = torch.rand(1024, 1024, device="cuda", generator=g)
+        O = torch.zeros(1024, 1024, device="cuda")
+        e0 = ctypes.c_void_p(); e1 = ctypes.c_void_p()
+        k.call("t4k_event_create", ctypes.byref(e0)); k.call("t4k_event_create", ctypes.byref(e1))
+        for _ in range(20):
+            k.call("t4k_gemm", A.data_ptr(), B.data_ptr(), O.data_ptr(), 1.0, 0.0, 0, 0, 1024, 1024, 1024, 1, None)
+        best = 1e9; tot = 0.0; reps = 5
+        for _ in range(reps):
+            k.call("t4k_event_record", e0, None)
+            for _ in range(args.gemm_iters):
+                k.call("t4k_gemm", A.data_ptr(), B.data_ptr(), O.data_ptr(), 1.0, 0.0, 0, 0, 1024, 1024, 1024, 1, None)
+            k.call("t4k_event_record", e1, None); k.call("t4k_event_sync", e1)
+            ms = ctypes.c_float(0); k.call("t4k_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+            per = ms.value / args.gemm_iters; tot += per; best = min(best, per)
+        avg_ms = tot / reps
+        flops = 2.0 * 1024 ** 3
+        tf = flops / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_gemm_mfma<64,64> (1024^3 fp32 matmul)", "bound": "mfma", "achieved": round(tf, 2),
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                           "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2), "best_launch_us": round(best * 1e3, 2),
+                           "flop_per_launch": flops}
+        # ---- CPU baseline: the oracle ("port"), bounded sample
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import t4oracle
+            om = build(t4oracle.OracleModel(N, 28, 28, 1, seed=1234))
+            om.forward(x); om.onehot_labels(lab)
+            t0 = time.perf_counter(); nst = 0
+            while True:
+                om.forward(x); om.backprop(); om.sgd(0.01, 0.0); nst += 1
+                if time.perf_counter() - t0 > 12.0 or nst >= 50:
+                    break
+            cdt = time.perf_counter() - t0
+            a = np.random.default_rng(1).random((1024, 1024)).astype(np.float32); o_ = np.zeros((1024, 1024), np.float32)
+            t1 = time.perf_counter()
+            t4oracle.lib().t4o_gemm_host_blocked(t4oracle.P(a), t4oracle.P(a), t4oracle.P(o_), 1.0, 0.0, 1024, 1024, 1024)
+            gdt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(N * nst / cdt, 1), "unit": "images/s", "cores": 1, "kind": "port",
+                                   "sample": "%d oracle training steps of the same %s batch-%d workload (single thread)" % (nst, args.net, N),
+                                   "host_cores_available": os.cpu_count(),
+                                   "gemm_1024_host_blocked_ms": round(gdt * 1e3, 1),
+                                   "gemm_1024_host_gflops": round(flops / gdt / 1e9, 2)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+/*
+ * t4k.h - C-ABI of the MI355X (gfx950) tensor/CNN kernel backend for tensorForth.
+ *
+ * This is the drop-in boundary: every entry point below replaces one CUDA kernel
+ * (or one host wrapper + kernel pair) of the reference, cited as file:line
+ * relative to the reference tree.  All pointers are plain device pointers
+ * (fp32 unless noted), all sizes plain ints/longs; no C++ / torch types.
+ *
+ * Conventions (reference src/mu/tensor.h:51-115):
+ *   - tensors are fp32, NHWC contiguous; a sample slice is data + n*H*W*C
+ *   - every call returns an int status (T4K_OK == 0); nothing throws or aborts
+ *     (reference convention is print-and-continue, src/ten4_types.h:25,186-191)
+ *   - calls are asynchronous on `stream` (NULL = the library's default stream);
+ *     the caller synchronises (t4k_sync) before touching results on the host.
+ *     The reference syncs after every launch (GPU_CHK, src/ten4_types.h:192);
+ *     here the host layer syncs only at the host-touch sites.
+ *   - kernels never allocate; scratch comes from a library-owned workspace that
+ *     replaces the reference's per-tensor `_tmp` slot (src/mu/tensor.cu:481).
+ */
+#ifndef T4K_H_
+#define T4K_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *t4k_stream_t;            /* hipStream_t */
+typedef void *t4k_event_t;             /* hipEvent_t  */
+typedef void *t4k_graph_t;             /* hipGraphExec_t */
+
+enum {
+    T4K_OK              =  0,
+    T4K_ERR_ARG         = -1,          /* bad shape / null pointer / unsupported parameter   */
+    T4K_ERR_HIP         = -2,          /* HIP runtime error (see t4k_last_error)             */
+    T4K_ERR_NOMEM       = -3,
+    T4K_ERR_UNSUPPORTED = -4,          /* e.g. conv (K,S,P) outside the reference's set      */
+    T4K_ERR_NODEVICE    = -5,          /* no gfx950 device: the product path fails loudly    */
+    T4K_ERR_SINGULAR    = -6           /* singular matrix in inverse/plu                     */
+};
+
+/* math_op: values identical to reference src/t4math.h:25-56 */
+enum {
+    T4K_ABS = 0, T4K_NEG, T4K_EXP, T4K_LN, T4K_LOG, T4K_TANH, T4K_RELU, T4K_SIGM,
+    T4K_SQRT, T4K_RCP, T4K_SAT, T4K_IDEN, T4K_FILL, T4K_GFILL, T4K_SCALE, T4K_POW,
+    T4K_ADD, T4K_SUB, T4K_MUL, T4K_DIV, T4K_MOD, T4K_MAX, T4K_MIN, T4K_MUL2, T4K_MOD2,
+    T4K_SIN, T4K_COS
+};
+/* t4_layer: values identical to reference src/nn/ntypes.h:16-36 */
+enum {
+    T4K_L_NONE = 0, T4K_L_CONV, T4K_L_LINEAR, T4K_L_FLATTEN, T4K_L_RELU, T4K_L_TANH,
+    T4K_L_SIGMOID, T4K_L_SELU, T4K_L_LEAKYRL, T4K_L_ELU, T4K_L_DROPOUT, T4K_L_SOFTMAX,
+    T4K_L_LOGSMAX, T4K_L_AVGPOOL, T4K_L_MAXPOOL, T4K_L_MINPOOL, T4K_L_BATCHNM,
+    T4K_L_USAMPLE, T4K_L_DCONV
+};
+/* rand_opt: reference src/util.h:22-25 */
+enum { T4K_UNIFORM = 0, T4K_NORMAL = 1 };
+/* reduction selector for t4k_reduce */
+enum { T4K_RED_SUM = 0, T4K_RED_NVAR, T4K_RED_MAX, T4K_RED_MIN };
+
+/* ------------------------------------------------------------------ runtime */
+/* Replaces cudaSetDevice / cudaMallocManaged arena / cudaMemcpy / cudaDeviceSynchronize
+ * uses (src/ten4.cu:125-152, src/mu/mmu.cu:44-46, src/ten4_types.h:192-201). */
+int         t4k_device_count(void);
+int         t4k_init(int device);                  /* select device, create default stream + workspace */
+void        t4k_shutdown(void);
+const char *t4k_last_error(void);
+const char *t4k_backend_name(void);                /* "hip-gfx950" for the product library */
+int         t4k_device_info(int *cu_count, int *clock_khz, size_t *hbm_bytes);
+
+int t4k_malloc(void **p, size_t bytes);            /* device (HBM) allocation */
+int t4k_free(void *p);
+int t4k_host_alloc(void **p, size_t bytes);        /* pinned host staging */
+int t4k_host_free(void *p);
+int t4k_memcpy_h2d(void *dst, const void *src, size_t bytes, t4k_stream_t s);
+int t4k_memcpy_d2h(void *dst, const void *src, size_t bytes, t4k_stream_t s);
+int t4k_memcpy_d2d(void *dst, const void *src, size_t bytes, t4k_stream_t s);
+int t4k_memset(void *dst, int byte, size_t bytes, t4k_stream_t s);   /* Tensor::zeros tensor.cu:558-563 */
+int t4k_sync(t4k_stream_t s);
+
+int t4k_stream_create(t4k_stream_t *s);
+int t4k_stream_destroy(t4k_stream_t s);
+int t4k_set_default_stream(t4k_stream_t s);        /* adopt an external stream (e.g. torch's current) */
+t4k_stream_t t4k_default_stream(void);
+
+int t4k_event_create(t4k_event_t *e);
+int t4k_event_record(t4k_event_t e, t4k_stream_t s);
+int t4k_event_sync(t4k_event_t e);
+int t4k_event_elapsed_ms(t4k_event_t start, t4k_event_t stop, float *ms);
+int t4k_event_destroy(t4k_event_t e);
+
+/* hipGraph capture of a launch sequence (replaces ~40 launch+sync pairs per training
+ * step of the reference).  begin..end captures every t4k_* kernel call
+ * issued on `s`; launch replays it. */
+int t4k_graph_begin(t4k_stream_t s);
+int t4k_graph_end(t4k_stream_t s, t4k_graph_t *g);
+int t4k_graph_launch(t4k_graph_t g, t4k_stream_t s);
+int t4k_graph_destroy(t4k_graph_t g);
+
+/* ------------------------------------------------- tensor kernels (t4math.cu) */
+/* k_sum :23, k_nvar :48, k_max/d__max :85-131 via Tensor::sum/std/norm/max/min
+ * (tensor.cu:224-277).  Result is written (not accumulated) to *out_dev. */
+int t4k_reduce(int red_op, const float *src, long n, float avg, float *out_dev, t4k_stream_t s);
+/* k_nan_inf :278 / Tensor::has_nan tensor.cu:326-333: count of NaN/Inf -> *cnt_dev (int) */
+int t4k_nan_inf(const float *src, long n, int *cnt_dev, t4k_stream_t s);
+/* k_copy :134 */
+int t4k_copy(const float *src, float *dst, long n, t4k_stream_t s);
+/* k_transpose :150 (one sample): dst[(H*j+i)*C+c] = src[(W*i+j)*C+c]; bit-exact */
+int t4k_transpose(const float *src, float *dst, int H, int W, int C, t4k_stream_t s);
+/* k_identity :160 (one sample) */
+int t4k_identity(float *dst, int H, int W, int C, t4k_stream_t s);
+/* k_math :173 in-place unary / scalar op (LN/LOG clamp 1e-12, SQRT clamp 0, GFILL = v*j/n) */
+int t4k_math(int op, float *A, float v, long n, t4k_stream_t s);
+/* k_ts_op :206  O = A op v,  op in {ADD,SUB,MUL,DIV} */
+int t4k_ts_op(int op, const float *A, float v, float *O, long n, t4k_stream_t s);
+/* k_tt_op :222  O = A op B */
+int t4k_tt_op(int op, const float *A, const float *B, float *O, long n, t4k_stream_t s);
+/* k_bce :248  *out_dev = sum t*ln(o+eps) + (1-t)*ln(1-o+eps), eps = 1e-6 */
+int t4k_bce(const float *T, const float *O, long n, float *out_dev, t4k_stream_t s);
+/* k_dot :309  O[c] = alpha*sum_k A[k*C+c]*B[k*C+c] + beta*O[c]  for c in [0,C) */
+int t4k_dot(const float *A, const float *B, float *O, float alpha, float beta,
+            int K, int C, t4k_stream_t s);
+/* k_gemm_tile_claude :478 (Tensor::gemm3 tensor.cu:161, Tensor::linear :79):
+ *   O[M,N,C] = alpha * op(A) @ op(B) + beta * O, per channel c (element stride C)
+ *   op(A) = tA ? A stored [K,M,C] : A stored [M,K,C];  op(B) = tB ? B[N,K,C] : B[K,N,C]
+ * fp32 accumulate on MFMA.  beta*O is read even when beta==0 (reference quirk, SURVEY a-1)
+ * only if T4K_GEMM_BETA0_READS (default off: beta==0 never reads O). */
+int t4k_gemm(const float *A, const float *B, float *O, float alpha, float beta,
+             int tA, int tB, int M, int N, int K, int C, t4k_stream_t s);
+/* k_gemm :370 / k_gemm_claude :411 (words gemm1/gemm2): double accumulator, tA/tB ignored */
+int t4k_gemm_f64acc(const float *A, const float *B, float *O, float alpha, float beta,
+                    int M, int N, int K, int C, t4k_stream_t s);
+
+/* ------------------------------------------------ linear algebra (t4math.cu) */
+/* Tensor::inverse tensor.cu:344-369 (k_find_pivot/k_swap_rows/k_diag/k_elim :742-836):
+ * Gauss-Jordan with partial pivoting on A[K,K] and I[K,K] in place; whole host loop runs
+ * on the device.  *status_dev (int): 0 ok, z+1 = singular at column z. */
+int t4k_inverse(float *A, float *I, int K, int *status_dev, t4k_stream_t s);
+/* Tensor::plu tensor.cu:371-398 (k_lu_col :854, k_pivot :887): A -> packed L\U in place,
+ * piv_dev[K] pivot rows; if I != NULL and I != A, apply the row swaps to I (=> P). */
+int t4k_plu(float *A, float *I, int *piv_dev, int K, int *status_dev, t4k_stream_t s);
+/* Tensor::lu_inverse tensor.cu:400-417 (k_fsub :904, k_bsub :920) */
+int t4k_lu_inverse(float *A, float *I, int *piv_dev, int K, int *status_dev, t4k_stream_t s);
+/* Tensor::lu tensor.cu:419-429 (k_lu :936): keep U (get_u) or unit-L of a packed L\U */
+int t4k_lu_extract(float *LU, int get_u, int K, t4k_stream_t s);
+/* k_logdet :952: *logdet_dev = sum ln|U[j,j]|, *sign_dev = prod sign(U[j,j]) */
+int t4k_logdet(const float *LU, int K, float *logdet_dev, int *sign_dev, t4k_stream_t s);
+
+/* ------------------------------------------------------- RNG (util.cu:28-70) */
+/* Counter-based Philox4x32-10 replaces the reference's 1024 cuRAND XORWOW states
+ * (distribution parity only; the reference seeds from time(), sys.cpp:37). */
+int t4k_rand_init(uint64_t seed);
+/* d[i] = scale * (bias + u_i), u uniform (0,1] or N(0,1) (util.cu:58-70) */
+int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s);
+uint64_t t4k_rand_offset(void);                    /* current stream offset (for checkpoint/tests) */
+int t4k_rand_set_offset(uint64_t off);
+
+/* --------------------------------------------------- nn kernels (nn/nmath.*) */
+/* k_bias nmath.cu:27  O[n,e] += B[e] */
+int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t s);
+/* k_activate nmath.cu:37: layer in {RELU,TANH,SIGMOID,SELU,LEAKYRL,ELU,DROPOUT};
+ * writes output O and derivative mask F (for DROPOUT, F holds uniform randoms on entry) */
+int t4k_activate(int layer, const float *I, float *O, float *F, float alpha, long n, t4k_stream_t s);
+/* k_softmax_small / k_softmax nmath.cu:74-169: row softmax over C per sample */
+int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t s);
+/* k_batchnorm_1/2/3 nmath.cu:177-264 (Model::_fbatchnorm forward.cu:263-309).
+ * stat_dev[3C]: [0,C) rvar = 1/(sqrt(max(var,0))+1e-6), [C,2C) mean, [2C,3C) scratch */
+int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B,
+                      float *stat_dev, int N, int HW, int C, t4k_stream_t s);
+/* k_dbatchnorm_1/2/3 nmath.cu:295-414 (Model::_bbatchnorm backprop.cu:311-370):
+ * dX = gamma*rvar*(dY - mean(dY) - xhat*mean(dY*xhat)); dB,dW += the MEANS (quirk a-17) */
+int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *DX,
+                      float *DW, float *DB, float *stat_dev, int N, int HW, int C,
+                      int train, t4k_stream_t s);
+/* k_dlinear_db nmath.cu:274  DB[e] += sum_n DY[n,e] */
+int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t s);
+/* k_conv2d<TS,KS,S,P> nmath.tcu:34 (Model::_fconv forward.cu:125-155):
+ * O[n,i,j,c0] = B[c0] + sum F[((c1*K+ky)*K+kx)*C0+c0] * I[n,i*S+ky-P,j*S+kx-P,c1]
+ * supported (K,S,P): (1,1,0) (3,1,1) (4,2,1) (5,1,2); output is written, not accumulated */
+int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
+                   int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                   int K, int S, int P, t4k_stream_t s);
+/* k_dconv2d<TS,KS,S,P> nmath.tcu:211 (Model::_bconv backprop.cu:152-191):
+ * DB[c0] += sum dO; DF += sum I*dO (both only if train);
+ * DX (overwritten) scatter (i*S+ky-P, j*S+kx-P) += F[c1,K-1-ky,K-1-kx,c0]*dO  (flipped, quirk a-11) */
+int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F,
+                   float *DF, float *DB,
+                   int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                   int K, int S, int P, int train, t4k_stream_t s);
+/* k_pool<KS> nmath.tcu:122 (layer in AVGPOOL/MAXPOOL/MINPOOL/USAMPLE), KS in {2,3} */
+int t4k_pool(int layer, const float *I, float *O, int N, int H1, int W1, int H0, int W0, int C,
+             int KS, t4k_stream_t s);
+/* k_dpool<KS> nmath.tcu:475: in place on the forward-input buffer I (reads x, zeroes the
+ * tile, writes dy at the first arg-max/min; avg: dy/KS^2; usample: broadcast) */
+int t4k_dpool(int layer, float *I, const float *DY, int N, int H1, int W1, int H0, int W0, int C,
+              int KS, t4k_stream_t s);
+/* k_sgd nmath.cu:419: dg=DG/Nw; beta~0: G-=lr*dg else M=b*M+(1-b)*dg, G-=lr*M; DG=0 */
+int t4k_sgd(float *G, float *DG, float *M, int Nw, float lr, float beta, long n, t4k_stream_t s);
+/* k_adam nmath.cu:438 (no bias correction, eps outside sqrt): zeroes DG */
+int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float b2,
+             long n, t4k_stream_t s);
+/* k_adamw nmath.cu:456 */
+int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd,
+              long n, t4k_stream_t s);
+/* Model::onehot(Dataset&) loss.cpp:47-72: hot[N,E] = 0; hot[n, label<E ? label : 0] = 1 */
+int t4k_onehot(const uint32_t *label_dev, float *hot, int N, int E, t4k_stream_t s);
+/* Model::hit loss.cpp:75-107: *cnt_dev = sum_n (int)hot[n, argmax_e out[n,e]] (first max wins) */
+int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt_dev, t4k_stream_t s);
+/* Dataset::_load dataset.cu:123-158: dst[i] = ((float)src_u8[i] - mean) * scale */
+int t4k_u8_normalize(const uint8_t *src_dev, float *dst, long n, float mean, float scale, t4k_stream_t s);
+
+/* ---------------------------------------------- fused MI355X-native launches */
+/* Model::_flinear forward.cu:157-198 in one launch:  Y[N,E0] = X[N,E1] @ W[E0,E1]^T + B[E0] */
+int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y,
+                   int N, int E0, int E1, t4k_stream_t s);
+/* Model::_blinear backprop.cu:193-254: DB += sum dY; DW += dY^T X (if train); DX = dY @ W.
+ * DX may alias X's buffer only when the caller guarantees X is no longer needed: the
+ * kernels read X for DW before DX is written (stream order). */
+int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX,
+                   float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
+/* multi-tensor optimizer step over a parameter table (one launch for all layers).
+ * tab_dev: array of n_tensors records {G, DG, M, V, n, Nw} on the device. */
+typedef struct { float *G, *DG, *M, *V; long n; int Nw; int pad; } t4k_param_rec;
+int t4k_opt_multi(int kind /*0 sgd,1 adam,2 adamw*/, const t4k_param_rec *tab_dev, int n_tensors,
+                  long max_n, float lr, float b1, float b2, float wd, t4k_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T4K_H_ */

@@ -1,0 +1,139 @@
+// optim.hip - fused parameter update + gradient zeroing, and Philox RNG fill.
+// Reference: k_sgd / k_adam / k_adamw src/nn/nmath.cu:419-472 (Model::sgd/adam/adamw
+// src/nn/gradient.cu:132-169); k_rand src/util.cu:56-70.
+#include "t4k_common.h"
+
+using namespace t4k;
+
+namespace {
+
+__device__ __forceinline__ void sgd1(float &g, float &dg, float &m, int Nw, float lr, float b, bool mom) {
+    const float d = dg / Nw;                               // Nw = parameter tensor's N, not batch (quirk a-19)
+    if (!mom) g -= lr * d;
+    else { m = b * m + (1.0f - b) * d; g -= lr * m; }
+    dg = 0.0f;
+}
+__device__ __forceinline__ void adam1(float &g, float &dg, float &m, float &v, float lr, float b1, float b2) {
+    const float d = dg;
+    m = b1 * m + (1.0f - b1) * d;
+    v = b2 * v + (1.0f - b2) * d * d;
+    g -= lr * m / (sqrtf(v) + DU_EPS);                     // no bias correction, eps outside sqrt
+    dg = 0.0f;
+}
+__device__ __forceinline__ void adamw1(float &g, float &dg, float &m, float &v, float lr, float b1, float b2, float wd) {
+    const float d = dg;
+    m = b1 * m + (1.0f - b1) * d;
+    v = b2 * v + (1.0f - b2) * d * d;
+    g -= lr * (m / (sqrtf(v) + DU_EPS) - wd * d);
+    dg = 0.0f;
+}
+
+__global__ void __launch_bounds__(BLK) k_sgd(float *G, float *DG, float *M, int Nw, float lr, float b, long n) {
+    const bool mom = !(fabsf(b) < DU_EPS);
+    for (long j = (long)blockIdx.x * BLK + threadIdx.x; j < n; j += (long)gridDim.x * BLK) {
+        float g = G[j], dg = DG[j], m = mom ? M[j] : 0.f;
+        sgd1(g, dg, m, Nw, lr, b, mom);
+        G[j] = g; DG[j] = 0.f; if (mom) M[j] = m;
+    }
+}
+__global__ void __launch_bounds__(BLK) k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, long n) {
+    for (long j = (long)blockIdx.x * BLK + threadIdx.x; j < n; j += (long)gridDim.x * BLK) {
+        float g = G[j], dg = DG[j], m = M[j], v = V[j];
+        adam1(g, dg, m, v, lr, b1, b2);
+        G[j] = g; DG[j] = 0.f; M[j] = m; V[j] = v;
+    }
+}
+__global__ void __launch_bounds__(BLK) k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd, long n) {
+    for (long j = (long)blockIdx.x * BLK + threadIdx.x; j < n; j += (long)gridDim.x * BLK) {
+        float g = G[j], dg = DG[j], m = M[j], v = V[j];
+        adamw1(g, dg, m, v, lr, b1, b2, wd);
+        G[j] = g; DG[j] = 0.f; M[j] = m; V[j] = v;
+    }
+}
+// one launch over every parameter tensor of a model: blockIdx.y = tensor, blockIdx.x strides its elements
+__global__ void __launch_bounds__(BLK) k_opt_multi(int kind, const t4k_param_rec *__restrict__ tab,
+                                                   float lr, float b1, float b2, float wd) {
+    const t4k_param_rec r = tab[blockIdx.y];
+    const bool mom = !(fabsf(b1) < DU_EPS);
+    for (long j = (long)blockIdx.x * BLK + threadIdx.x; j < r.n; j += (long)gridDim.x * BLK) {
+        float g = r.G[j], dg = r.DG[j];
+        if (kind == 0) {
+            float m = mom ? r.M[j] : 0.f;
+            sgd1(g, dg, m, r.Nw, lr, b1, mom);
+            if (mom) r.M[j] = m;
+        } else {
+            float m = r.M[j], v = r.V[j];
+            if (kind == 1) adam1(g, dg, m, v, lr, b1, b2); else adamw1(g, dg, m, v, lr, b1, b2, wd);
+            r.M[j] = m; r.V[j] = v;
+        }
+        r.G[j] = g; r.DG[j] = 0.f;
+    }
+}
+
+// d[i] = scale * (bias + u_i): element i <- Philox(counter = (off+i)/4)[i%4]
+__global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float bias, float scale, uint64_t seed, uint64_t base) {
+    const long nq = (n + 3) >> 2;
+    for (long q = (long)blockIdx.x * BLK + threadIdx.x; q < nq; q += (long)gridDim.x * BLK) {
+        uint32_t r[4]; float v[4];
+        philox4x32_10(base + (uint64_t)q, seed, r);
+        if (opt == T4K_NORMAL) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const float u1 = u01(r[2 * p]), u2 = u01(r[2 * p + 1]);
+                const float rad = sqrtf(-2.0f * logf(u1)), ang = 6.2831853071795865f * u2;
+                v[2 * p] = rad * cosf(ang); v[2 * p + 1] = rad * sinf(ang);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = u01(r[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const long i = q * 4 + k; if (i < n) d[i] = scale * (bias + v[k]); }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int t4k_sgd(float *G, float *DG, float *M, int Nw, float lr, float beta, long n, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
+    if (!G || !DG || Nw == 0) return fail(T4K_ERR_ARG, "t4k_sgd: bad argument");
+    if (!(fabsf(beta) < DU_EPS) && !M) return fail(T4K_ERR_ARG, "t4k_sgd: momentum tensor missing");
+    hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, Nw, lr, beta, n);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, long n, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
+    if (!G || !DG || !M || !V) return fail(T4K_ERR_ARG, "t4k_adam: null");
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, V, lr, b1, b2, n);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd, long n, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
+    if (!G || !DG || !M || !V) return fail(T4K_ERR_ARG, "t4k_adamw: null");
+    hipLaunchKernelGGL(k_adamw, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, V, lr, b1, b2, wd, n);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long max_n,
+                  float lr, float b1, float b2, float wd, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n_tensors <= 0) return T4K_OK;
+    if (!tab_dev || kind < 0 || kind > 2) return fail(T4K_ERR_ARG, "t4k_opt_multi: bad argument");
+    int gx = grid_for(max_n); if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(k_opt_multi, dim3(gx, n_tensors), dim3(BLK), 0, S(s), kind, tab_dev, lr, b1, b2, wd);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+
+int t4k_rand_init(uint64_t seed) { st().seed = seed; st().rng_off = 0; return T4K_OK; }
+uint64_t t4k_rand_offset(void) { return st().rng_off; }
+int t4k_rand_set_offset(uint64_t off) { st().rng_off = off & ~3ull; return T4K_OK; }
+int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
+    if (!d) return fail(T4K_ERR_ARG, "t4k_rand: null");
+    State &g = st();
+    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), d, n, opt, bias, scale, g.seed, g.rng_off / 4);
+    g.rng_off += (uint64_t)((n + 3) / 4) * 4;
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+
+} // extern "C"

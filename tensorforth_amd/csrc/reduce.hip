@@ -1,0 +1,272 @@
+// reduce.hip - reductions on wave64 shuffles: full reductions (sum / n*var / max / min /
+// BCE / NaN count), per-channel dot, row softmax, hit count, bias gradient, batchnorm.
+// Every reduction is deterministic (fixed tree, no fp32 atomics), unlike the reference's
+// atomicAdd epilogues.
+// Reference: src/t4math.cu:23-131,248-365, src/nn/nmath.cu:74-414, src/nn/loss.cpp:75-107.
+#include "t4k_common.h"
+#include <float.h>
+
+using namespace t4k;
+
+namespace {
+
+constexpr int RED_MAX_PARTS = 1024;
+
+enum { R_SUM = 0, R_NVAR, R_MAX, R_MIN, R_BCE };
+
+template <int OP> __device__ __forceinline__ float r_init() {
+    return OP == R_MAX ? -FLT_MAX : (OP == R_MIN ? FLT_MAX : 0.0f);
+}
+template <int OP> __device__ __forceinline__ float r_comb(float a, float b) {
+    return OP == R_MAX ? fmaxf(a, b) : (OP == R_MIN ? fminf(a, b) : a + b);
+}
+template <int OP> __device__ __forceinline__ float r_term(float x, float y, float avg) {
+    if (OP == R_NVAR) { float d = x - avg; return d * d; }
+    if (OP == R_BCE)  return y * __logf(x + DU_EPS) + (1.0f - y) * __logf(1.0f - x + DU_EPS);  // x = O, y = T
+    return x;
+}
+template <int OP> __device__ __forceinline__ float wave_comb_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = r_comb<OP>(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <int OP> __device__ __forceinline__ float block_comb(float v, float *sm) {
+    v = wave_comb_all<OP>(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = r_comb<OP>(r_comb<OP>(sm[0], sm[1]), r_comb<OP>(sm[2], sm[3]));
+    __syncthreads();
+    return r;
+}
+
+// stage 1: each block reduces a grid-strided slice to one partial (or the result if gridDim==1)
+template <int OP>
+__global__ void __launch_bounds__(BLK) k_reduce1(const float *__restrict__ X, const float *__restrict__ Y,
+                                                 long n, float avg, float *__restrict__ out, bool vec) {
+    __shared__ float sm[4];
+    const long tx = (long)blockIdx.x * BLK + threadIdx.x, step = (long)gridDim.x * BLK;
+    float v = r_init<OP>();
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long q = tx; q < n4; q += step) {
+            float4 x = reinterpret_cast<const float4 *>(X)[q];
+            float4 y = (OP == R_BCE) ? reinterpret_cast<const float4 *>(Y)[q] : make_float4(0, 0, 0, 0);
+            v = r_comb<OP>(v, r_term<OP>(x.x, y.x, avg)); v = r_comb<OP>(v, r_term<OP>(x.y, y.y, avg));
+            v = r_comb<OP>(v, r_term<OP>(x.z, y.z, avg)); v = r_comb<OP>(v, r_term<OP>(x.w, y.w, avg));
+        }
+        for (long j = (n4 << 2) + tx; j < n; j += step) v = r_comb<OP>(v, r_term<OP>(X[j], OP == R_BCE ? Y[j] : 0.0f, avg));
+    } else {
+        for (long j = tx; j < n; j += step) v = r_comb<OP>(v, r_term<OP>(X[j], OP == R_BCE ? Y[j] : 0.0f, avg));
+    }
+    v = block_comb<OP>(v, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+// stage 2: one block folds the partials in index order
+template <int OP>
+__global__ void __launch_bounds__(BLK) k_reduce2(const float *__restrict__ part, int np, float *__restrict__ out) {
+    __shared__ float sm[4];
+    float v = r_init<OP>();
+    for (int j = threadIdx.x; j < np; j += BLK) v = r_comb<OP>(v, part[j]);
+    v = block_comb<OP>(v, sm);
+    if (threadIdx.x == 0) *out = v;
+}
+
+template <int OP>
+int launch_reduce(const float *X, const float *Y, long n, float avg, float *out, hipStream_t s) {
+    const bool vec = aligned16(X) && (OP != R_BCE || aligned16(Y));
+    long g = (n + (long)BLK * 16 - 1) / ((long)BLK * 16);
+    if (g > RED_MAX_PARTS) g = RED_MAX_PARTS;
+    if (g <= 1) {
+        hipLaunchKernelGGL(k_reduce1<OP>, dim3(1), dim3(BLK), 0, s, X, Y, n, avg, out, vec);
+    } else {
+        float *part = (float *)st().ws;
+        hipLaunchKernelGGL(k_reduce1<OP>, dim3((int)g), dim3(BLK), 0, s, X, Y, n, avg, part, vec);
+        hipLaunchKernelGGL(k_reduce2<(OP == R_MAX || OP == R_MIN) ? OP : R_SUM>, dim3(1), dim3(BLK), 0, s, part, (int)g, out);
+    }
+    T4K_LAUNCH_CHECK();
+    return T4K_OK;
+}
+
+// NaN/Inf count: integer atomics are order-independent
+__global__ void __launch_bounds__(BLK) k_nan_inf(const float *__restrict__ X, long n, int *cnt) {
+    int v = 0;
+    for (long j = (long)blockIdx.x * BLK + threadIdx.x; j < n; j += (long)gridDim.x * BLK) {
+        float x = X[j];
+        if (isnan(x) || isinf(x)) v++;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(cnt, v);
+}
+
+// O[c] = alpha * <A[:,c], B[:,c]> + beta * O[c]; one block per channel
+__global__ void __launch_bounds__(BLK) k_dot(const float *__restrict__ A, const float *__restrict__ B, float *O,
+                                             float alpha, float beta, int K, int C) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    float acc = 0.0f;
+    for (int k = threadIdx.x; k < K; k += BLK) { long i = (long)k * C + c; acc = fmaf(A[i], B[i], acc); }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) O[c] = acc * alpha + (beta == 0.0f ? 0.0f : O[c] * beta);
+}
+
+// row softmax: one wave per sample (lanes stride over C), 4 samples per block
+__global__ void __launch_bounds__(BLK) k_softmax(const float *__restrict__ I, float *__restrict__ O, int N, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row  = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float *s = I + (long)row * C; float *d = O + (long)row * C;
+    float mx = -FLT_MAX;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, s[c]);
+    mx = wave_max_all(mx);
+    float sm = 0.0f;
+    for (int c = lane; c < C; c += 64) { float e = __expf(s[c] - mx); d[c] = e; sm += e; }
+    sm = wave_sum_all(sm);
+    for (int c = lane; c < C; c += 64) d[c] = d[c] / sm;
+}
+
+// hit count: per-sample first arg-max, then sum of hot[n, argmax]; single block, exact
+__global__ void __launch_bounds__(BLK) k_hit(const float *__restrict__ out, const float *__restrict__ hot, int N, int E, int *cnt) {
+    __shared__ int sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int local = 0;
+    for (int n = w; n < N; n += 4) {
+        const float *o = out + (long)n * E;
+        float m = -FLT_MAX; int idx = 0x7fffffff;
+        for (int e = lane; e < E; e += 64) { float v = o[e]; if (v > m) { m = v; idx = e; } }   // first max within lane
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float m2 = __shfl_xor(m, off, 64); int i2 = __shfl_xor(idx, off, 64);
+            if (m2 > m || (m2 == m && i2 < idx)) { m = m2; idx = i2; }
+        }
+        if (lane == 0) { if (idx >= E) idx = 0; local += (int)hot[(long)n * E + idx]; }
+    }
+    if (lane == 0) sm[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) *cnt = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// DB[e] += sum_n DY[n,e]: 64 columns x 4 row-groups per block, coalesced along e
+__global__ void __launch_bounds__(BLK) k_dlinear_db(const float *__restrict__ DY, float *DB, int N, int E0) {
+    __shared__ float sm[4][64];
+    const int ex = threadIdx.x & 63, ny = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + ex;
+    float acc = 0.0f;
+    if (e < E0) for (int n = ny; n < N; n += 4) acc += DY[(long)n * E0 + e];
+    sm[ny][ex] = acc;
+    __syncthreads();
+    if (ny == 0 && e < E0) DB[e] += (sm[0][ex] + sm[1][ex]) + (sm[2][ex] + sm[3][ex]);
+}
+
+// batchnorm statistics: one block per channel, finalised in the same launch
+__global__ void __launch_bounds__(BLK) k_bn_stats(const float *__restrict__ I, float *stat, long NHW, int C) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    float ts = 0.0f, tq = 0.0f;
+    for (long k = threadIdx.x; k < NHW; k += BLK) { float v = I[k * C + c]; ts += v; tq = fmaf(v, v, tq); }
+    ts = block_sum(ts, sm); tq = block_sum(tq, sm);
+    if (threadIdx.x == 0) {
+        float avg = ts / (float)NHW;
+        float var = tq / (float)NHW - avg * avg;
+        stat[C + c] = avg;
+        stat[c]     = 1.0f / (sqrtf(fmaxf(var, 0.0f)) + DU_EPS);
+    }
+}
+__global__ void __launch_bounds__(BLK) k_bn_apply(const float *__restrict__ I, float *O, float *XH,
+                                                  const float *__restrict__ W, const float *__restrict__ B,
+                                                  const float *__restrict__ stat, long total, int C) {
+    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
+        int c = (int)(z % C);
+        float xh = (I[z] - stat[C + c]) * stat[c];
+        XH[z] = xh; O[z] = xh * W[c] + B[c];
+    }
+}
+__global__ void __launch_bounds__(BLK) k_dbn_stats(const float *__restrict__ DY, const float *__restrict__ XH,
+                                                   float *stat, float *DW, float *DB, long NHW, int C, int train) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    float a = 0.0f, b = 0.0f;
+    for (long k = threadIdx.x; k < NHW; k += BLK) { long z = k * C + c; float d = DY[z]; a += d; b = fmaf(d, XH[z], b); }
+    a = block_sum(a, sm); b = block_sum(b, sm);
+    if (threadIdx.x == 0) {
+        float s1 = a / (float)NHW, s2 = b / (float)NHW;
+        stat[C + c] = s1; stat[2 * C + c] = s2;
+        if (train) { DB[c] += s1; DW[c] += s2; }
+    }
+}
+__global__ void __launch_bounds__(BLK) k_dbn_apply(const float *__restrict__ W, const float *__restrict__ DY,
+                                                   const float *__restrict__ XH, float *DX,
+                                                   const float *__restrict__ stat, long total, int C) {
+    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
+        int c = (int)(z % C);
+        DX[z] = (stat[c] * W[c]) * (DY[z] - stat[C + c] - XH[z] * stat[2 * C + c]);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int t4k_reduce(int red_op, const float *src, long n, float avg, float *out, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!src || !out || n < 0) return fail(T4K_ERR_ARG, "t4k_reduce: bad argument");
+    switch (red_op) {
+    case T4K_RED_SUM:  return launch_reduce<R_SUM>(src, nullptr, n, 0.0f, out, S(s));
+    case T4K_RED_NVAR: return launch_reduce<R_NVAR>(src, nullptr, n, avg, out, S(s));
+    case T4K_RED_MAX:  return launch_reduce<R_MAX>(src, nullptr, n, 0.0f, out, S(s));
+    case T4K_RED_MIN:  return launch_reduce<R_MIN>(src, nullptr, n, 0.0f, out, S(s));
+    }
+    return fail(T4K_ERR_ARG, "t4k_reduce: op %d", red_op);
+}
+int t4k_bce(const float *T, const float *O, long n, float *out, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!T || !O || !out || n < 0) return fail(T4K_ERR_ARG, "t4k_bce: bad argument");
+    return launch_reduce<R_BCE>(O, T, n, 0.0f, out, S(s));
+}
+int t4k_nan_inf(const float *src, long n, int *cnt, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!src || !cnt) return fail(T4K_ERR_ARG, "t4k_nan_inf: null");
+    T4K_HIP(hipMemsetAsync(cnt, 0, sizeof(int), S(s)));
+    if (n > 0) hipLaunchKernelGGL(k_nan_inf, dim3(grid_for(n, 8)), dim3(BLK), 0, S(s), src, n, cnt);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_dot(const float *A, const float *B, float *O, float alpha, float beta, int K, int C, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!A || !B || !O || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_dot: bad argument");
+    hipLaunchKernelGGL(k_dot, dim3(C), dim3(BLK), 0, S(s), A, B, O, alpha, beta, K, C);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (N <= 0 || C <= 0) return T4K_OK;
+    hipLaunchKernelGGL(k_softmax, dim3((N + 3) / 4), dim3(BLK), 0, S(s), I, O, N, C);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!out || !hot || !cnt || N < 0 || E < 1) return fail(T4K_ERR_ARG, "t4k_hit: bad argument");
+    hipLaunchKernelGGL(k_hit, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (N <= 0 || E0 <= 0) return T4K_OK;
+    hipLaunchKernelGGL(k_dlinear_db, dim3((E0 + 63) / 64), dim3(BLK), 0, S(s), DY, DB, N, E0);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B,
+                      float *stat, int N, int HW, int C, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_fwd: shape");
+    const long NHW = (long)N * HW, total = NHW * C;
+    hipLaunchKernelGGL(k_bn_stats, dim3(C), dim3(BLK), 0, S(s), I, stat, NHW, C);
+    hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), I, O, XH, W, B, stat, total, C);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *DX,
+                      float *DW, float *DB, float *stat, int N, int HW, int C, int train, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_bwd: shape");
+    const long NHW = (long)N * HW, total = NHW * C;
+    hipLaunchKernelGGL(k_dbn_stats, dim3(C), dim3(BLK), 0, S(s), DY, XH, stat, DW, DB, NHW, C, train);
+    hipLaunchKernelGGL(k_dbn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), W, DY, XH, DX, stat, total, C);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+
+} // extern "C"

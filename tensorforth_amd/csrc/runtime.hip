@@ -1,0 +1,156 @@
+// runtime.hip - device selection, HBM allocation, copies, streams, events, hipGraph capture.
+// Replaces the reference's cudaSetDevice / cudaMallocManaged arena / cudaMemcpy /
+// cudaDeviceSynchronize plumbing (src/ten4.cu:125-152, src/mu/mmu.cu:44-46,
+// src/ten4_types.h:186-201).
+#include "t4k_common.h"
+#include <stdarg.h>
+#include <string.h>
+
+namespace t4k {
+
+State &st() { static State s; return s; }
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(st().err, sizeof(st().err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    snprintf(st().err, sizeof(st().err), "HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    return T4K_ERR_HIP;
+}
+
+} // namespace t4k
+
+using namespace t4k;
+
+extern "C" {
+
+int t4k_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int t4k_init(int device) {
+    State &g = st();
+    if (g.ready && g.device == device) return T4K_OK;
+    int n = t4k_device_count();
+    if (n <= 0) return fail(T4K_ERR_NODEVICE, "no HIP device visible: libt4hip has no CPU fallback");
+    if (device < 0 || device >= n) return fail(T4K_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    T4K_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    T4K_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(T4K_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    g.cu_count = prop.multiProcessorCount;
+    if (!g.stream) { T4K_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking)); g.own_stream = true; }
+    if (!g.ws) {
+        g.ws_bytes = (size_t)64 << 20;                 // 64 MiB: reductions, split-K slabs, linalg
+        T4K_HIP(hipMalloc(&g.ws, g.ws_bytes));
+        T4K_HIP(hipMemsetAsync(g.ws, 0, g.ws_bytes, g.stream));
+    }
+    g.device = device;
+    g.ready  = true;
+    return T4K_OK;
+}
+
+void t4k_shutdown(void) {
+    State &g = st();
+    if (!g.ready) return;
+    (void)hipDeviceSynchronize();
+    if (g.ws) { (void)hipFree(g.ws); g.ws = nullptr; }
+    if (g.own_stream && g.stream) { (void)hipStreamDestroy(g.stream); }
+    g.stream = nullptr; g.own_stream = false;
+    g.ready = false;
+}
+
+const char *t4k_last_error(void)  { return st().err; }
+const char *t4k_backend_name(void) { return "hip-gfx950"; }
+
+int t4k_device_info(int *cu_count, int *clock_khz, size_t *hbm_bytes) {
+    T4K_REQUIRE_INIT();
+    hipDeviceProp_t prop;
+    T4K_HIP(hipGetDeviceProperties(&prop, st().device));
+    if (cu_count)  *cu_count  = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return T4K_OK;
+}
+
+int t4k_malloc(void **p, size_t bytes) {
+    T4K_REQUIRE_INIT();
+    if (!p) return fail(T4K_ERR_ARG, "t4k_malloc: null");
+    hipError_t e = hipMalloc(p, bytes ? bytes : 4);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(T4K_ERR_NOMEM, "out of HBM (%zu bytes)", bytes); }
+    T4K_HIP(e);
+    return T4K_OK;
+}
+int t4k_free(void *p) { T4K_REQUIRE_INIT(); if (p) T4K_HIP(hipFree(p)); return T4K_OK; }
+int t4k_host_alloc(void **p, size_t bytes) { T4K_REQUIRE_INIT(); T4K_HIP(hipHostMalloc(p, bytes ? bytes : 4, hipHostMallocDefault)); return T4K_OK; }
+int t4k_host_free(void *p) { T4K_REQUIRE_INIT(); if (p) T4K_HIP(hipHostFree(p)); return T4K_OK; }
+
+int t4k_memcpy_h2d(void *dst, const void *src, size_t bytes, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (!bytes) return T4K_OK;
+    T4K_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(s)));
+    return T4K_OK;
+}
+int t4k_memcpy_d2h(void *dst, const void *src, size_t bytes, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (!bytes) return T4K_OK;
+    T4K_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(s)));
+    return T4K_OK;
+}
+int t4k_memcpy_d2d(void *dst, const void *src, size_t bytes, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (!bytes) return T4K_OK;
+    T4K_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)));
+    return T4K_OK;
+}
+int t4k_memset(void *dst, int byte, size_t bytes, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (!bytes) return T4K_OK;
+    T4K_HIP(hipMemsetAsync(dst, byte, bytes, S(s)));
+    return T4K_OK;
+}
+int t4k_sync(t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipStreamSynchronize(S(s))); return T4K_OK; }
+
+int t4k_stream_create(t4k_stream_t *s) {
+    T4K_REQUIRE_INIT();
+    hipStream_t h; T4K_HIP(hipStreamCreateWithFlags(&h, hipStreamNonBlocking)); *s = (t4k_stream_t)h;
+    return T4K_OK;
+}
+int t4k_stream_destroy(t4k_stream_t s) { T4K_REQUIRE_INIT(); if (s) T4K_HIP(hipStreamDestroy((hipStream_t)s)); return T4K_OK; }
+int t4k_set_default_stream(t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    State &g = st();
+    if (g.own_stream && g.stream && g.stream != (hipStream_t)s) { (void)hipStreamSynchronize(g.stream); (void)hipStreamDestroy(g.stream); }
+    g.stream = (hipStream_t)s; g.own_stream = false;
+    return T4K_OK;
+}
+t4k_stream_t t4k_default_stream(void) { return (t4k_stream_t)st().stream; }
+
+int t4k_event_create(t4k_event_t *e) { T4K_REQUIRE_INIT(); hipEvent_t h; T4K_HIP(hipEventCreate(&h)); *e = (t4k_event_t)h; return T4K_OK; }
+int t4k_event_record(t4k_event_t e, t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventRecord((hipEvent_t)e, S(s))); return T4K_OK; }
+int t4k_event_sync(t4k_event_t e) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventSynchronize((hipEvent_t)e)); return T4K_OK; }
+int t4k_event_elapsed_ms(t4k_event_t a, t4k_event_t b, float *ms) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return T4K_OK; }
+int t4k_event_destroy(t4k_event_t e) { T4K_REQUIRE_INIT(); if (e) T4K_HIP(hipEventDestroy((hipEvent_t)e)); return T4K_OK; }
+
+int t4k_graph_begin(t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    T4K_HIP(hipStreamBeginCapture(S(s), hipStreamCaptureModeThreadLocal));
+    return T4K_OK;
+}
+int t4k_graph_end(t4k_stream_t s, t4k_graph_t *g) {
+    T4K_REQUIRE_INIT();
+    hipGraph_t graph = nullptr;
+    T4K_HIP(hipStreamEndCapture(S(s), &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    T4K_HIP(e);
+    *g = (t4k_graph_t)exec;
+    return T4K_OK;
+}
+int t4k_graph_launch(t4k_graph_t g, t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipGraphLaunch((hipGraphExec_t)g, S(s))); return T4K_OK; }
+int t4k_graph_destroy(t4k_graph_t g) { T4K_REQUIRE_INIT(); if (g) T4K_HIP(hipGraphExecDestroy((hipGraphExec_t)g)); return T4K_OK; }
+
+} // extern "C"

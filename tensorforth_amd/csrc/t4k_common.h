@@ -1,0 +1,95 @@
+// t4k_common.h - shared internals of libt4hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/t4k.h"
+
+namespace t4k {
+
+constexpr int WAVE   = 64;
+constexpr int BLK    = 256;            // default workgroup: 4 waves, one per SIMD
+constexpr int MAX_WG = 2048;           // 256 CUs x 8 resident blocks: grid-stride above this
+constexpr float DU_EPS = 1.0e-6f;      // reference src/ten4_types.h:85
+
+struct State {
+    bool        ready   = false;
+    int         device  = -1;
+    hipStream_t stream  = nullptr;     // library default stream
+    bool        own_stream = false;
+    void       *ws      = nullptr;     // device workspace (replaces per-tensor _tmp)
+    size_t      ws_bytes = 0;
+    uint64_t    seed    = 0;           // Philox key
+    uint64_t    rng_off = 0;           // Philox element offset (multiple of 4)
+    int         cu_count = 256;
+    char        err[256] = {0};
+};
+State &st();
+
+int  fail(int code, const char *fmt, ...);
+int  hip_fail(hipError_t e, const char *what);
+inline hipStream_t S(t4k_stream_t s) { return s ? (hipStream_t)s : st().stream; }
+
+#define T4K_REQUIRE_INIT() do { if (!t4k::st().ready) return t4k::fail(T4K_ERR_NODEVICE, "t4k_init not called or no gfx950 device"); } while (0)
+#define T4K_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) return t4k::hip_fail(_e, #call); } while (0)
+#define T4K_LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return t4k::hip_fail(_e, "kernel launch"); } while (0)
+
+inline int grid_for(long n, int per_thread = 1) {
+    long g = (n + (long)BLK * per_thread - 1) / ((long)BLK * per_thread);
+    if (g > MAX_WG) g = MAX_WG;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- device helpers ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;                                   // lane 0 holds the sum
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;                                   // every lane holds the sum
+}
+__device__ __forceinline__ float wave_max_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// block-wide sum for BLK=256 (4 waves); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float *smem4) {
+    v = wave_sum_all(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) smem4[w] = v;
+    __syncthreads();
+    float r = smem4[0] + smem4[1] + smem4[2] + smem4[3];
+    __syncthreads();
+    return r;
+}
+
+// Philox4x32-10; counter = element_index/4, key = seed (same definition as the oracle)
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) {   // (0,1]
+    return __fmaf_rn((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+}
+
+} // namespace t4k

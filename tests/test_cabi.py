@@ -1,0 +1,46 @@
+"""CPU-side checks of the drop-in boundary: libt4hip.so loads, exports every symbol
+include/t4k.h declares, and refuses to run without a gfx950 device (no CPU fallback)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tensorforth_amd.lib import T4K
+    h = T4K()
+    assert h.missing == [], h.missing
+    assert len(h.decls) >= 60
+    out = subprocess.check_output(["nm", "-D", "--defined-only", h.path]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(h.decls) <= exported
+
+
+def test_backend_identifies_itself_and_has_no_oracle_dependency():
+    from tensorforth_amd.lib import T4K
+    h = T4K()
+    assert h.lib.t4k_backend_name() == b"hip-gfx950"
+    ldd = subprocess.check_output(["ldd", h.path]).decode()
+    assert "oracle" not in ldd and "libamdhip64" in ldd
+
+
+def test_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from tensorforth_amd.lib import T4K, T4KError
+    h = T4K()
+    assert h.lib.t4k_device_count() == 0
+    with pytest.raises(T4KError):
+        h.init(0)
+    # a compute entry point must refuse, not silently fall back
+    assert h.lib.t4k_gemm(None, None, None, 1.0, 0.0, 0, 0, 4, 4, 4, 1, None) == -5
+    assert b"no" in h.lib.t4k_last_error().lower() or b"init" in h.lib.t4k_last_error().lower()
+
+
+def test_header_cites_reference_lines():
+    text = open(os.path.join(ROOT, "include", "t4k.h")).read()
+    for needle in ("k_gemm_tile_claude :478", "nmath.tcu:34", "nmath.tcu:211", "nmath.cu:419", "tensor.cu:344"):
+        assert needle in text

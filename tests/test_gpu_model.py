@@ -1,0 +1,121 @@
+"""Model-level GPU parity: the same layer words run on libt4hip.so (tensorforth_amd.pymodel)
+and on the CPU oracle (oracle/t4oracle.OracleModel) with the same Philox seed, then every
+activation, gradient and updated parameter is compared.  Includes the reference's own
+known-answer scripts replayed on the GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat_reference_examples.json")))
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
+
+
+def np_(t, m):
+    m.sync(); return t.detach().cpu().numpy()
+
+
+def _pair(oracle, build, n, h=28, w=28, c=1, seed=99):
+    import torch
+    from tensorforth_amd import pymodel
+    g = build(pymodel.Model(n, h, w, c, seed=seed))
+    o = build(oracle.OracleModel(n, h, w, c, seed=seed))
+    return torch, g, o
+
+
+def _compare_params(g, o, tol):
+    for Lg, Lo in zip(g.layers, o.layers):
+        for name in ("w", "b", "dw", "db"):
+            tg, to = getattr(Lg, name), getattr(Lo, name)
+            if to is not None:
+                assert rel(np_(tg, g), to) < tol, (Lo.fn, name)
+
+
+@pytest.mark.parametrize("net,n", [("nn_c", 8), ("nn_c", 128), ("nn_f", 8), ("nn_f", 128)])
+def test_training_step_matches_oracle(oracle, t4k, net, n):
+    from tensorforth_amd import pymodel
+    build = (lambda m: pymodel.nn_c(m)) if net == "nn_c" else (lambda m: pymodel.nn_f(m, dropout=False))
+    torch, g, o = _pair(oracle, build, n)
+    _compare_params(g, o, 1e-7)                                  # identical Philox init
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 28, 28, 1)).astype(np.float32)
+    lab = rng.integers(0, 10, n).astype(np.uint32)
+    xd = torch.from_numpy(x).cuda(); labd = torch.from_numpy(lab.view(np.int32)).cuda()
+    for step in range(2):
+        yo = o.forward(x); yg = g.forward(xd)
+        for i in range(len(o.t)):
+            assert rel(np_(g.t[i], g), o.t[i]) < 1e-4, ("fwd", step, i)
+        o.onehot_labels(lab); g.onehot_labels(labd)
+        assert g.hit() == o.hit
+        assert abs(g.loss(pymodel.LOSS_CE, g.hot) - o.loss(oracle.LOSS_CE, o.hot)) < 1e-4
+        o.backprop(); g.backprop()
+        for i in range(len(o.t)):
+            assert rel(np_(g.t[i], g), o.t[i]) < 2e-4, ("bwd", step, i)
+        _compare_params(g, o, 2e-4)
+        if step == 0:
+            o.sgd(0.01, 0.0); g.sgd(0.01, 0.0)
+        else:
+            o.adam(0.001); g.adam(0.001)
+        _compare_params(g, o, 2e-4)
+
+
+def test_dropout_masks_are_bit_identical(oracle, t4k):
+    from tensorforth_amd import pymodel
+    torch, g, o = _pair(oracle, lambda m: pymodel.nn_f(m, dropout=True), 4)
+    x = np.random.default_rng(0).random((4, 28, 28, 1)).astype(np.float32)
+    o.forward(x); g.forward(torch.from_numpy(x).cuda())
+    for Lg, Lo in zip(g.layers, o.layers):
+        if Lo.fn == oracle.L_DROPOUT:
+            assert np.array_equal(np_(Lg.aux, g), Lo.aux)        # same Philox stream -> same mask
+    assert rel(np_(g.t[-1], g), o.t[-1]) < 1e-4
+
+
+def test_reference_kat_t4_30b_on_gpu(oracle, t4k):
+    """examples/t4_30b.4th replayed through libt4hip.so"""
+    import torch
+    from tensorforth_amd import pymodel
+    k = KAT["t4_30b"]; e = k["expect"]
+    m = pymodel.Model(*k["model_in"]).linear(3).sigmoid().linear(2).sigmoid()
+    up = lambda a: torch.tensor(np.array(a, np.float32)).cuda()
+    m.layers[0].w.copy_(up(k["w0"])); m.layers[0].b.copy_(up(k["b0"]))
+    m.layers[2].w.copy_(up(k["w2"])); m.layers[2].b.copy_(up(k["b2"]))
+    torch.cuda.synchronize()
+    m.forward(up(k["input"]))
+    close = lambda t, v: np.testing.assert_allclose(np_(t, m).ravel(), np.array(v).ravel(), atol=6e-5)
+    close(m.t[1], e["L1_in"]); close(m.layers[1].aux, e["L1_mask"]); close(m.t[2], e["L2_in"])
+    close(m.t[3], e["L3_in"]); close(m.t[4], e["out"])
+    tgt = up(k["target"])
+    assert abs(m.loss(pymodel.LOSS_MSE, tgt) - e["loss_mse"]) < 2e-6
+    m.backprop(tgt)
+    close(m.t[4], e["L4_dY"]); close(m.layers[2].db, e["L2_dB"]); close(m.layers[2].dw, e["L2_dW"])
+    close(m.t[2], e["L2_dX"]); close(m.layers[0].db, e["L0_dB"]); close(m.layers[0].dw, e["L0_dW"]); close(m.t[0], e["L0_dX"])
+    m.sgd(0.5, 0.0)
+    close(m.layers[2].w, e["L2_W_after"]); close(m.layers[2].b, e["L2_B_after"])
+    close(m.layers[0].w, e["L0_W_after"]); close(m.layers[0].b, e["L0_B_after"])
+
+
+def test_training_reduces_loss_on_synthetic_blobs(t4k):
+    """statistical parity: class-dependent synthetic images, loss must fall"""
+    import torch
+    from tensorforth_amd import pymodel
+    rng = np.random.default_rng(42)
+    n = 128
+    m = pymodel.nn_c(pymodel.Model(n, 28, 28, 1, seed=7))
+    lab = rng.integers(0, 10, n).astype(np.uint32)
+    x = rng.random((n, 28, 28, 1)).astype(np.float32) * 0.2
+    for i, l in enumerate(lab):
+        x[i, 2 * l:2 * l + 8, 2 * l:2 * l + 8, 0] += 0.8
+    xd = torch.from_numpy(x).cuda(); labd = torch.from_numpy(lab.view(np.int32)).cuda()
+    losses = []
+    for _ in range(30):
+        m.forward(xd); m.onehot_labels(labd); losses.append(m.loss(pymodel.LOSS_CE, m.hot))
+        m.backprop(); m.adam(0.001)
+    assert losses[-1] < 0.5 * losses[0], losses
+    assert m.hit() > 64

@@ -1,0 +1,409 @@
+"""GPU parity: every t4k_* entry point of libt4hip.so (called through the C-ABI with raw
+device pointers) against the CPU oracle on the same seeded inputs.
+Bar: bit-exact for index/shape/integer work; 1e-4 relative for fp32 math (north_star)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
+
+
+class Dev:
+    """device buffers via torch (plumbing only); pointers cross the ABI as integers"""
+
+    def __init__(self, t4k):
+        import torch
+        self.torch = torch
+        self.h = t4k
+        t4k.call("t4k_set_default_stream", None)        # legacy null stream == torch's default stream
+
+    def up(self, a, dtype=None):
+        t = self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return t
+
+    def zeros(self, shape, dtype=None):
+        return self.torch.zeros(shape, dtype=dtype or self.torch.float32, device="cuda")
+
+    def down(self, t):
+        self.h.call("t4k_sync", None)
+        return t.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def dev(t4k):
+    return Dev(t4k)
+
+
+def p(t):
+    return t.data_ptr()
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (128, 100, 1960), (100, 1960, 128), (128, 1960, 100),
+                                   (128, 10, 100), (33, 17, 5), (1, 1, 1), (256, 256, 256), (200, 300, 77)])
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_vs_oracle(t4k, dev, oracle, M, N, K, tA, tB):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + tA * 2 + tB)
+    A = rng.uniform(-1, 1, (K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (N, K) if tB else (K, N)).astype(np.float32)
+    O0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    for alpha, beta in ((1.0, 0.0), (0.5, 2.0)):
+        ref = oracle.gemm(A, B, O0.copy(), alpha, beta, tA, tB)
+        dA, dB_, dO = dev.up(A), dev.up(B), dev.up(O0)
+        t4k.call("t4k_gemm", p(dA), p(dB_), p(dO), alpha, beta, tA, tB, M, N, K, 1, None)
+        assert rel(dev.down(dO), ref) < RTOL
+
+
+def test_gemm_channel_interleaved_and_unaligned(t4k, dev, oracle):
+    rng = np.random.default_rng(1)
+    M, N, K, C = 20, 12, 9, 3
+    A = rng.uniform(-1, 1, (M, K, C)).astype(np.float32); B = rng.uniform(-1, 1, (K, N, C)).astype(np.float32)
+    ref = oracle.gemm(A, B, C=C)
+    dA, dB_, dO = dev.up(A), dev.up(B), dev.zeros((M, N, C))
+    t4k.call("t4k_gemm", p(dA), p(dB_), p(dO), 1.0, 0.0, 0, 0, M, N, K, C, None)
+    assert rel(dev.down(dO), ref) < RTOL
+    # operands at a 4-byte (not 16-byte) aligned address take the scalar-load path
+    M, N, K = 64, 64, 64
+    A = rng.uniform(-1, 1, (M * K + 1)).astype(np.float32); B = rng.uniform(-1, 1, (K * N + 1)).astype(np.float32)
+    ref = oracle.gemm(A[1:].reshape(M, K), B[1:].reshape(K, N))
+    dA, dB_, dO = dev.up(A), dev.up(B), dev.zeros((M, N))
+    t4k.call("t4k_gemm", p(dA) + 4, p(dB_) + 4, p(dO), 1.0, 0.0, 0, 0, M, N, K, 1, None)
+    assert rel(dev.down(dO), ref) < RTOL
+
+
+def test_gemm_1024_exact_on_integer_operands(t4k, dev):
+    """BASELINE config #2 at full size: small-integer operands make every fp32 partial sum
+    exact, so the MFMA result must equal the int64 product bit for bit, in any k order."""
+    rng = np.random.default_rng(1234)
+    A = rng.integers(-2, 3, (1024, 1024)).astype(np.float32); B = rng.integers(-2, 3, (1024, 1024)).astype(np.float32)
+    ref = (A.astype(np.int64) @ B.astype(np.int64)).astype(np.float32)
+    dA, dB_, dO = dev.up(A), dev.up(B), dev.zeros((1024, 1024))
+    t4k.call("t4k_gemm", p(dA), p(dB_), p(dO), 1.0, 0.0, 0, 0, 1024, 1024, 1024, 1, None)
+    assert np.array_equal(dev.down(dO), ref)
+    # linearity: gemm(A, B; alpha=2, beta=1 on previous result) == 3 * ref
+    t4k.call("t4k_gemm", p(dA), p(dB_), p(dO), 2.0, 1.0, 0, 0, 1024, 1024, 1024, 1, None)
+    assert np.array_equal(dev.down(dO), 3 * ref)
+    # the 128x128-tile variant (2048^2 output) on the same kind of data
+    A2 = rng.integers(-2, 3, (2048, 512)).astype(np.float32); B2 = rng.integers(-2, 3, (512, 2048)).astype(np.float32)
+    ref2 = (A2.astype(np.int64) @ B2.astype(np.int64)).astype(np.float32)
+    dA, dB_, dO = dev.up(A2), dev.up(B2), dev.zeros((2048, 2048))
+    t4k.call("t4k_gemm", p(dA), p(dB_), p(dO), 1.0, 0.0, 0, 0, 2048, 2048, 512, 1, None)
+    assert np.array_equal(dev.down(dO), ref2)
+
+
+def test_gemm_1024_uniform_vs_oracle(t4k, dev, oracle):
+    rng = np.random.default_rng(1234)
+    A = rng.uniform(0, 1, (1024, 1024)).astype(np.float32); B = rng.uniform(0, 1, (1024, 1024)).astype(np.float32)
+    ref = oracle.gemm(A, B)
+    dA, dB_, dO = dev.up(A), dev.up(B), dev.zeros((1024, 1024))
+    t4k.call("t4k_gemm", p(dA), p(dB_), p(dO), 1.0, 0.0, 0, 0, 1024, 1024, 1024, 1, None)
+    assert rel(dev.down(dO), ref) < 1e-5
+    dO2 = dev.zeros((1024, 1024))
+    t4k.call("t4k_gemm_f64acc", p(dA), p(dB_), p(dO2), 1.0, 0.0, 1024, 1024, 1024, 1, None)
+    assert rel(dev.down(dO2), ref) < 1e-5
+
+
+# ---------------------------------------------------------------- elementwise / reductions
+def test_elementwise_ops(t4k, dev, oracle):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(2)
+    for n in (1, 3, 1000, 100003):
+        x = rng.uniform(0.1, 2.0, n).astype(np.float32); y = rng.uniform(0.5, 2.0, n).astype(np.float32)
+        for op in (oracle.ABS, oracle.NEG, oracle.EXP, oracle.LN, oracle.LOG, oracle.TANH, oracle.RELU, oracle.SIGM,
+                   oracle.SQRT, oracle.RCP, oracle.SAT, oracle.FILL, oracle.GFILL, oracle.SCALE, oracle.POW,
+                   oracle.ADD, oracle.SUB, oracle.MUL, oracle.DIV):
+            a = (x - 1.0).copy() if op in (oracle.ABS, oracle.NEG, oracle.RELU, oracle.TANH, oracle.SAT) else x.copy()
+            d = dev.up(a); o.t4o_math(op, P(a), 1.5, n)
+            t4k.call("t4k_math", op, p(d), 1.5, n, None)
+            assert rel(dev.down(d), a) < RTOL, op
+        for op in (oracle.ADD, oracle.SUB, oracle.MUL, oracle.DIV):
+            r = np.zeros_like(x); o.t4o_tt_op(op, P(x), P(y), P(r), n)
+            dx, dy, dr = dev.up(x), dev.up(y), dev.zeros(n)
+            t4k.call("t4k_tt_op", op, p(dx), p(dy), p(dr), n, None)
+            assert np.array_equal(dev.down(dr), r)                 # single IEEE op: bit exact
+            o.t4o_ts_op(op, P(x), 0.3, P(r), n)
+            t4k.call("t4k_ts_op", op, p(dx), 0.3, p(dr), n, None)
+            assert np.array_equal(dev.down(dr), r)
+        dc = dev.zeros(n); t4k.call("t4k_copy", p(dev.up(x)), p(dc), n, None)
+        assert np.array_equal(dev.down(dc), x)
+    assert t4k.lib.t4k_math(99, p(dev.zeros(4)), 0.0, 4, None) == -4     # unsupported op reports, never aborts
+
+
+def test_transpose_identity_bit_exact(t4k, dev, oracle):
+    rng = np.random.default_rng(3)
+    for H, W, C in ((5, 7, 1), (64, 64, 1), (100, 130, 3), (1, 9, 2)):
+        a = rng.standard_normal((H, W, C)).astype(np.float32)
+        d, t = dev.up(a), dev.zeros((W, H, C))
+        t4k.call("t4k_transpose", p(d), p(t), H, W, C, None)
+        assert np.array_equal(dev.down(t), a.transpose(1, 0, 2))
+        e = dev.up(a); t4k.call("t4k_identity", p(e), H, W, C, None)
+        ref = np.zeros((H, W, C), np.float32)
+        for i in range(min(H, W)):
+            ref[i, i, :] = 1
+        assert np.array_equal(dev.down(e), ref)
+
+
+def test_reductions(t4k, dev, oracle):
+    rng = np.random.default_rng(4)
+    for n in (5, 1000, 65536, 1 << 20):
+        x = rng.standard_normal(n).astype(np.float32)
+        d, out = dev.up(x), dev.zeros(1)
+        t4k.call("t4k_reduce", oracle.RED_SUM, p(d), n, 0.0, p(out), None)
+        assert abs(dev.down(out)[0] - x.astype(np.float64).sum()) < 1e-4 * max(1.0, np.abs(x).sum())
+        avg = float(x.mean())
+        t4k.call("t4k_reduce", oracle.RED_NVAR, p(d), n, avg, p(out), None)
+        assert rel(dev.down(out)[0], ((x.astype(np.float64) - avg) ** 2).sum()) < RTOL
+        t4k.call("t4k_reduce", oracle.RED_MAX, p(d), n, 0.0, p(out), None); assert dev.down(out)[0] == x.max()
+        t4k.call("t4k_reduce", oracle.RED_MIN, p(d), n, 0.0, p(out), None); assert dev.down(out)[0] == x.min()
+    x[17] = np.nan; x[99] = np.inf
+    cnt = dev.zeros(1, dev.torch.int32)
+    t4k.call("t4k_nan_inf", p(dev.up(x)), x.size, p(cnt), None); assert dev.down(cnt)[0] == 2
+    # BCE
+    o = oracle.lib(); P = oracle.P
+    t = rng.integers(0, 2, 5000).astype(np.float32); y = rng.uniform(0.01, 0.99, 5000).astype(np.float32)
+    r = np.zeros(1, np.float32); o.t4o_bce(P(t), P(y), 5000, P(r)); out = dev.zeros(1)
+    t4k.call("t4k_bce", p(dev.up(t)), p(dev.up(y)), 5000, p(out), None)
+    assert rel(dev.down(out)[0], r[0]) < RTOL
+    # dot with channel stride
+    A = rng.standard_normal((300, 3)).astype(np.float32); B = rng.standard_normal((300, 3)).astype(np.float32)
+    O = np.ones(3, np.float32); dO = dev.up(O)
+    o.t4o_dot(P(A), P(B), P(O), 2.0, 0.5, 300, 3)
+    t4k.call("t4k_dot", p(dev.up(A)), p(dev.up(B)), p(dO), 2.0, 0.5, 300, 3, None)
+    assert rel(dev.down(dO), O) < RTOL
+
+
+# ------------------------------------------------------------------------------- nn
+@pytest.mark.parametrize("K,S,P_", [(1, 1, 0), (3, 1, 1), (4, 2, 1), (5, 1, 2)])
+@pytest.mark.parametrize("N,H1,C1,C0", [(2, 6, 2, 3), (3, 14, 10, 20), (4, 28, 1, 10)])
+def test_conv2d(t4k, dev, oracle, K, S, P_, N, H1, C1, C0):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(K + N)
+    I = rng.standard_normal((N, H1, H1, C1)).astype(np.float32)
+    F = rng.standard_normal((C1, K, K, C0)).astype(np.float32); B = rng.standard_normal(C0).astype(np.float32)
+    ref = oracle.conv2d_fwd(I, F, B, K, S, P_); H0 = ref.shape[1]
+    dI, dF, dB_, dO = dev.up(I), dev.up(F), dev.up(B), dev.zeros(ref.shape)
+    t4k.call("t4k_conv2d_fwd", p(dI), p(dO), p(dF), p(dB_), N, H1, H1, C1, H0, H0, C0, K, S, P_, None)
+    assert rel(dev.down(dO), ref) < RTOL
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    DX = np.zeros_like(I); DF = rng.standard_normal(F.shape).astype(np.float32); DB = rng.standard_normal(C0).astype(np.float32)
+    dDX, dDF, dDB, dg = dev.zeros(I.shape), dev.up(DF), dev.up(DB), dev.up(g)
+    o.t4o_conv2d_bwd(P(I), P(g), P(DX), P(F), P(DF), P(DB), N, H1, H1, C1, H0, H0, C0, K, S, P_, 1)
+    t4k.call("t4k_conv2d_bwd", p(dI), p(dg), p(dDX), p(dF), p(dDF), p(dDB), N, H1, H1, C1, H0, H0, C0, K, S, P_, 1, None)
+    assert rel(dev.down(dDX), DX) < RTOL and rel(dev.down(dDF), DF) < RTOL and rel(dev.down(dDB), DB) < RTOL
+    # train == 0 leaves DF/DB untouched
+    t4k.call("t4k_conv2d_bwd", p(dI), p(dg), p(dDX), p(dF), p(dDF), p(dDB), N, H1, H1, C1, H0, H0, C0, K, S, P_, 0, None)
+    assert rel(dev.down(dDF), DF) < RTOL
+
+
+def test_conv2d_unsupported_geometry_is_reported(t4k, dev):
+    z = dev.zeros(16)
+    assert t4k.lib.t4k_conv2d_fwd(p(z), p(z), p(z), p(z), 1, 4, 4, 1, 4, 4, 1, 7, 1, 3, None) == -4
+    assert b"not supported" in t4k.lib.t4k_last_error()
+
+
+@pytest.mark.parametrize("KS", [2, 3])
+@pytest.mark.parametrize("H1", [12, 7])
+def test_pool_and_dpool(t4k, dev, oracle, KS, H1):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(KS * H1)
+    N, C = 3, 5; H0 = (H1 + KS - 1) // KS
+    I = rng.standard_normal((N, H1, H1, C)).astype(np.float32)
+    dy = rng.standard_normal((N, H0, H0, C)).astype(np.float32)
+    for layer in (oracle.L_MAXPOOL, oracle.L_AVGPOOL, oracle.L_MINPOOL):
+        O = np.zeros((N, H0, H0, C), np.float32); o.t4o_pool(layer, P(I), P(O), N, H1, H1, H0, H0, C, KS)
+        dI, dO = dev.up(I), dev.zeros(O.shape)
+        t4k.call("t4k_pool", layer, p(dI), p(dO), N, H1, H1, H0, H0, C, KS, None)
+        got = dev.down(dO)
+        assert np.array_equal(got, O) if layer != oracle.L_AVGPOOL else rel(got, O) < 1e-6
+        X = I.copy(); o.t4o_dpool(layer, P(X), P(dy), N, H1, H1, H0, H0, C, KS)
+        t4k.call("t4k_dpool", layer, p(dI), p(dev.up(dy)), N, H1, H1, H0, H0, C, KS, None)
+        got = dev.down(dI)
+        assert np.array_equal(got, X) if layer != oracle.L_AVGPOOL else rel(got, X) < 1e-6
+
+
+def test_activations_softmax_bias(t4k, dev, oracle):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(6)
+    n = 12345
+    x = rng.standard_normal(n).astype(np.float32); r = rng.random(n).astype(np.float32)
+    for layer, alpha in ((oracle.L_RELU, 0), (oracle.L_TANH, 0), (oracle.L_SIGMOID, 0), (oracle.L_SELU, 0),
+                         (oracle.L_LEAKYRL, 0.01), (oracle.L_ELU, 1.0), (oracle.L_DROPOUT, 0.5)):
+        y = np.zeros_like(x); f = r.copy(); o.t4o_activate(layer, P(x), P(y), P(f), alpha, n)
+        dx, dy_, df = dev.up(x), dev.zeros(n), dev.up(r)
+        t4k.call("t4k_activate", layer, p(dx), p(dy_), p(df), alpha, n, None)
+        gy, gf = dev.down(dy_), dev.down(df)
+        if layer in (oracle.L_RELU, oracle.L_DROPOUT):
+            assert np.array_equal(gy, y) and np.array_equal(gf, f)          # masks are exact
+        else:
+            assert rel(gy, y) < RTOL and rel(gf, f) < RTOL
+    for N, C in ((128, 10), (5, 300), (1, 1)):
+        a = (rng.standard_normal((N, C)) * 4).astype(np.float32); y = np.zeros_like(a)
+        o.t4o_softmax(P(a), P(y), N, C); dy_ = dev.zeros((N, C))
+        t4k.call("t4k_softmax", p(dev.up(a)), p(dy_), N, C, None)
+        assert rel(dev.down(dy_), y) < RTOL
+    Y = rng.standard_normal((128, 100)).astype(np.float32); b = rng.standard_normal(100).astype(np.float32)
+    dY = dev.up(Y); o.t4o_bias(P(b), P(Y), 128, 100)
+    t4k.call("t4k_bias", p(dev.up(b)), p(dY), 128, 100, None)
+    assert np.array_equal(dev.down(dY), Y)
+
+
+@pytest.mark.parametrize("N,E0,E1", [(128, 100, 1960), (128, 10, 100), (3, 2, 2), (256, 512, 784)])
+def test_linear_fwd_bwd(t4k, dev, oracle, N, E0, E1):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N + E0)
+    X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(E0).astype(np.float32)
+    Y = np.zeros((N, E0), np.float32); o.t4o_linear_fwd(P(X), P(W), P(b), P(Y), N, E0, E1)
+    dX, dW, db, dY = dev.up(X), dev.up(W), dev.up(b), dev.zeros((N, E0))
+    t4k.call("t4k_linear_fwd", p(dX), p(dW), p(db), p(dY), N, E0, E1, None)
+    assert rel(dev.down(dY), Y) < RTOL
+    G = rng.standard_normal((N, E0)).astype(np.float32)
+    DW = rng.standard_normal((E0, E1)).astype(np.float32); DB = rng.standard_normal(E0).astype(np.float32)
+    DX = np.zeros_like(X)
+    dG, dDW, dDB = dev.up(G), dev.up(DW), dev.up(DB)
+    o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)
+    t4k.call("t4k_linear_bwd", p(dX), p(dW), p(dG), p(dX), p(dDW), p(dDB), N, E0, E1, 1, None)   # dX in place (as the host does)
+    assert rel(dev.down(dX), DX) < RTOL and rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL
+    DBo = DB.copy(); o.t4o_dlinear_db(P(G), P(DBo), N, E0)
+    t4k.call("t4k_dlinear_db", p(dG), p(dDB), N, E0, None)
+    assert rel(dev.down(dDB), DBo) < RTOL
+
+
+def test_batchnorm(t4k, dev, oracle):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(8)
+    N, HW, C = 8, 49, 6
+    x = (rng.standard_normal((N, HW, C)) * 2 + 1).astype(np.float32)
+    g = rng.standard_normal(C).astype(np.float32); b = rng.standard_normal(C).astype(np.float32)
+    y = np.zeros_like(x); xh = np.zeros_like(x); stat = np.zeros(3 * C, np.float32)
+    o.t4o_batchnorm_fwd(P(x), P(y), P(xh), P(g), P(b), P(stat), N, HW, C)
+    dx, dg, db, dy_, dxh, dst = dev.up(x), dev.up(g), dev.up(b), dev.zeros(x.shape), dev.zeros(x.shape), dev.zeros(3 * C)
+    t4k.call("t4k_batchnorm_fwd", p(dx), p(dy_), p(dxh), p(dg), p(db), p(dst), N, HW, C, None)
+    assert rel(dev.down(dy_), y) < RTOL and rel(dev.down(dxh), xh) < RTOL and rel(dev.down(dst)[:2 * C], stat[:2 * C]) < RTOL
+    gy = rng.standard_normal(x.shape).astype(np.float32)
+    DX = np.zeros_like(x); DW = np.ones(C, np.float32); DB = np.ones(C, np.float32)
+    o.t4o_batchnorm_bwd(P(g), P(gy), P(xh), P(DX), P(DW), P(DB), P(stat), N, HW, C, 1)
+    dDX, dDW, dDB = dev.zeros(x.shape), dev.up(np.ones(C, np.float32)), dev.up(np.ones(C, np.float32))
+    t4k.call("t4k_batchnorm_bwd", p(dg), p(dev.up(gy)), p(dxh), p(dDX), p(dDW), p(dDB), p(dst), N, HW, C, 1, None)
+    assert rel(dev.down(dDX), DX) < 5e-4 and rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL
+
+
+def test_optimizers_and_multi_tensor_step(t4k, dev, oracle):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(9)
+    n = 197210                                                     # C128 parameter count (SURVEY a-18)
+    w = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+    m = (rng.standard_normal(n) * 0.1).astype(np.float32); v = (np.abs(rng.standard_normal(n)) * 0.1).astype(np.float32)
+    for kind in ("sgd0", "sgdm", "adam", "adamw"):
+        W, G, M, V = w.copy(), g.copy(), m.copy(), v.copy()
+        dW, dG, dM, dV = dev.up(w), dev.up(g), dev.up(m), dev.up(v)
+        if kind == "sgd0":
+            o.t4o_sgd(P(W), P(G), P(M), 3, 0.01, 0.0, n); t4k.call("t4k_sgd", p(dW), p(dG), p(dM), 3, 0.01, 0.0, n, None)
+        elif kind == "sgdm":
+            o.t4o_sgd(P(W), P(G), P(M), 1, 0.01, 0.9, n); t4k.call("t4k_sgd", p(dW), p(dG), p(dM), 1, 0.01, 0.9, n, None)
+        elif kind == "adam":
+            o.t4o_adam(P(W), P(G), P(M), P(V), 1e-3, 0.9, 0.999, n); t4k.call("t4k_adam", p(dW), p(dG), p(dM), p(dV), 1e-3, 0.9, 0.999, n, None)
+        else:
+            o.t4o_adamw(P(W), P(G), P(M), P(V), 1e-3, 0.9, 0.999, 0.01, n); t4k.call("t4k_adamw", p(dW), p(dG), p(dM), p(dV), 1e-3, 0.9, 0.999, 0.01, n, None)
+        assert rel(dev.down(dW), W) < 1e-5 and rel(dev.down(dM), M) < 1e-5 and rel(dev.down(dV), V) < 1e-5
+        assert not dev.down(dG).any()                               # gradients zeroed by the step
+    # multi-tensor launch == per-tensor launches
+    sizes = [90, 10, 196000, 100, 1000, 10]
+    import struct
+    bufs = []; recs = b""
+    for i, sz in enumerate(sizes):
+        W = rng.standard_normal(sz).astype(np.float32); G = rng.standard_normal(sz).astype(np.float32)
+        dW, dG, dM, dV = dev.up(W), dev.up(G), dev.zeros(sz), dev.zeros(sz)
+        M = np.zeros(sz, np.float32); V = np.zeros(sz, np.float32)
+        o.t4o_adam(P(W), P(G), P(M), P(V), 1e-3, 0.9, 0.999, sz)
+        bufs.append((dW, dG, dM, dV, W))
+        recs += struct.pack("<QQQQqii", p(dW), p(dG), p(dM), p(dV), sz, 1, 0)
+    tab = dev.up(np.frombuffer(recs, np.uint8))
+    t4k.call("t4k_opt_multi", 1, p(tab), len(sizes), max(sizes), 1e-3, 0.9, 0.999, 0.0, None)
+    for dW, dG, dM, dV, W in bufs:
+        assert rel(dev.down(dW), W) < 1e-5 and not dev.down(dG).any()
+
+
+def test_onehot_hit_u8(t4k, dev, oracle):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(10)
+    N, E = 128, 10
+    lab = rng.integers(0, 12, N).astype(np.uint32)                  # some labels >= classes -> class 0
+    hot = np.zeros((N, E), np.float32); o.t4o_onehot(P(lab), P(hot), N, E)
+    dhot = dev.zeros((N, E)); dlab = dev.up(lab.view(np.int32))
+    t4k.call("t4k_onehot", p(dlab), p(dhot), N, E, None)
+    assert np.array_equal(dev.down(dhot), hot)
+    out = rng.standard_normal((N, E)).astype(np.float32); out[5, 3] = out[5, 7] = 9.0     # tie: first max wins
+    c = ctypes.c_int(0); o.t4o_hit(P(out), P(hot), N, E, ctypes.byref(c))
+    dc = dev.zeros(1, dev.torch.int32)
+    t4k.call("t4k_hit", p(dev.up(out)), p(dhot), N, E, p(dc), None)
+    assert int(dev.down(dc)[0]) == c.value
+    u8 = rng.integers(0, 256, 128 * 784).astype(np.uint8); ref = np.zeros(u8.size, np.float32)
+    o.t4o_u8_normalize(P(u8), P(ref), u8.size, 128.0, 1 / 128.0)
+    d = dev.zeros(u8.size); t4k.call("t4k_u8_normalize", p(dev.up(u8)), p(d), u8.size, 128.0, 1 / 128.0, None)
+    assert np.array_equal(dev.down(d), ref)
+
+
+def test_rand_matches_oracle_stream(t4k, dev, oracle):
+    o = oracle.lib(); P = oracle.P
+    for n in (1, 5, 4096, 100001):
+        o.t4o_rand_init(777); t4k.call("t4k_rand_init", 777)
+        a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+        o.t4o_rand(P(a), n, 0, -0.5, 0.2); o.t4o_rand(P(b), n, 1, 0.0, 1.0)
+        da, db = dev.zeros(n), dev.zeros(n)
+        t4k.call("t4k_rand", p(da), n, 0, -0.5, 0.2, None); t4k.call("t4k_rand", p(db), n, 1, 0.0, 1.0, None)
+        assert np.array_equal(dev.down(da), a)                       # integer stream + one fma: bit exact
+        assert np.max(np.abs(dev.down(db) - b)) < 1e-4               # Box-Muller: libm vs device ulps
+        assert t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
+
+
+def test_linear_algebra(t4k, dev, oracle):
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(11)
+    for K in (3, 4, 17, 64):
+        A = (rng.standard_normal((K, K)) + np.eye(K) * 2).astype(np.float32)
+        a, I = A.copy(), np.eye(K, dtype=np.float32); st = ctypes.c_int(0)
+        o.t4o_inverse(P(a), P(I), K, ctypes.byref(st))
+        dA, dI, dst = dev.up(A), dev.up(np.eye(K, dtype=np.float32)), dev.zeros(1, dev.torch.int32)
+        t4k.call("t4k_inverse", p(dA), p(dI), K, p(dst), None)
+        assert dev.down(dst)[0] == 0 and rel(dev.down(dI), I) < 1e-3
+        a, I, piv = A.copy(), np.eye(K, dtype=np.float32), np.zeros(K, np.int32)
+        o.t4o_lu_inverse(P(a), P(I), P(piv), K, ctypes.byref(st))
+        dA, dI, dpiv = dev.up(A), dev.up(np.eye(K, dtype=np.float32)), dev.zeros(K, dev.torch.int32)
+        t4k.call("t4k_lu_inverse", p(dA), p(dI), p(dpiv), K, p(dst), None)
+        assert np.array_equal(dev.down(dpiv), piv) and rel(dev.down(dI), I) < 1e-3 and rel(dev.down(dA), a) < 1e-3
+        ld = np.zeros(1, np.float32); sg = ctypes.c_int(0); o.t4o_logdet(P(a), K, P(ld), ctypes.byref(sg))
+        dld, dsg = dev.zeros(1), dev.zeros(1, dev.torch.int32)
+        t4k.call("t4k_logdet", p(dA), K, p(dld), p(dsg), None)
+        assert abs(dev.down(dld)[0] - ld[0]) < 1e-3 and dev.down(dsg)[0] == sg.value
+        for get_u in (0, 1):
+            ref = a.copy(); o.t4o_lu_extract(P(ref), get_u, K)
+            d = dev.up(a); t4k.call("t4k_lu_extract", p(d), get_u, K, None)
+            assert np.array_equal(dev.down(d), ref)
+    sing = np.array([[1, 2], [2, 4]], np.float32)
+    dst = dev.zeros(1, dev.torch.int32)
+    t4k.call("t4k_inverse", p(dev.up(sing)), p(dev.up(np.eye(2, dtype=np.float32))), 2, p(dst), None)
+    assert dev.down(dst)[0] == 2
+
+
+def test_graph_capture_replays_a_launch_sequence(t4k, dev):
+    """hipGraph capture of t4k launches on a private stream (the step-graph mechanism)."""
+    s = ctypes.c_void_p(); t4k.call("t4k_stream_create", ctypes.byref(s))
+    x = dev.up(np.ones(1000, np.float32)); dev.h.call("t4k_sync", None)
+    g = ctypes.c_void_p()
+    t4k.call("t4k_graph_begin", s)
+    t4k.call("t4k_math", 14, p(x), 2.0, 1000, s)          # SCALE by 2
+    t4k.call("t4k_math", 16, p(x), 1.0, 1000, s)          # ADD 1
+    t4k.call("t4k_graph_end", s, ctypes.byref(g))
+    for _ in range(3):
+        t4k.call("t4k_graph_launch", g, s)
+    t4k.call("t4k_sync", s)
+    assert np.all(x.cpu().numpy() == 15.0)                # ((1*2+1)*2+1)*2+1
+    t4k.call("t4k_graph_destroy", g); t4k.call("t4k_stream_destroy", s)
