@@ -43,6 +43,8 @@ class Model:
         self.k = load()
         self.k.init(self.dev.index or 0)
         self.s = stream                      # None -> library default stream
+        if stream is None:                   # share torch's (null) stream: torch allocs/copies and
+            self.k.call("t4k_set_default_stream", None)   # RCCL collectives order with our launches
         self.t = [self._zeros((n, h, w, c))]
         self.layers = []
         self.train = True
