@@ -24,6 +24,11 @@ class T4K:
         if not os.path.exists(path):
             raise T4KError("libt4hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
         self.path = path
+        try:                      # one HIP runtime per process: if torch is around, let it load its
+            import torch          # bundled libamdhip64 first so libt4hip.so binds to the same one
+            torch.cuda.is_available()
+        except Exception:
+            pass
         self.lib = ctypes.CDLL(path)
         self.decls = _cabi.parse_header(os.path.join(root_dir(), "include", "t4k.h"), "t4k_")
         self.missing = _cabi.bind(self.lib, self.decls)
