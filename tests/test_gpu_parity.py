@@ -23,13 +23,19 @@ class Dev:
         self.torch = torch
         self.h = t4k
         t4k.call("t4k_set_default_stream", None)        # legacy null stream == torch's default stream
+        self.keep = []      # hold every buffer: `p(dev.up(x))` temporaries must not be recycled mid-call
 
     def up(self, a, dtype=None):
-        t = self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        t = self.torch.from_numpy(np.array(a, copy=True)).cuda()
+        self.keep.append(t)
+        if len(self.keep) > 4000:
+            del self.keep[:2000]
         return t
 
     def zeros(self, shape, dtype=None):
-        return self.torch.zeros(shape, dtype=dtype or self.torch.float32, device="cuda")
+        t = self.torch.zeros(shape, dtype=dtype or self.torch.float32, device="cuda")
+        self.keep.append(t)
+        return t
 
     def down(self, t):
         self.h.call("t4k_sync", None)
