@@ -1,11 +1,19 @@
-// conv.hip - conv2d forward / backward and pooling for NHWC fp32 tensors.
+// conv.hip - conv2d forward / backward as implicit GEMMs on the gfx950 matrix cores
+// (v_mfma_f32_32x32x2_f32), plus pooling, for NHWC fp32 tensors.
 // Reference: k_conv2d / k_dconv2d / k_pool / k_dpool, src/nn/nmath.tcu:34-568;
 // host wrappers Model::_fconv src/nn/forward.cu:125-155, Model::_bconv src/nn/backprop.cu:152-191.
 //
-// Round-1 kernels (direct, VALU): the filter index is wave-uniform so filter taps are read
-// through the scalar cache; every output is written exactly once (no memset + fp32
-// atomicAdd over c1 as in the reference), dF/dB are reduced deterministically through
-// workspace partials.  An MFMA implicit-GEMM path replaces the hot variants later.
+// The reference launches one 16x16 block per (n, c1, c0) plane tile, re-stages the same input
+// patch for every c0 and accumulates across c1 with fp32 atomicAdd into a pre-zeroed output.
+// Here each of the three contractions is one dense MFMA GEMM whose A operand is gathered on the
+// fly (implicit im2col):
+//   forward  O [pix0 , c0]  = sum_{ky,kx,c1} I [pix0 shifted, c1] * F [c1,ky,kx,c0]      (+ bias)
+//   dX       dX[pix1 , c1]  = sum_{ky,kx,c0} dO[pix1 shifted, c0] * F [c1,K-1-ky,K-1-kx,c0]
+//   dF|dB    dF[tap  , c0] += sum_{pix0}     I [pix0 shifted by tap] * dO[pix0, c0]   (row `ntaps` = dB)
+// One wave owns a 32 (pixels or taps) x 32 (channels) accumulator.  The filter slice is staged in
+// LDS in MFMA-B order; the k-pair of one MFMA is two adjacent channels of the same tap, so the two
+// lane halves read adjacent floats.  Every output element is written once (no memset, no atomics);
+// dF/dB are reduced wave -> workgroup (LDS) -> workspace slabs -> one fold launch, in fixed order.
 #include "t4k_common.h"
 #include <float.h>
 
@@ -13,115 +21,163 @@ using namespace t4k;
 
 namespace {
 
-// ------------------------------------------------------------------ forward
-// one thread = one output pixel x CT output channels
-template <int K, int S, int P, int CT>
-__global__ void __launch_bounds__(BLK) k_conv_fwd(const float *__restrict__ I, float *__restrict__ O,
-                                                  const float *__restrict__ F, const float *__restrict__ B,
-                                                  int N, int H1, int W1, int C1, int H0, int W0, int C0) {
-    const long npix = (long)N * H0 * W0;
-    const long pix = (long)blockIdx.x * BLK + threadIdx.x;
-    if (pix >= npix) return;
-    const int j0 = (int)(pix % W0), i0 = (int)((pix / W0) % H0), n = (int)(pix / ((long)W0 * H0));
-    const float *nI = I + (long)n * H1 * W1 * C1;
-    for (int c0b = blockIdx.y * CT; c0b < C0; c0b += gridDim.y * CT) {
-        float acc[CT];
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LDS_FILTER_FLOATS = 8192;          // 32 KiB filter slice per workgroup
+
+// ------------------------------------------------------------------ forward / dX gather-GEMM
+// BWD = false: forward (Cin = C1 of I, Cout = C0);  BWD = true: dX (Cin = C0 of dO, Cout = C1)
+template <int K, int S, int P, bool BWD>
+__global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, float *__restrict__ Y,
+                                                   const float *__restrict__ F, const float *__restrict__ B,
+                                                   int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout,
+                                                   int C0 /* filter inner dim */, int pairs_per_chunk) {
+    __shared__ float Bl[LDS_FILTER_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const long npix = (long)N * Hy * Wy;
+    const long tile = (long)blockIdx.x * 4 + w;
+    const long pix  = tile * 32 + l31;                       // this lane's A-row pixel
+    const int  co0  = blockIdx.y * 32;                       // output-channel tile
+    const bool pok  = pix < npix;
+    int jy = 0, iy = 0, n = 0;
+    if (pok) { jy = (int)(pix % Wy); long t = pix / Wy; iy = (int)(t % Hy); n = (int)(t / Hy); }
+    const float *nX = X + (long)n * Hx * Wx * Cin;
+
+    f32x16 acc;
 #pragma unroll
-        for (int t = 0; t < CT; t++) acc[t] = (c0b + t < C0) ? B[c0b + t] : 0.f;
-        for (int c1 = 0; c1 < C1; c1++) {
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+
+    const int npairs = (Cin + 1) >> 1;
+    for (int cp0 = 0; cp0 < npairs; cp0 += pairs_per_chunk) {
+        const int cpn = min(pairs_per_chunk, npairs - cp0);
+        // ---- stage the filter slice: Bl[((cp*K+ky)*K+kx)*2+hh][col] ----
+        __syncthreads();
+        const int nent = cpn * K * K * 2 * 32;
+        for (int e = tid; e < nent; e += 256) {
+            const int col = e & 31; int t = e >> 5;
+            const int hh = t & 1; t >>= 1;
+            const int kx = t % K; t /= K; const int ky = t % K; const int cp = t / K;
+            const int ci = 2 * (cp0 + cp) + hh, co = co0 + col;
+            float v = 0.f;
+            if (ci < Cin && co < Cout) {
+                if (!BWD) v = F[((long)(ci * K + ky) * K + kx) * C0 + co];                          // F[c1=ci][ky][kx][c0=co]
+                else      v = F[((long)(co * K + (K - 1 - ky)) * K + (K - 1 - kx)) * C0 + ci];      // F[c1=co][flip][c0=ci]
+            }
+            Bl[e] = v;
+        }
+        __syncthreads();
+        for (int cp = 0; cp < cpn; cp++) {
+            const int ci = 2 * (cp0 + cp) + h;
+            const bool cok = pok && ci < Cin;
 #pragma unroll
             for (int ky = 0; ky < K; ky++) {
-                const int gi = i0 * S + ky - P;
+                int gi; bool iok;
+                if (!BWD) { gi = iy * S + ky - P; iok = gi >= 0 && gi < Hx; }
+                else { const int ti = iy + P - ky; gi = ti / S; iok = ti >= 0 && (ti % S) == 0 && gi < Hx; }
 #pragma unroll
                 for (int kx = 0; kx < K; kx++) {
-                    const int gj = j0 * S + kx - P;
-                    const float v = (gi >= 0 && gi < H1 && gj >= 0 && gj < W1) ? nI[((long)W1 * gi + gj) * C1 + c1] : 0.f;
-                    const float *f = F + ((long)(c1 * K + ky) * K + kx) * C0 + c0b;     // wave-uniform
-#pragma unroll
-                    for (int t = 0; t < CT; t++) if (c0b + t < C0) acc[t] = fmaf(f[t], v, acc[t]);
+                    int gj; bool jok;
+                    if (!BWD) { gj = jy * S + kx - P; jok = gj >= 0 && gj < Wx; }
+                    else { const int tj = jy + P - kx; gj = tj / S; jok = tj >= 0 && (tj % S) == 0 && gj < Wx; }
+                    const float a = (cok && iok && jok) ? nX[((long)gi * Wx + gj) * Cin + ci] : 0.f;
+                    const float b = Bl[(((cp * K + ky) * K + kx) * 2 + h) * 32 + l31];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
                 }
             }
         }
-        float *o = O + pix * C0 + c0b;
-#pragma unroll
-        for (int t = 0; t < CT; t++) if (c0b + t < C0) o[t] = acc[t];
     }
-}
-
-// ------------------------------------------------------------------ backward: dX
-// gather form of the reference's scatter: dX[gi,gj,c1] = sum over (ky,kx,c0) with
-// i0*S+ky-P == gi, j0*S+kx-P == gj of F[c1,K-1-ky,K-1-kx,c0] * dO[i0,j0,c0]   (flipped index,
-// nmath.tcu:304-305)
-template <int K, int S, int P, int CT>
-__global__ void __launch_bounds__(BLK) k_conv_dx(const float *__restrict__ DO, float *__restrict__ DX,
-                                                 const float *__restrict__ F,
-                                                 int N, int H1, int W1, int C1, int H0, int W0, int C0) {
-    const long npix = (long)N * H1 * W1;
-    const long pix = (long)blockIdx.x * BLK + threadIdx.x;
-    if (pix >= npix) return;
-    const int gj = (int)(pix % W1), gi = (int)((pix / W1) % H1), n = (int)(pix / ((long)W1 * H1));
-    const float *nO = DO + (long)n * H0 * W0 * C0;
-    for (int c1b = blockIdx.y * CT; c1b < C1; c1b += gridDim.y * CT) {
-        float acc[CT];
+    // ---- epilogue: D[row = pixel][col = channel]; col = lane&31, row = (r&3)+8*(r>>2)+4*h
+    const int co = co0 + l31;
+    if (co < Cout) {
+        const float bias = (!BWD && B) ? B[co] : 0.f;
 #pragma unroll
-        for (int t = 0; t < CT; t++) acc[t] = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < K; ky++) {
-            const int ti = gi + P - ky;
-            if (ti < 0 || (ti % S) != 0) continue;
-            const int i0 = ti / S; if (i0 >= H0) continue;
-#pragma unroll
-            for (int kx = 0; kx < K; kx++) {
-                const int tj = gj + P - kx;
-                if (tj < 0 || (tj % S) != 0) continue;
-                const int j0 = tj / S; if (j0 >= W0) continue;
-                const float *d = nO + ((long)W0 * i0 + j0) * C0;
-                const int fo = ((K - 1 - ky) * K + (K - 1 - kx)) * C0;
-                for (int c0 = 0; c0 < C0; c0++) {
-                    const float dv = d[c0];
-#pragma unroll
-                    for (int t = 0; t < CT; t++)
-                        if (c1b + t < C1) acc[t] = fmaf(F[(long)(c1b + t) * K * K * C0 + fo + c0], dv, acc[t]);
-                }
-            }
+        for (int r = 0; r < 16; r++) {
+            const long p2 = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (p2 < npix) Y[p2 * Cout + co] = acc[r] + bias;
         }
-        float *o = DX + pix * C1 + c1b;
-#pragma unroll
-        for (int t = 0; t < CT; t++) if (c1b + t < C1) o[t] = acc[t];
     }
 }
 
-// ------------------------------------------------------------------ backward: dF partials
-// thread = one filter element (c1,ky,kx,c0); block.x = chunk of output pixels
+// ------------------------------------------------------------------ dF | dB
+// grid = (slices, m_tiles, c0_tiles); each wave accumulates D[tap][c0] over its output rows
 template <int K, int S, int P>
-__global__ void __launch_bounds__(BLK) k_conv_df(const float *__restrict__ I, const float *__restrict__ DO,
-                                                 float *__restrict__ part,
-                                                 int N, int H1, int W1, int C1, int H0, int W0, int C0,
-                                                 long npix, int pix_per_chunk) {
-    const int nf = C1 * K * K * C0;
-    const int fi = blockIdx.y * BLK + threadIdx.x;
-    if (fi >= nf) return;
-    const int c0 = fi % C0, kx = (fi / C0) % K, ky = (fi / (C0 * K)) % K, c1 = fi / (C0 * K * K);
-    const long p0 = (long)blockIdx.x * pix_per_chunk;
-    const long p1 = min(npix, p0 + pix_per_chunk);
-    float acc = 0.f;
-    for (long pix = p0; pix < p1; pix++) {
-        const int j0 = (int)(pix % W0), i0 = (int)((pix / W0) % H0), n = (int)(pix / ((long)W0 * H0));
-        const int gi = i0 * S + ky - P, gj = j0 * S + kx - P;
-        if (gi >= 0 && gi < H1 && gj >= 0 && gj < W1)
-            acc = fmaf(I[(((long)n * H1 + gi) * W1 + gj) * C1 + c1], DO[pix * C0 + c0], acc);
+__global__ void __launch_bounds__(256) k_conv_df_mfma(const float *__restrict__ I, const float *__restrict__ DO,
+                                                      float *__restrict__ part,
+                                                      int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                                                      int rows_per_wave) {
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int ntaps = C1 * K * K;                           // row `ntaps` is the bias row (all ones)
+    const int tap = blockIdx.y * 32 + l31;
+    const int co  = blockIdx.z * 32 + l31;
+    int c1 = 0, ky = 0, kx = 0;
+    const bool is_tap = tap < ntaps, is_bias = tap == ntaps;
+    if (is_tap) { kx = tap % K; ky = (tap / K) % K; c1 = tap / (K * K); }
+    const bool cok = co < C0;
+    const int rows = N * H0;
+    const int row_beg = (blockIdx.x * 4 + w) * rows_per_wave;
+    const int row_end = min(rows, row_beg + rows_per_wave);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+
+    for (int row = row_beg; row < row_end; row++) {
+        const int n = row / H0, i0 = row - n * H0;          // wave-uniform
+        const int gi = i0 * S + ky - P;
+        const bool iok = is_tap && gi >= 0 && gi < H1;
+        const float *rI = I + (((long)n * H1 + gi) * W1) * C1 + c1;
+        const float *rO = DO + ((long)row * W0) * C0 + co;
+        for (int it = 0; it < (W0 + 1) / 2; it++) {         // wave-uniform trip count; lane half h takes pixel 2*it + h
+            const int j0 = 2 * it + h;
+            const bool jv = j0 < W0;
+            const int gj = j0 * S + kx - P;
+            float a = 0.f;
+            if (jv) { if (is_bias) a = 1.f; else if (iok && gj >= 0 && gj < W1) a = rI[(long)gj * C1]; }
+            const float b = (jv && cok) ? rO[(long)j0 * C0] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
     }
-    part[(long)blockIdx.x * nf + fi] = acc;
+    // wave -> workgroup reduction through LDS, then one slab entry per (slice, tap, c0)
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[r];
+    __syncthreads();
+    const int nrow1 = ntaps + 1;
+    for (int e = tid; e < 1024; e += 256) {
+        const int tr = e >> 5, tc = e & 31;
+        const int gt = blockIdx.y * 32 + tr, gc = blockIdx.z * 32 + tc;
+        if (gt < nrow1 && gc < C0)
+            part[((long)blockIdx.x * nrow1 + gt) * C0 + gc] = (red[0][tr][tc] + red[1][tr][tc]) + (red[2][tr][tc] + red[3][tr][tc]);
+    }
 }
-// OUT[i] += sum_chunk part[chunk][i]   (chunk ascending: deterministic)
+// fold the slabs in slice order: DF[i] += ..., DB[c0] += ...   (64 outputs x 4 slice-groups per block)
+__global__ void __launch_bounds__(256) k_conv_df_fold(const float *__restrict__ part, float *DF, float *DB,
+                                                      int nslice, int ndf, int ntot) {
+    __shared__ float sm[4][64];
+    const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + ex;
+    float s = 0.f;
+    if (i < ntot) {
+#pragma unroll 8
+        for (int k = g; k < nslice; k += 4) s += part[(long)k * ntot + i];
+    }
+    sm[g][ex] = s;
+    __syncthreads();
+    if (g == 0 && i < ntot) {
+        const float t = (sm[0][ex] + sm[1][ex]) + (sm[2][ex] + sm[3][ex]);
+        if (i < ndf) DF[i] += t; else DB[i - ndf] += t;
+    }
+}
+
+// ------------------------------------------------------------------ generic column sums (dlinear_db)
 __global__ void __launch_bounds__(BLK) k_fold_add(const float *__restrict__ part, float *OUT, int n, int nchunk) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nchunk; k++) s += part[(long)k * n + i];
     OUT[i] += s;
 }
-// column sums: part[chunk][e] = sum over rows of the chunk of X[row][e]
 __global__ void __launch_bounds__(BLK) k_colsum_part(const float *__restrict__ X, float *__restrict__ part,
                                                      long rows, int E, int rows_per_chunk, float *direct) {
     __shared__ float sm[4][64];
@@ -129,7 +185,10 @@ __global__ void __launch_bounds__(BLK) k_colsum_part(const float *__restrict__ X
     const int e = blockIdx.y * 64 + ex;
     const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float acc = 0.f;
-    if (e < E) for (long r = r0 + ry; r < r1; r += 4) acc += X[r * E + e];
+    if (e < E) {
+#pragma unroll 4
+        for (long r = r0 + ry; r < r1; r += 4) acc += X[r * E + e];
+    }
     sm[ry][ex] = acc;
     __syncthreads();
     if (ry == 0 && e < E) {
@@ -199,21 +258,25 @@ bool conv_supported(int K, int S, int P) {
            (K == 4 && S == 2 && P == 1) || (K == 5 && S == 1 && P == 2);
 }
 
-#define CONV_DISPATCH(KERN, CT, ...)                                                             \
-    switch ((K << 8) | (S << 4) | P) {                                                           \
-    case 0x110: hipLaunchKernelGGL((KERN<1, 1, 0, CT>), g, dim3(BLK), 0, hs, __VA_ARGS__); break; \
-    case 0x311: hipLaunchKernelGGL((KERN<3, 1, 1, CT>), g, dim3(BLK), 0, hs, __VA_ARGS__); break; \
-    case 0x421: hipLaunchKernelGGL((KERN<4, 2, 1, CT>), g, dim3(BLK), 0, hs, __VA_ARGS__); break; \
-    case 0x512: hipLaunchKernelGGL((KERN<5, 1, 2, CT>), g, dim3(BLK), 0, hs, __VA_ARGS__); break; \
+template <bool BWD>
+void launch_conv_gemm(int K, int S, int P, dim3 g, hipStream_t hs, const float *X, float *Y, const float *F, const float *B,
+                      int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0) {
+    const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);            // channel pairs per LDS filter slice
+    switch ((K << 8) | (S << 4) | P) {
+    case 0x110: hipLaunchKernelGGL((k_conv_gemm<1, 1, 0, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x311: hipLaunchKernelGGL((k_conv_gemm<3, 1, 1, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x421: hipLaunchKernelGGL((k_conv_gemm<4, 2, 1, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x512: hipLaunchKernelGGL((k_conv_gemm<5, 1, 2, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
     }
+}
 
 } // namespace
 
 namespace t4k {
-// shared with fused.hip / reduce users: OUT[e] += sum_rows X[row][e], deterministic two-stage
+// OUT[e] += sum_rows X[row][e], deterministic (used by t4k_linear_bwd / t4k_dlinear_db)
 int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs) {
     if (rows <= 0 || E <= 0) return T4K_OK;
-    long want = (rows + 1023) / 1024; if (want > 256) want = 256; if (want < 1) want = 1;
+    long want = (rows + 1023) / 1024; if (want > 64) want = 64; if (want < 1) want = 1;
     const int rpc = (int)((rows + want - 1) / want);
     const int nchunk = (int)((rows + rpc - 1) / rpc);
     float *part = (float *)st().ws + (8 << 20);            // second 32 MiB half of the workspace
@@ -236,12 +299,10 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
     T4K_REQUIRE_INIT();
     if (!conv_supported(K, S, P))
         return fail(T4K_ERR_UNSUPPORTED, "nn#fconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
-    if (!I || !O || !F || !B || N <= 0 || C0 <= 0 || C1 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_fwd: bad argument");
-    hipStream_t hs = t4k::S(s);
+    if (!I || !O || !F || !B || N <= 0 || C0 <= 0 || C1 <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_fwd: bad argument");
     const long npix = (long)N * H0 * W0;
-    dim3 g((unsigned)((npix + BLK - 1) / BLK), 1);
-    if (C0 <= 16) { CONV_DISPATCH(k_conv_fwd, 16, I, O, F, B, N, H1, W1, C1, H0, W0, C0) }
-    else          { CONV_DISPATCH(k_conv_fwd, 32, I, O, F, B, N, H1, W1, C1, H0, W0, C0) }
+    dim3 g((unsigned)((npix + 127) / 128), (unsigned)((C0 + 31) / 32));
+    launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }
@@ -252,33 +313,33 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, f
     T4K_REQUIRE_INIT();
     if (!conv_supported(K, S, P))
         return fail(T4K_ERR_UNSUPPORTED, "nn#bconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
-    if (!I || !DO || !DX || !F || N <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: bad argument");
+    if (!I || !DO || !DX || !F || N <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: bad argument");
     hipStream_t hs = t4k::S(s);
-    const long npix0 = (long)N * H0 * W0, npix1 = (long)N * H1 * W1;
     if (train) {
         if (!DF || !DB) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: train needs DF/DB");
-        // dB[c0] += sum dO ; dF += sum I*dO  (before dX is written: DX may alias I in the host layer)
-        int rc = colsum_add(DO, DB, npix0, C0, hs); if (rc) return rc;
-        const int nf = C1 * K * K * C0;
-        long want = (npix0 + 255) / 256; if (want > 512) want = 512; if (want < 1) want = 1;
-        const int ppc = (int)((npix0 + want - 1) / want);
-        const int nchunk = (int)((npix0 + ppc - 1) / ppc);
+        // dF | dB first: they read I, which the host layer may let DX overwrite
+        const int ntaps = C1 * K * K, nrow1 = ntaps + 1;
+        const int rows = N * H0;
+        int nslice = (rows + 3) / 4; if (nslice > 128) nslice = 128; if (nslice < 1) nslice = 1;
+        const int rpw = (rows + nslice * 4 - 1) / (nslice * 4);
+        nslice = (rows + rpw * 4 - 1) / (rpw * 4);
         float *part = (float *)st().ws;
-        if ((size_t)nchunk * nf * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "conv dF workspace");
-        dim3 g(nchunk, (nf + BLK - 1) / BLK);
+        if ((size_t)nslice * nrow1 * C0 * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "conv dF workspace");
+        dim3 g(nslice, (nrow1 + 31) / 32, (C0 + 31) / 32);
         switch ((K << 8) | (S << 4) | P) {
-        case 0x110: hipLaunchKernelGGL((k_conv_df<1, 1, 0>), g, dim3(BLK), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, npix0, ppc); break;
-        case 0x311: hipLaunchKernelGGL((k_conv_df<3, 1, 1>), g, dim3(BLK), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, npix0, ppc); break;
-        case 0x421: hipLaunchKernelGGL((k_conv_df<4, 2, 1>), g, dim3(BLK), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, npix0, ppc); break;
-        case 0x512: hipLaunchKernelGGL((k_conv_df<5, 1, 2>), g, dim3(BLK), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, npix0, ppc); break;
+        case 0x110: hipLaunchKernelGGL((k_conv_df_mfma<1, 1, 0>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
+        case 0x311: hipLaunchKernelGGL((k_conv_df_mfma<3, 1, 1>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
+        case 0x421: hipLaunchKernelGGL((k_conv_df_mfma<4, 2, 1>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
+        case 0x512: hipLaunchKernelGGL((k_conv_df_mfma<5, 1, 2>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
         }
-        hipLaunchKernelGGL(k_fold_add, dim3((nf + BLK - 1) / BLK), dim3(BLK), 0, hs, part, DF, nf, nchunk);
+        const int ntot = nrow1 * C0;
+        hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 63) / 64), dim3(256), 0, hs, part, DF, DB, nslice, ntaps * C0, ntot);
     }
     {
-        dim3 g((unsigned)((npix1 + BLK - 1) / BLK), 1);
-        if (C1 <= 4)       { CONV_DISPATCH(k_conv_dx, 4,  DO, DX, F, N, H1, W1, C1, H0, W0, C0) }
-        else if (C1 <= 16) { CONV_DISPATCH(k_conv_dx, 16, DO, DX, F, N, H1, W1, C1, H0, W0, C0) }
-        else               { CONV_DISPATCH(k_conv_dx, 32, DO, DX, F, N, H1, W1, C1, H0, W0, C0) }
+        const long npix1 = (long)N * H1 * W1;
+        dim3 g((unsigned)((npix1 + 127) / 128), (unsigned)((C1 + 31) / 32));
+        // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1)
+        launch_conv_gemm<true>(K, S, P, g, hs, DO, DX, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0);
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;
@@ -290,8 +351,8 @@ int t4k_pool(int layer, const float *I, float *O, int N, int H1, int W1, int H0,
     if (layer != T4K_L_AVGPOOL && layer != T4K_L_MAXPOOL && layer != T4K_L_MINPOOL && layer != T4K_L_USAMPLE)
         return fail(T4K_ERR_UNSUPPORTED, "t4k_pool: layer %d", layer);
     const long total = (long)N * H0 * W0 * C; if (total <= 0) return T4K_OK;
-    if (KS == 2) hipLaunchKernelGGL(k_pool<2>, dim3(grid_for(total)), dim3(BLK), 0, S(s), layer, I, O, N, H1, W1, H0, W0, C);
-    else         hipLaunchKernelGGL(k_pool<3>, dim3(grid_for(total)), dim3(BLK), 0, S(s), layer, I, O, N, H1, W1, H0, W0, C);
+    if (KS == 2) hipLaunchKernelGGL(k_pool<2>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, O, N, H1, W1, H0, W0, C);
+    else         hipLaunchKernelGGL(k_pool<3>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, O, N, H1, W1, H0, W0, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_dpool(int layer, float *I, const float *DY, int N, int H1, int W1, int H0, int W0, int C, int KS, t4k_stream_t s) {
@@ -300,8 +361,8 @@ int t4k_dpool(int layer, float *I, const float *DY, int N, int H1, int W1, int H
     if (layer != T4K_L_AVGPOOL && layer != T4K_L_MAXPOOL && layer != T4K_L_MINPOOL && layer != T4K_L_USAMPLE)
         return fail(T4K_ERR_UNSUPPORTED, "t4k_dpool: layer %d", layer);
     const long total = (long)N * H0 * W0 * C; if (total <= 0) return T4K_OK;
-    if (KS == 2) hipLaunchKernelGGL(k_dpool<2>, dim3(grid_for(total)), dim3(BLK), 0, S(s), layer, I, DY, N, H1, W1, H0, W0, C);
-    else         hipLaunchKernelGGL(k_dpool<3>, dim3(grid_for(total)), dim3(BLK), 0, S(s), layer, I, DY, N, H1, W1, H0, W0, C);
+    if (KS == 2) hipLaunchKernelGGL(k_dpool<2>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, DY, N, H1, W1, H0, W0, C);
+    else         hipLaunchKernelGGL(k_dpool<3>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, DY, N, H1, W1, H0, W0, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
