@@ -1,0 +1,126 @@
+/*
+ * t4k_on_oracle.cpp - TEST INFRASTRUCTURE ONLY.
+ *
+ * Implements the C-ABI of include/t4k.h on plain host memory by forwarding every compute entry
+ * point to the CPU oracle (t4o_*).  Linking the host VM sources against THIS file instead of
+ * libt4hip.so yields `ten4_oracle`, a CPU replica of the product that runs the reference's own
+ * .4th known-answer scripts.  It is used (a) to pin the oracle + host orchestration against the
+ * expected values in examples/t4_30a/b/c, t4_20a, t4_22a, and (b) as the checker that the GPU
+ * `ten4` output is compared with.  The product binary never links or loads this file.
+ */
+#include "../include/t4k.h"
+#include "t4_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static char g_err[128] = "";
+
+extern "C" {
+
+int t4k_device_count(void) { return 1; }
+int t4k_init(int) { return T4K_OK; }
+void t4k_shutdown(void) {}
+const char *t4k_last_error(void) { return g_err; }
+const char *t4k_backend_name(void) { return "cpu-oracle (test infrastructure)"; }
+int t4k_device_info(int *cu, int *khz, size_t *hbm) { if (cu) *cu = 1; if (khz) *khz = 0; if (hbm) *hbm = 0; return T4K_OK; }
+
+int t4k_malloc(void **p, size_t bytes) { *p = aligned_alloc(256, (bytes + 255) & ~(size_t)255); return *p ? T4K_OK : T4K_ERR_NOMEM; }
+int t4k_free(void *p) { free(p); return T4K_OK; }
+int t4k_host_alloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 4); return T4K_OK; }
+int t4k_host_free(void *p) { free(p); return T4K_OK; }
+int t4k_memcpy_h2d(void *d, const void *s, size_t n, t4k_stream_t) { memmove(d, s, n); return T4K_OK; }
+int t4k_memcpy_d2h(void *d, const void *s, size_t n, t4k_stream_t) { memmove(d, s, n); return T4K_OK; }
+int t4k_memcpy_d2d(void *d, const void *s, size_t n, t4k_stream_t) { memmove(d, s, n); return T4K_OK; }
+int t4k_memset(void *d, int b, size_t n, t4k_stream_t) { memset(d, b, n); return T4K_OK; }
+int t4k_sync(t4k_stream_t) { return T4K_OK; }
+int t4k_stream_create(t4k_stream_t *s) { *s = nullptr; return T4K_OK; }
+int t4k_stream_destroy(t4k_stream_t) { return T4K_OK; }
+int t4k_set_default_stream(t4k_stream_t) { return T4K_OK; }
+t4k_stream_t t4k_default_stream(void) { return nullptr; }
+int t4k_event_create(t4k_event_t *e) { *e = nullptr; return T4K_OK; }
+int t4k_event_record(t4k_event_t, t4k_stream_t) { return T4K_OK; }
+int t4k_event_sync(t4k_event_t) { return T4K_OK; }
+int t4k_event_elapsed_ms(t4k_event_t, t4k_event_t, float *ms) { *ms = 0; return T4K_OK; }
+int t4k_event_destroy(t4k_event_t) { return T4K_OK; }
+int t4k_graph_begin(t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
+int t4k_graph_end(t4k_stream_t, t4k_graph_t *) { return T4K_ERR_UNSUPPORTED; }
+int t4k_graph_launch(t4k_graph_t, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
+int t4k_graph_destroy(t4k_graph_t) { return T4K_OK; }
+
+static int rc(int r, const char *w) { if (r) snprintf(g_err, sizeof(g_err), "%s (oracle rc=%d)", w, r); return r; }
+
+int t4k_reduce(int op, const float *s, long n, float avg, float *out, t4k_stream_t) { return rc(t4o_reduce(op, s, n, avg, out), "reduce"); }
+int t4k_nan_inf(const float *s, long n, int *c, t4k_stream_t) { return t4o_nan_inf(s, n, c); }
+int t4k_copy(const float *s, float *d, long n, t4k_stream_t) { return t4o_copy(s, d, n); }
+int t4k_transpose(const float *s, float *d, int H, int W, int C, t4k_stream_t) { return t4o_transpose(s, d, H, W, C); }
+int t4k_identity(float *d, int H, int W, int C, t4k_stream_t) { return t4o_identity(d, H, W, C); }
+int t4k_math(int op, float *A, float v, long n, t4k_stream_t) { return rc(t4o_math(op, A, v, n), "k_math op not supported"); }
+int t4k_ts_op(int op, const float *A, float v, float *O, long n, t4k_stream_t) { return rc(t4o_ts_op(op, A, v, O, n), "k_ts_op"); }
+int t4k_tt_op(int op, const float *A, const float *B, float *O, long n, t4k_stream_t) { return rc(t4o_tt_op(op, A, B, O, n), "k_tt_op"); }
+int t4k_bce(const float *T, const float *O, long n, float *out, t4k_stream_t) { return t4o_bce(T, O, n, out); }
+int t4k_dot(const float *A, const float *B, float *O, float a, float b, int K, int C, t4k_stream_t) { return t4o_dot(A, B, O, a, b, K, C); }
+int t4k_gemm(const float *A, const float *B, float *O, float a, float b, int tA, int tB, int M, int N, int K, int C, t4k_stream_t) {
+    if (b == 0.0f) memset(O, 0, sizeof(float) * (size_t)M * N * C);      // product contract: beta == 0 never reads O
+    return rc(t4o_gemm(A, B, O, a, b, tA, tB, M, N, K, C), "gemm");
+}
+int t4k_gemm_f64acc(const float *A, const float *B, float *O, float a, float b, int M, int N, int K, int C, t4k_stream_t) {
+    if (b == 0.0f) memset(O, 0, sizeof(float) * (size_t)M * N * C);
+    return t4o_gemm_f64acc(A, B, O, a, b, M, N, K, C);
+}
+int t4k_inverse(float *A, float *I, int K, int *st, t4k_stream_t) { return t4o_inverse(A, I, K, st); }
+int t4k_plu(float *A, float *I, int *piv, int K, int *st, t4k_stream_t) { return t4o_plu(A, I, piv, K, st); }
+int t4k_lu_inverse(float *A, float *I, int *piv, int K, int *st, t4k_stream_t) { return t4o_lu_inverse(A, I, piv, K, st); }
+int t4k_lu_extract(float *LU, int u, int K, t4k_stream_t) { return t4o_lu_extract(LU, u, K); }
+int t4k_logdet(const float *LU, int K, float *ld, int *sg, t4k_stream_t) { return t4o_logdet(LU, K, ld, sg); }
+int t4k_rand_init(uint64_t seed) { return t4o_rand_init(seed); }
+int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t) { return t4o_rand(d, n, opt, bias, scale); }
+uint64_t t4k_rand_offset(void) { return t4o_rand_offset(); }
+int t4k_rand_set_offset(uint64_t o) { return t4o_rand_set_offset(o); }
+int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t) { return t4o_bias(B, O, N, E0); }
+int t4k_activate(int l, const float *I, float *O, float *F, float a, long n, t4k_stream_t) { return rc(t4o_activate(l, I, O, F, a, n), "k_activate"); }
+int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t) { return t4o_softmax(I, O, N, C); }
+int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B, float *st, int N, int HW, int C, t4k_stream_t) {
+    return t4o_batchnorm_fwd(I, O, XH, W, B, st, N, HW, C);
+}
+int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *DX, float *DW, float *DB, float *st, int N, int HW, int C, int tr, t4k_stream_t) {
+    return t4o_batchnorm_bwd(W, DY, XH, DX, DW, DB, st, N, HW, C, tr);
+}
+int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t) { return t4o_dlinear_db(DY, DB, N, E0); }
+int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B, int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t) {
+    int r = t4o_conv2d_fwd(I, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P);
+    if (r) snprintf(g_err, sizeof(g_err), "nn#fconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
+    return r;
+}
+int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB, int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                   int K, int S, int P, int tr, t4k_stream_t) {
+    int r = t4o_conv2d_bwd(I, DO, DX, F, DF, DB, N, H1, W1, C1, H0, W0, C0, K, S, P, tr);
+    if (r) snprintf(g_err, sizeof(g_err), "nn#bconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
+    return r;
+}
+int t4k_pool(int l, const float *I, float *O, int N, int H1, int W1, int H0, int W0, int C, int KS, t4k_stream_t) { return rc(t4o_pool(l, I, O, N, H1, W1, H0, W0, C, KS), "k_pool"); }
+int t4k_dpool(int l, float *I, const float *DY, int N, int H1, int W1, int H0, int W0, int C, int KS, t4k_stream_t) { return rc(t4o_dpool(l, I, DY, N, H1, W1, H0, W0, C, KS), "k_dpool"); }
+int t4k_sgd(float *G, float *DG, float *M, int Nw, float lr, float b, long n, t4k_stream_t) { return t4o_sgd(G, DG, M, Nw, lr, b, n); }
+int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, long n, t4k_stream_t) { return t4o_adam(G, DG, M, V, lr, b1, b2, n); }
+int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd, long n, t4k_stream_t) { return t4o_adamw(G, DG, M, V, lr, b1, b2, wd, n); }
+int t4k_onehot(const uint32_t *l, float *hot, int N, int E, t4k_stream_t) { return t4o_onehot(l, hot, N, E); }
+int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t) { return t4o_hit(out, hot, N, E, cnt); }
+int t4k_u8_normalize(const uint8_t *s, float *d, long n, float mean, float scale, t4k_stream_t) { return t4o_u8_normalize(s, d, n, mean, scale); }
+int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int N, int E0, int E1, t4k_stream_t) {
+    memset(Y, 0, sizeof(float) * (size_t)N * E0);
+    return t4o_linear_fwd(X, W, B, Y, N, E0, E1);
+}
+int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t) {
+    return t4o_linear_bwd(X, W, DY, DX, DW, DB, N, E0, E1, tr);
+}
+int t4k_opt_multi(int kind, const t4k_param_rec *tab, int nt, long, float lr, float b1, float b2, float wd, t4k_stream_t) {
+    for (int i = 0; i < nt; i++) {
+        const t4k_param_rec &r = tab[i];
+        if (kind == 0) t4o_sgd(r.G, r.DG, r.M, r.Nw, lr, b1, r.n);
+        else if (kind == 1) t4o_adam(r.G, r.DG, r.M, r.V, lr, b1, b2, r.n);
+        else t4o_adamw(r.G, r.DG, r.M, r.V, lr, b1, b2, wd, r.n);
+    }
+    return T4K_OK;
+}
+
+} // extern "C"

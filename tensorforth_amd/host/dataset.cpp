@@ -1,0 +1,101 @@
+// dataset.cpp - corpus readers (MNIST IDX, CIFAR-10 binary) and the batch feed.
+// Restates src/ld/{loader,mnist,cifar10}.cpp and Dataset::fetch/_load (src/mu/dataset.cu:64-158):
+// the u8 batch is copied to HBM once and normalised ON the GPU (t4k_u8_normalize) instead of a
+// host loop into a pageable std::vector followed by a blocking H2D.
+#include "t4.h"
+#include <map>
+
+namespace t4 {
+
+static std::map<std::string, Corpus *> &corpora() {      // Loader::init src/ld/loader.cpp:31-46
+    static std::map<std::string, Corpus *> m;
+    if (m.empty()) {
+        auto mk = [&](const char *nm, const char *d, const char *l, bool cifar) {
+            Corpus *c = new Corpus(); c->name = nm; c->f_data = d; c->f_label = l ? l : ""; c->cifar = cifar; m[nm] = c;
+        };
+        mk("mnist_train", "./data/MNIST/raw/train-images-idx3-ubyte", "./data/MNIST/raw/train-labels-idx1-ubyte", false);
+        mk("mnist_test",  "./data/MNIST/raw/t10k-images-idx3-ubyte",  "./data/MNIST/raw/t10k-labels-idx1-ubyte", false);
+        mk("cifar10_train", "./data/CIFAR10/cifar-10-batches-bin/data_batch.bin", nullptr, true);
+        mk("cifar10_test",  "./data/CIFAR10/cifar-10-batches-bin/test_batch.bin", nullptr, true);
+    }
+    return m;
+}
+static uint32_t be32(FILE *f) { uint8_t b[4] = {0, 0, 0, 0}; if (fread(b, 1, 4, f) != 4) return 0; return (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3]; }
+
+bool Corpus::init(int batch) {
+    N = batch; eof = false; batch_sz = 0;
+    if (fd) { fclose(fd); fd = nullptr; } if (fl) { fclose(fl); fl = nullptr; }
+    fd = fopen(f_data.c_str(), "rb");
+    if (!fd) { printf("failed to open file %s\n", f_data.c_str()); return false; }
+    if (cifar) {                                         // 1 label byte + 3x32x32 planar bytes per sample
+        H = W = 32; C = 3;
+        fseek(fd, 0, SEEK_END); corpus_sz = (int)(ftell(fd) / 3073); fseek(fd, 0, SEEK_SET);
+        return true;
+    }
+    fl = fopen(f_label.c_str(), "rb");
+    if (!fl) { printf("failed to open file %s\n", f_label.c_str()); return false; }
+    be32(fl); const uint32_t n1 = be32(fl);              // label magic 0x0801, count
+    be32(fd); const uint32_t n = be32(fd); H = be32(fd); W = be32(fd); C = 1;   // image magic 0x0803
+    if (n != n1) { printf("Mnist::init label count %d != image count %d\n", n1, n); return false; }
+    corpus_sz = n;
+    return true;
+}
+void Corpus::rewind() { eof = false; }
+bool Corpus::fetch(int bid) {
+    const long off = (long)N * bid;
+    if (eof || off >= corpus_sz) { printf("%s::fetch EOF reached (needs rewind)\n", cifar ? "Cifar10" : "Mnist"); eof = true; return false; }
+    const size_t cell = (size_t)H * W * C;
+    data.resize((size_t)N * cell); label.resize(N);
+    size_t n = 0;
+    if (cifar) {
+        std::vector<uint8_t> buf((size_t)N * 3073);
+        fseek(fd, off * 3073, SEEK_SET);
+        n = fread(buf.data(), 1, buf.size(), fd) / 3073;
+        const size_t HW = (size_t)H * W;
+        for (size_t i = 0; i < n; i++) {                 // planar RGB -> HWC (cifar10.cpp:118-126)
+            const uint8_t *bp = &buf[i * 3073]; label[i] = bp[0]; bp++;
+            uint8_t *dp = &data[i * cell];
+            for (size_t j = 0; j < HW; j++) { *dp++ = bp[j]; *dp++ = bp[HW + j]; *dp++ = bp[2 * HW + j]; }
+        }
+    } else {
+        fseek(fl, 8 + off, SEEK_SET);
+        const size_t nl = fread(label.data(), 1, N, fl);
+        fseek(fd, 16 + off * (long)cell, SEEK_SET);
+        n = fread(data.data(), 1, (size_t)N * cell, fd) / cell;
+        if (nl != n) { printf("Mnist::fetch #label=%d != #image=%d\n", (int)nl, (int)n); return false; }
+    }
+    batch_sz = (int)n;
+    if (off + (long)n >= corpus_sz) eof = true;
+    return n > 0;
+}
+
+int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
+    if (ds_name) {
+        auto it = corpora().find(ds_name);
+        if (it == corpora().end()) { printf("  } dataset#fetch => not found in Loader\n"); return -1; }
+        cp = it->second;
+        if (!cp->init(N())) { printf("  } dataset#fetch => corpus init failed!\n"); return -2; }
+        dataset_size = cp->corpus_sz;
+        numel = (uint64_t)cp->N * cp->H * cp->W * cp->C;
+        rank = 4; shape[0] = cp->H; shape[1] = cp->W; shape[2] = cp->C; shape[3] = cp->N;
+    }
+    if (!cp) { printf("  } dataset#fetch => not found in Loader\n"); return -1; }
+    if (rewind) { cp->rewind(); batch_id = done = 0; }
+    if (!cp->fetch(batch_id)) { printf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
+    const int n = batch_sz = cp->batch_sz;
+    done = cp->eof;
+    die_if_no_backend();
+    if (!data)    { void *p; t4k_malloc(&p, sizeof(float) * numel); data = (float *)p; t4k_memset(data, 0, sizeof(float) * numel, stream()); }
+    if (!label)   { void *p; t4k_malloc(&p, sizeof(uint32_t) * N()); label = (uint32_t *)p; }
+    if (!raw_dev) { void *p; t4k_malloc(&p, numel); raw_dev = (uint8_t *)p; }
+    const long NX = (long)n * HWC();
+    t4k_memcpy_h2d(raw_dev, cp->data.data(), NX, stream());
+    chk(t4k_u8_normalize(raw_dev, data, NX, mean, scale, stream()), "dataset#load");   // (x - mean) * scale on the GPU
+    std::vector<uint32_t> l32(n); for (int i = 0; i < n; i++) l32[i] = cp->label[i];
+    t4k_memcpy_h2d(label, l32.data(), sizeof(uint32_t) * n, stream());
+    t4k_sync(stream());                                  // host staging buffers are reused by the next fetch
+    batch_id++;
+    return 0;
+}
+
+} // namespace t4

@@ -1,0 +1,325 @@
+// model.cpp - NN model: layer factory, forward / backprop orchestration, loss, optimizers.
+// Restates src/nn/model.cpp:82-310, forward.cu:28-113, backprop.cu:39-140, gradient.cu:19-169,
+// loss.cpp:16-136 on top of the t4k_* C-ABI.  Everything is launched asynchronously on one
+// stream; the host only synchronises when a scalar (loss, hit) is read back.
+#include "t4.h"
+#include <algorithm>
+
+namespace t4 {
+
+#define NLOG(...) do { if (trace && *trace) printf(__VA_ARGS__); } while (0)
+
+Tensor &Model::T4(uint32_t n, uint32_t h, uint32_t w, uint32_t c) { return Store::get().tensor(n, h, w, c); }
+Tensor &Model::VEC(uint64_t n) { return Store::get().tensor(n); }
+void Model::RAND(Tensor &t, DU scale) {                 // Model::RAND model.cpp:73-78: uniform [-scale, scale)
+    chk(t4k_rand(t.data, (long)t.numel, T4K_UNIFORM, -0.5f, scale * 2.0f, stream()), "rand");
+}
+
+// ---------------------------------------------------------------- layer factory (Model::add)
+Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
+    Tensor &in = at(-1);
+    if (in.grad_fn != T4K_L_NONE) return *this;
+    NLOG("  Model::add %s n=%d bias=%g {\n", LAYER_NAME[fn], n, bias);
+    for (int i = 0; i < 5; i++) in.grad[i] = in.mtum[i] = nullptr;
+    switch (fn) {
+    case T4K_L_CONV: case T4K_L_DCONV: {                // _iconv model.cpp:121-180
+        const bool txn = fn == T4K_L_DCONV;
+        const uint32_t N1 = in.N(), H1 = in.H(), W1 = in.W(), C1 = in.C(), C0 = n;
+        const uint16_t K = opt[0], S = opt[1];
+        const uint16_t P = (K > 1 && opt[2]) ? opt[2] : (K - 1) / 2;
+        uint16_t H0, W0;
+        if (txn) { const uint16_t P0 = (H1 + P * 2 - K) % S; H0 = (H1 - 1) * S - P * 2 + K + P0; W0 = (W1 - 1) * S - P * 2 + K + P0; }
+        else     { H0 = (H1 - K + P * 2) / S + 1; W0 = (H1 - K + P * 2) / S + 1; }      // W0 from H1: reference quirk :137
+        if ((!txn && K != 1 && K != 3 && K != 5) || (txn && K != 4)) {
+            printf("nn#iconv %s f=[%d,%d]? 1x1, 3x3, 4x4, and 5x5 supported only.\n", LAYER_NAME[fn], K, K);
+            return *this;
+        }
+        in.stride[0] = in.stride[1] = S; in.stride[2] = in.stride[3] = P; in.xparm = bias;
+        Tensor *f = in.grad[0] = &T4(C1, K, K, C0);
+        Tensor *b = in.grad[1] = &VEC(C0);
+        in.grad[2] = &T4(C1, K, K, C0).zeros();
+        in.grad[3] = &VEC(C0).zeros();
+        in.grad[4] = &T4(N1, H1, W1, C1).zeros();
+        RAND(*f, sqrtf(6.0f / (K * K * C1))); RAND(*b, bias);
+        layer.push_back(&T4(N1, H0, W0, C0));
+    } break;
+    case T4K_L_LINEAR: {                                // _ilinear model.cpp:182-226
+        const uint32_t N1 = in.N(); const uint64_t E1 = in.HWC(); const uint32_t E0 = n;
+        Tensor *w = in.grad[0] = &T4(1, E0, (uint32_t)E1, 1);
+        Tensor *b = in.grad[1] = &VEC(E0);
+        in.grad[2] = &T4(1, E0, (uint32_t)E1, 1).zeros();
+        in.grad[3] = &VEC(E0).zeros();
+        if (in.W() != E1) printf("    WARN linear: treats in[%d,%d,%d,%d] as [%d,1,%ld,1]\n", N1, in.H(), in.W(), in.C(), N1, (long)E1);
+        in.xparm = bias;
+        RAND(*w, sqrtf(1.0f / (E0 + E1))); RAND(*b, bias);
+        layer.push_back(&T4(N1, 1, E0, 1));
+    } break;
+    case T4K_L_FLATTEN: layer.push_back(&T4(in.N(), 1, (uint32_t)in.HWC(), 1)); break;
+    case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SIGMOID: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU: case T4K_L_DROPOUT:
+        in.grad[4] = &T4(in.N(), in.H(), in.W(), in.C()); in.xparm = bias;
+        layer.push_back(&T4(in.N(), in.H(), in.W(), in.C())); break;
+    case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
+        in.grad[4] = &T4(1, in.H(), in.W(), in.C());
+        layer.push_back(&T4(in.N(), in.H(), in.W(), in.C())); break;
+    case T4K_L_AVGPOOL: case T4K_L_MAXPOOL: case T4K_L_MINPOOL: {    // _ipool model.cpp:260-274 (ceil dims)
+        const uint16_t k = (uint16_t)n;
+        if (k != 2 && k != 3) { printf("nn#ipool k=%dx%d? 2x2 and 3x3 supported only\n", k, k); return *this; }
+        in.stride[0] = k; in.stride[1] = 1; in.stride[2] = 1; in.stride[3] = 0;
+        layer.push_back(&T4(in.N(), (in.H() + k - 1) / k, (in.W() + k - 1) / k, in.C()));
+    } break;
+    case T4K_L_BATCHNM: {                               // _ibatchnorm model.cpp:276-292 (dW/dB zeroed here)
+        const int C = in.C();
+        in.grad[0] = &VEC(C).map(T4K_FILL, 1.0f); in.grad[2] = &VEC(C).zeros();
+        in.grad[1] = &VEC(C).zeros();             in.grad[3] = &VEC(C).zeros();
+        in.grad[4] = &T4(in.N(), in.H(), in.W(), in.C());
+        in.mtum[4] = &VEC(C * 3).zeros();
+        in.xparm = bias;
+        layer.push_back(&T4(in.N(), in.H(), in.W(), in.C()));
+    } break;
+    case T4K_L_USAMPLE: {                               // _iup model.cpp:294-310
+        const uint16_t k = (uint16_t)n;
+        if (k != 2 && k != 3) { printf("nn#iup k=%dx%d? only 2x2 and 3x3 supported\n", k, k); return *this; }
+        in.iparm = (int)bias;
+        in.stride[0] = k; in.stride[1] = 1; in.stride[2] = 1; in.stride[3] = 1;
+        layer.push_back(&T4(in.N(), in.H() * k, in.W() * k, in.C()));
+    } break;
+    default: printf("Model#add layer %d not supported\n", fn); return *this;
+    }
+    in.grad_fn = fn;
+    Tensor &out = at(-1);
+    NLOG("  } Model::add[%ld] %s => out[%d,%d,%d,%d]\n", (long)layer.size(), LAYER_NAME[fn], out.N(), out.H(), out.W(), out.C());
+    return *this;
+}
+
+// ---------------------------------------------------------------- forward
+Model &Model::forward(Tensor &input) {
+    Tensor &n0 = at(0);
+    if (input.numel != n0.numel) {
+        printf("nn#forward dataset wrong shape[%d,%d,%d,%d] != model input[%d,%d,%d,%d]\n",
+               input.N(), input.H(), input.W(), input.C(), n0.N(), n0.H(), n0.W(), n0.C());
+        return *this;
+    }
+    n0 = input;                                         // layer 0 holds a COPY of the batch (forward.cu:39)
+    NLOG("\nModel::forward starts trace=%d {", *trace);
+    for (int i = 0; i + 1 < (int)layer.size(); i++) {
+        Tensor &in = at(i), &out = at(i + 1);
+        if (trace && *trace)
+            printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
+                   in.N(), in.H(), in.W(), in.C(), in.sum() / in.N() / in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
+        fstep(in, out);
+        if (trace && *trace && out.has_nan()) { printf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+    }
+    if (input.type == T_DATASET) { onehot((Dataset &)input); hit_ = hit(true); }
+    NLOG("\n} Model::forward\n");
+    return *this;
+}
+void Model::fstep(Tensor &in, Tensor &out) {            // _fstep forward.cu:82-113
+    const int fn = in.grad_fn;
+    t4k_stream_t s = stream();
+    switch (fn) {
+    case T4K_L_CONV:
+        chk(t4k_conv2d_fwd(in.data, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
+                           out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], s), "nn#fconv"); break;
+    case T4K_L_LINEAR:
+        chk(t4k_linear_fwd(in.data, in.grad[0]->data, in.grad[1]->data, out.data, out.N(), (int)out.HWC(), (int)in.HWC(), s), "nn#flinear"); break;
+    case T4K_L_FLATTEN: out = in; break;
+    case T4K_L_DROPOUT:
+        chk(t4k_rand(in.grad[4]->data, (long)in.grad[4]->numel, T4K_UNIFORM, 0.0f, 1.0f, s), "rand");   /* fall through */
+    case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SIGMOID: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU:
+        chk(t4k_activate(fn, in.data, out.data, in.grad[4]->data, in.xparm, (long)in.numel, s), "nn#factivate"); break;
+    case T4K_L_SOFTMAX: chk(t4k_softmax(in.data, out.data, in.N(), (int)in.HWC(), s), "nn#fsoftmax"); break;
+    case T4K_L_LOGSMAX: {                               // _flogsoftmax forward.cu:245-259 (log10 and exp(x) kept: reference bug a-16)
+        out = in; out.map(T4K_EXP);
+        std::vector<float> h; out.to_host(h);
+        for (uint32_t n = 0; n < out.N(); n++) {
+            DU sum = 0; for (uint64_t i = 0; i < out.HWC(); i++) sum += h[n * out.HWC() + i];
+            DU ls = log10f(fmaxf(sum, DU_EPS));
+            t4k_ts_op(T4K_SUB, out.slice(n), ls, out.slice(n), (long)out.HWC(), s);
+        }
+    } break;
+    case T4K_L_AVGPOOL: case T4K_L_MAXPOOL: case T4K_L_MINPOOL:
+        chk(t4k_pool(fn, in.data, out.data, out.N(), in.H(), in.W(), out.H(), out.W(), out.C(), in.stride[0], s), "nn#fpool"); break;
+    case T4K_L_BATCHNM:
+        chk(t4k_batchnorm_fwd(in.data, out.data, in.grad[4]->data, in.grad[0]->data, in.grad[1]->data, in.mtum[4]->data,
+                              out.N(), out.H() * out.W(), out.C(), s), "nn#fbatchnorm"); break;
+    case T4K_L_USAMPLE:                                 // nearest: broadcast each cell to a kxk tile
+        chk(t4k_dpool(T4K_L_USAMPLE, out.data, in.data, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#fupsample"); break;
+    default: printf("nn#fstep layer=%d not supported\n", fn);
+    }
+}
+
+// ---------------------------------------------------------------- one-hot / hit / loss
+Tensor &Model::onehot() {
+    if (hot) return *hot;
+    printf("Model.onehot not provided by dataset, use nn.onehot= to setup!\n");
+    return at(-1);
+}
+Tensor &Model::onehot(Tensor &t) {
+    Tensor &out = at(-1);
+    const uint32_t N = out.N(), E = (uint32_t)out.HWC();
+    if (hot) { printf("WARN: Model.onehot exists, replaced\n"); Store::get().free(*hot); }
+    else if (t.N() != N || (uint32_t)t.HWC() != E) { printf("Model.onehot dimension is not [%d,1,%d,1]\n", N, E); return t; }
+    hot = &t; hit_ = hit(true);
+    return *hot;
+}
+Tensor &Model::onehot(Dataset &d) {                     // loss.cpp:47-72
+    Tensor &out = at(-1);
+    const uint32_t E = (uint32_t)out.HWC();
+    if (!hot) hot = &T4(out.N(), 1, E, 1);
+    if ((uint32_t)d.batch_sz < out.N()) hot->zeros();
+    chk(t4k_onehot(d.label, hot->data, d.batch_sz, E, stream()), "nn#onehot");
+    return *hot;
+}
+int Model::hit(bool recalc) {                           // loss.cpp:75-107
+    if (!recalc) return hit_;
+    if (!hot) return 0;
+    Tensor &out = at(-1);
+    if (!hit_dev) { void *p; t4k_malloc(&p, 64); hit_dev = (int *)p; }
+    chk(t4k_hit(out.data, hot->data, out.N(), (int)out.HWC(), hit_dev, stream()), "nn#hit");
+    int c = 0; t4k_memcpy_d2h(&c, hit_dev, sizeof(int), stream()); t4k_sync(stream());
+    return c;
+}
+DU Model::loss(Loss op) { return hot ? loss(op, *hot) : 0.0f; }
+DU Model::loss(Loss op, Tensor &tgt) {                  // loss.cpp:119-136: non-destructive (works on a copy)
+    Tensor &out = at(-1);
+    if (out.numel != tgt.numel) {
+        printf("nn::loss model output shape[%d,%d,%d,%d] != tgt[%d,%d,%d,%d]\n", out.N(), out.H(), out.W(), out.C(), tgt.N(), tgt.H(), tgt.W(), tgt.C());
+        return 0;
+    }
+    if (loss_t) *loss_t = out; else loss_t = &Store::get().copy(out);
+    return loss_t->loss(op, tgt);
+}
+
+// ---------------------------------------------------------------- backprop
+Model &Model::broadcast(Tensor &tgt) {                  // backprop.cu:17-29: [N,1] -> [N,HWC]
+    Tensor &out = at(-1);
+    const uint64_t HWC = out.HWC(); const uint32_t N = out.N();
+    if (!hot) hot = &T4(N, 1, (uint32_t)HWC, 1);
+    std::vector<float> t, h(N * HWC); tgt.to_host(t);
+    for (uint32_t n = 0; n < N && n < t.size(); n++) for (uint64_t i = 0; i < HWC; i++) h[n * HWC + i] = t[n];
+    hot->from_host(h.data(), h.size());
+    return *this;
+}
+Model &Model::backprop() {
+    if (hot) return backprop(*hot);
+    printf("nn#backprop missing onehot vector?\n");
+    return *this;
+}
+Model &Model::backprop(Tensor &tgt) {
+    Tensor &out = at(-1);
+    if (out.numel != tgt.numel) {                       // _bprep backprop.cu:75-109
+        printf("Model#bprep: Onehot wrong shape[%d,%d,%d,%d] != [%d,%d,%d,%d], numel=%ld,%ld ", tgt.N(), tgt.H(), tgt.W(), tgt.C(),
+               out.N(), out.H(), out.W(), out.C(), (long)tgt.numel, (long)out.numel);
+        return *this;
+    }
+    switch (at(-2).grad_fn) {
+    case T4K_L_LINEAR: case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX: Tensor::ten_op(T4K_SUB, out, tgt, out); break;
+    default: out = tgt; break;
+    }
+    NLOG("\nModel::backprop starts trace=%d train=%d {", *trace, (int)train);
+    for (int i = (int)layer.size() - 2, j = 0; i >= 0; i--, j++) {
+        Tensor &in = at(i), &o = at(i + 1);
+        if (trace && *trace)
+            printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
+                   in.N(), in.H(), in.W(), in.C(), in.xparm, o.sum() / o.N() / o.C(), o.N(), o.H(), o.W(), o.C());
+        bstep(in, o, j == 0);
+        if (trace && *trace && in.has_nan()) { printf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+    }
+    NLOG("\n} Model::backprop\n");
+    return *this;
+}
+void Model::bstep(Tensor &in, Tensor &out, bool last) {  // _bstep backprop.cu:111-140
+    const int fn = in.grad_fn;
+    t4k_stream_t s = stream();
+    switch (fn) {
+    case T4K_L_CONV: {
+        Tensor &dx = *in.grad[4];
+        chk(t4k_conv2d_bwd(in.data, out.data, dx.data, in.grad[0]->data, in.grad[2]->data, in.grad[3]->data,
+                           in.N(), in.H(), in.W(), in.C(), out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], train, s), "nn#bconv");
+        in = dx;                                        // x = dX (overwrite), backprop.cu:185
+    } break;
+    case T4K_L_LINEAR:
+        if (last) in = out;                             // linear as the last layer: pass dY (backprop.cu:119-121)
+        else chk(t4k_linear_bwd(in.data, in.grad[0]->data, out.data, in.data, in.grad[2]->data, in.grad[3]->data,
+                                in.N(), (int)out.HWC(), (int)in.HWC(), train, s), "nn#blinear");
+        break;
+    case T4K_L_FLATTEN: case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX: in = out; break;   // pass-through (:122,129-131)
+    case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU: case T4K_L_DROPOUT:
+        Tensor::ten_op(T4K_MUL, out, *in.grad[4], in); break;
+    case T4K_L_AVGPOOL: case T4K_L_MAXPOOL: case T4K_L_MINPOOL:
+        chk(t4k_dpool(fn, in.data, out.data, out.N(), in.H(), in.W(), out.H(), out.W(), out.C(), in.stride[0], s), "nn#bpool"); break;
+    case T4K_L_BATCHNM:
+        chk(t4k_batchnorm_bwd(in.grad[0]->data, out.data, in.grad[4]->data, in.data, in.grad[2]->data, in.grad[3]->data,
+                              in.mtum[4]->data, in.N(), in.H() * in.W(), in.C(), train, s), "nn#bbatchnorm"); break;
+    case T4K_L_USAMPLE:                                 // gradient of nearest upsampling = sum over the tile = k*k * avgpool
+        chk(t4k_pool(T4K_L_AVGPOOL, out.data, in.data, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#bupsample");
+        in.map(T4K_SCALE, (DU)(in.stride[0] * in.stride[0])); break;
+    default: printf("nn#bstep layer=%d not supported\n", fn);
+    }
+}
+
+// ---------------------------------------------------------------- optimizers
+void Model::build_table(Optim op) {                      // one multi-tensor launch replaces 6-8 launch+sync pairs
+    std::vector<t4k_param_rec> recs;
+    tab_max = 0;
+    for (int i = 0; i + 1 < (int)layer.size(); i++) {
+        Tensor &in = at(i);
+        for (int k = 0; k < 2; k++) {
+            if (!in.mtum[k] || !in.grad[k] || !in.grad[k + 2]) continue;
+            t4k_param_rec r;
+            r.G = in.grad[k]->data; r.DG = in.grad[k + 2]->data; r.M = in.mtum[k]->data;
+            r.V = in.mtum[k + 2] ? in.mtum[k + 2]->data : in.mtum[k]->data;
+            r.n = (long)in.grad[k]->numel; r.Nw = (int)in.grad[k]->N(); r.pad = 0;     // g.N(): C1 for conv filters (quirk a-19)
+            recs.push_back(r); tab_max = std::max(tab_max, r.n);
+        }
+    }
+    if (tab_dev) t4k_free(tab_dev);
+    tab_n = (int)recs.size(); tab_kind = op; tab_dev = nullptr;
+    if (tab_n) {
+        t4k_malloc(&tab_dev, recs.size() * sizeof(t4k_param_rec));
+        t4k_memcpy_h2d(tab_dev, recs.data(), recs.size() * sizeof(t4k_param_rec), stream()); t4k_sync(stream());
+    }
+}
+Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {   // gradient.cu:63-126
+    NLOG("\nModel::%s starts (%s) batch_sz=%d, lr=%7.4f, mtum/b1=%6.3f, b2=%6.3f {\n", nm, train ? "trainning" : "testing", at(1).N(), lr, b1, b2);
+    const bool first = (iter++ == 0 && epoch == 0);
+    if (first || tab_kind != op) {                      // grad_alloc gradient.cu:19-59 (+ re-allocation when the optimizer is switched mid-run,
+        for (int i = 0; i + 1 < (int)layer.size(); i++) {   //   where the reference would read the SGD alias / a null V)
+            Tensor &in = at(i); Tensor *w = in.grad[0], *b = in.grad[1];
+            Tensor *g[2] = { w, b };
+            for (int k = 0; k < 2; k++) {
+                if (!g[k]) continue;
+                if (op == OPTI_SGD) { if (!in.mtum[k]) in.mtum[k] = g[k]; continue; }
+                if (!in.mtum[k] || in.mtum[k] == g[k]) in.mtum[k] = &T4(g[k]->N(), g[k]->H(), g[k]->W(), g[k]->C()).zeros();
+                if (op != OPTI_SGDM && !in.mtum[k + 2]) in.mtum[k + 2] = &T4(g[k]->N(), g[k]->H(), g[k]->W(), g[k]->C()).zeros();
+            }
+        }
+        build_table(op);
+    }
+    if (!train) return *this;
+    if (!tab_dev || tab_kind != op) build_table(op);
+    const int kind = (op == OPTI_ADAM) ? 1 : (op == OPTI_ADAMW ? 2 : 0);
+    chk(t4k_opt_multi(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_max, lr, b1, b2, wd, stream()), nm);
+    NLOG("} Model::%s\n", nm);
+    return *this;
+}
+Model &Model::sgd(DU lr, DU b) { return gradient("sgd", ZEQ(b) ? OPTI_SGD : OPTI_SGDM, lr, iter ? b : 0.0f, 0, 0); }   // `_iter ? b : 0` gradient.cu:139
+Model &Model::adam(DU lr, DU b1, DU b2) { return gradient("adam", OPTI_ADAM, lr, b1, b2, 0); }
+Model &Model::adamw(DU lr, DU wd, DU b1, DU b2) { return gradient("adamw", OPTI_ADAMW, lr, b1, b2, wd); }
+
+void Model::free_all() {
+    for (int i = (int)layer.size() - 1; i >= 0; i--) Store::get().free(*layer[i]);
+    layer.clear();
+    if (hot) { Store::get().free(*hot); hot = nullptr; }
+    if (loss_t) { Store::get().free(*loss_t); loss_t = nullptr; }
+    if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }
+    if (hit_dev) { t4k_free(hit_dev); hit_dev = nullptr; }
+}
+
+Model &Store::model(int *trace) { Model *m = new Model(); m->type = T_MODEL; m->trace = trace; put(m); return *m; }
+Dataset &Store::dataset(uint32_t batch) {
+    Dataset *d = new Dataset(); d->type = T_DATASET; d->rank = 4; d->shape[3] = batch; d->owns = false; d->data = nullptr;
+    put(d); return *d;
+}
+
+} // namespace t4

@@ -1,0 +1,222 @@
+// t4.h - host side of the MI355X tensorForth backend: object model, HBM arena, Tensor / Model /
+// Dataset classes and the eForth VM, all written against the C-ABI of include/t4k.h only.
+//
+// This restates (does not copy) the reference's host layer so that existing .4th scripts run
+// unchanged: word tables src/vm/eforth.cpp:155-431, tenvm.cpp:450-636, netvm.cpp:291-485;
+// Tensor/Model semantics src/mu/tensor.cu, src/nn/{model.cpp,forward.cu,backprop.cu,
+// gradient.cu,loss.cpp}; print formats src/io/aio_tensor.cpp, aio_model.cpp, src/debug.cpp.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/t4k.h"
+
+namespace t4 {
+
+typedef float DU;
+constexpr DU DU_EPS = 1.0e-6f;
+
+// ---- stack cell tagging (reference src/t4base.h:16-35): bit0 = object, bits0-1 == 3 = view
+inline uint32_t du_bits(DU v) { uint32_t u; memcpy(&u, &v, 4); return u; }
+inline DU bits_du(uint32_t u) { DU v; memcpy(&v, &u, 4); return v; }
+inline bool IS_OBJ(DU v)  { return (du_bits(v) & 1u) != 0; }
+inline bool IS_VIEW(DU v) { return (du_bits(v) & 3u) == 3u; }
+inline DU   SCALAR(DU v)  { return bits_du(du_bits(v) & ~1u); }        // clears the mantissa LSB
+inline DU   AS_VIEW(DU v) { return bits_du(du_bits(v) | 3u); }
+inline bool ZEQ(DU d) { return fabsf(d) < DU_EPS; }
+inline DU   BOOL(bool f) { return f ? -1.0f : 0.0f; }
+
+enum ObjType { T_TENSOR = 0, T_MODEL = 1, T_DATASET = 2 };
+enum Loss { LOSS_MSE = 0, LOSS_BCE, LOSS_CE, LOSS_NLL };
+enum Optim { OPTI_SGD = 0, OPTI_SGDM, OPTI_ADAM, OPTI_ADAMW };
+extern const char *LAYER_NAME[];     // 7-char names, src/nn/ntypes.h:47-51
+
+void die_if_no_backend();            // lazily t4k_init(); prints and exits when no gfx950 device
+int  chk(int rc, const char *what);  // prints t4k_last_error() on failure (print-and-continue)
+t4k_stream_t stream();
+
+// ---------------------------------------------------------------- HBM arena
+// One (growable) slab of device memory, out-of-band metadata on the host, 256-byte aligned blocks.
+// Replaces the reference's host-run TLSF over a 2 GiB cudaMallocManaged arena (src/mu/mmu.cu:44-46,
+// tlsf.cpp), whose in-band headers made the host touch device pages on every alloc/free.
+class Arena {
+public:
+    static Arena &get();
+    float *alloc(size_t nfloat);
+    void   free(float *p);
+    size_t used() const { return used_; }
+    size_t live() const { return blocks_.size(); }
+private:
+    struct Slab { char *base; size_t size; };
+    std::vector<Slab> slabs_;
+    std::map<char *, size_t> free_;       // address -> bytes (coalesced)
+    std::map<char *, size_t> blocks_;     // live allocations
+    size_t used_ = 0;
+    void add_slab(size_t need);
+};
+
+struct Obj {
+    ObjType type = T_TENSOR;
+    int id = -1;
+    virtual ~Obj() {}
+};
+
+// ---------------------------------------------------------------- Tensor
+struct Tensor : Obj {
+    uint64_t numel = 0;
+    int rank = 1;
+    uint32_t shape[4] = {1, 1, 1, 1};        // H, W, C, N  (reference src/mu/tensor.h:53)
+    uint16_t stride[4] = {1, 1, 1, 1};       // conv: S,S,P,P ; pool: k
+    int   grad_fn = 0;                       // t4k layer enum
+    Tensor *grad[5] = {0, 0, 0, 0, 0};       // w, b, dw, db, aux(mask | dx | xhat)
+    Tensor *mtum[5] = {0, 0, 0, 0, 0};       // m_w, m_b, v_w, v_b, batchnorm stats
+    int   iparm = 0;
+    DU    xparm = 0;
+    float *data = nullptr;                   // device pointer (HBM)
+    bool  owns = true;
+
+    uint32_t &H() { return shape[0]; }
+    uint32_t &W() { return shape[1]; }
+    uint32_t &C() { return shape[2]; }
+    uint32_t &N() { return shape[3]; }
+    uint64_t HWC() const { return (uint64_t)shape[0] * shape[1] * shape[2]; }
+    float *slice(int n) { return data + HWC() * n; }
+    bool same_shape(const Tensor &t) const { return memcmp(shape, t.shape, sizeof(shape)) == 0; }
+
+    Tensor &reshape(uint64_t sz);
+    Tensor &reshape(uint32_t h, uint32_t w);
+    Tensor &reshape(uint32_t n, uint32_t h, uint32_t w, uint32_t c);
+
+    // device ops (all asynchronous on the library stream)
+    Tensor &zeros();
+    Tensor &map(int op, DU v = 0);
+    Tensor &identity();
+    Tensor &normalize(DU avg, DU std);
+    Tensor &operator=(Tensor &t);            // copy elements (k_copy)
+    DU sum(); DU avg(); DU std(); DU norm(); DU max(); DU min();
+    DU dot(Tensor &B);
+    DU loss(Loss op, Tensor &tgt);           // destructive, as the reference's Tensor::loss
+    DU det();
+    uint32_t has_nan();
+    // host access (synchronises)
+    void to_host(std::vector<float> &h, uint64_t n = 0);
+    void from_host(const float *h, uint64_t n, uint64_t off = 0);
+    DU   get(uint64_t i);
+    void set(uint64_t i, DU v);
+
+    static Tensor &ten_op(int op, Tensor &A, DU v, Tensor &O);
+    static Tensor &ten_op(int op, Tensor &A, Tensor &B, Tensor &O);
+    static Tensor &mm(Tensor &A, Tensor &B, Tensor &O, bool inc = false, bool tA = false, bool tB = false);
+    static Tensor &gemm(int variant, Tensor &A, Tensor &B, Tensor &O, DU alpha, DU beta);
+    static Tensor &transpose(Tensor &A, Tensor &T);
+    static Tensor &inverse(Tensor &A, Tensor &I);
+    static Tensor &lu_inverse(Tensor &A, Tensor &I);
+    static Tensor &plu(Tensor &A, Tensor &I, int *piv_dev);
+    static Tensor &lu(Tensor &LU, bool get_u);
+};
+
+// ---------------------------------------------------------------- object store
+class Store {
+public:
+    static Store &get();
+    Tensor &tensor(uint64_t sz);
+    Tensor &tensor(uint32_t h, uint32_t w);
+    Tensor &tensor(uint32_t n, uint32_t h, uint32_t w, uint32_t c);
+    Tensor &copy(Tensor &t);                          // deep copy (grad pointers dropped)
+    Tensor &slice(Tensor &t, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1);
+    Tensor &dim(Tensor &t);
+    struct Model   &model(int *trace);
+    struct Dataset &dataset(uint32_t batch);
+    void free(Tensor &t);
+    void drop(Obj &o);
+    void mark_free(DU v);
+    void sweep();
+    Obj &du2obj(DU v);
+    DU   obj2du(Obj &o);
+    int  live() const { return nlive_; }
+private:
+    std::vector<Obj *> objs_;
+    std::vector<int> free_ids_;
+    std::vector<DU> marked_;
+    int nlive_ = 0;
+    int put(Obj *o);
+    void release(Obj *o);
+};
+
+// ---------------------------------------------------------------- Dataset / loaders
+struct Corpus {
+    std::string name, f_data, f_label;
+    int N = 0, H = 0, W = 0, C = 0, corpus_sz = 0, batch_sz = 0;
+    bool eof = false;
+    std::vector<uint8_t> data, label;
+    FILE *fd = nullptr, *fl = nullptr;
+    bool init(int batch);                      // src/ld/mnist.cpp:21-62 (IDX header, big endian)
+    bool fetch(int batch_id);
+    void rewind();
+    bool cifar = false;
+};
+struct Dataset : Tensor {
+    uint64_t dataset_size = 0;
+    int batch_id = 0, batch_sz = 0, done = 1;
+    uint32_t *label = nullptr;                 // device
+    uint8_t *raw_dev = nullptr;                // device staging of the u8 batch
+    DU mean = 0.0f, scale = 1.0f / 256.0f;     // src/mu/dataset.h:36-37
+    Corpus *cp = nullptr;
+    void set_norm(DU m, DU s) { mean = m; scale = 1.0f / s; }
+    int  fetch(const char *ds_name, bool rewind);
+};
+
+// ---------------------------------------------------------------- Model
+struct Model : Obj {
+    std::vector<Tensor *> layer;               // layer[i] = input tensor of op i; layer.back() = output
+    bool train = true;
+    bool err = false;
+    int  epoch = 0, iter = 0, hit_ = 0;
+    DU   max_norm = 0;
+    int *trace = nullptr;
+    Tensor *hot = nullptr, *loss_t = nullptr;
+    int  *hit_dev = nullptr;
+
+    Tensor &at(int i) { return *layer[i < 0 ? (int)layer.size() + i : i]; }
+    int  batch_size() { return layer.empty() ? 1 : (int)layer[0]->N(); }
+    void tick() { epoch++; iter = 0; }
+
+    Model &add(int fn, uint32_t n = 0, DU bias = 0, uint16_t *opt = nullptr);
+    Model &forward(Tensor &input);
+    Model &broadcast(Tensor &tgt);
+    Model &backprop();
+    Model &backprop(Tensor &tgt);
+    Tensor &onehot();
+    Tensor &onehot(Tensor &t);
+    Tensor &onehot(Dataset &d);
+    int  hit(bool recalc = true);
+    DU   loss(Loss op);
+    DU   loss(Loss op, Tensor &tgt);
+    Model &sgd(DU lr, DU b = 0.9f);
+    Model &adam(DU lr, DU b1 = 0.9f, DU b2 = 0.999f);
+    Model &adamw(DU lr, DU wd = 0.001f, DU b1 = 0.9f, DU b2 = 0.999f);
+    void  free_all();
+private:
+    Tensor &T4(uint32_t n, uint32_t h, uint32_t w, uint32_t c);
+    Tensor &VEC(uint64_t n);
+    void RAND(Tensor &t, DU scale);
+    void fstep(Tensor &in, Tensor &out);
+    void bstep(Tensor &in, Tensor &out, bool last);
+    Model &gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd);
+    // one-launch optimizer over a device parameter table
+    void *tab_dev = nullptr; int tab_n = 0; long tab_max = 0; Optim tab_kind = OPTI_SGD;
+    void build_table(Optim op);
+};
+
+// ---------------------------------------------------------------- printing
+std::string fmt_scalar(DU v, int base);                 // src/io/aio.cpp:38-57
+std::string fmt_objname(Obj &o, bool view);             // "T2[2,3]" etc, src/io/aio_tensor.cpp:16-58
+std::string fmt_tensor(Tensor &t);                      // src/io/aio_tensor.cpp:141-226
+std::string fmt_model(Model &m);                        // src/io/aio_model.cpp:65-141
+
+} // namespace t4

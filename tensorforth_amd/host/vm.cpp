@@ -1,0 +1,489 @@
+// vm.cpp - eForth core: outer interpreter, token-threaded inner interpreter, compiler words.
+// Word set and stack effects: reference src/vm/eforth.cpp:155-431; number parsing :459-483;
+// inner-interpreter opcodes :81-137; stack dump format src/debug.cpp:63-81.
+#include "vm.h"
+#include <chrono>
+#include <sstream>
+#include <thread>
+
+namespace t4 {
+
+static inline uint32_t ALIGN4(uint32_t v) { return (v + 3u) & ~3u; }
+static double now_ms() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+VM::VM() : pmem_(PMEM_SZ, 0) { base() = 10; }
+
+// ---------------------------------------------------------------- input
+const char *VM::fetch() {
+    while (pos_ < line_.size() && isspace((unsigned char)line_[pos_])) pos_++;
+    if (pos_ >= line_.size()) return nullptr;
+    size_t e = pos_;
+    while (e < line_.size() && !isspace((unsigned char)line_[e])) e++;
+    tok_ = line_.substr(pos_, e - pos_);
+    pos_ = e;
+    return tok_.c_str();
+}
+std::string VM::scan(char delim) {
+    if (delim == '\n') { std::string s = pos_ < line_.size() ? line_.substr(pos_) : ""; pos_ = line_.size(); return s; }
+    size_t e = line_.find(delim, pos_);
+    std::string s = line_.substr(pos_, e == std::string::npos ? std::string::npos : e - pos_);
+    pos_ = e == std::string::npos ? line_.size() : e + 1;
+    return s;
+}
+
+// ---------------------------------------------------------------- dictionary / compiler
+int VM::find(const char *name) {
+    for (int i = (int)dict_.size() - 1; i > 0; --i) if (dict_[i].name == name) return i;
+    return 0;
+}
+void VM::add(const char *name, std::function<void()> f, bool immd) {
+    Word w; w.name = name; w.immd = immd; w.xt = std::move(f); dict_.push_back(std::move(w));
+}
+void VM::add_cell(uint32_t v) { if (here_ + 4 <= PMEM_SZ) { set_cell(here_, v); here_ += 4; } else pstr("pmem full\n"); }
+void VM::add_du(DU d) { uint32_t u; memcpy(&u, &d, 4); add_cell(u); }
+void VM::add_p(int op, uint32_t operand, bool udf, bool exit) {
+    add_cell(((uint32_t)op << 28) | (udf ? 1u << 27 : 0) | (exit ? 1u << 26 : 0) | (operand & 0xFFFFFFu));
+}
+void VM::add_lit(DU v, bool exit) { add_p(P_LIT, 0, false, exit); add_du(v); }
+void VM::add_w(int w) { Word &c = dict_[w]; add_p(P_WORD, c.udf ? c.pfa : (uint32_t)w, c.udf); }
+int VM::add_str(const std::string &s) {
+    uint32_t sz = ALIGN4((uint32_t)s.size() + 1);
+    if (here_ + sz > PMEM_SZ) return 0;
+    memset(&pmem_[here_], 0, sz); memcpy(&pmem_[here_], s.data(), s.size());
+    here_ += sz;
+    return (int)sz;
+}
+bool VM::new_word() {
+    const char *name = fetch();
+    if (!name || !*name) { pstr(" name?\n"); return false; }
+    if (find(name)) { pstr(name); pstr(" reDef? \n"); }
+    Word w; w.name = name; w.udf = true;
+    here_ = ALIGN4(here_);
+    w.pfa = here_;
+    dict_.push_back(std::move(w));
+    return true;
+}
+
+// ---------------------------------------------------------------- inner interpreter
+void VM::ds_next(uint32_t target) {                      // ForthVM::_ds_next eforth.cpp:614-634
+    Obj &m = st().du2obj(tos_);
+    if (m.type != T_MODEL) { pstr("TOS is not a network model?\n"); return; }
+    Obj &d = st().du2obj(RS(-1));
+    if (d.type != T_DATASET) { pstr("RTOS is not a dataset?\n"); return; }
+    Dataset &ds = (Dataset &)d;
+    if (ds.done) { DU v = rs_pop(); DROP(v); ((Model &)m).tick(); }
+    else { ds.fetch(nullptr, false); ip_ = target; }      // serviced inline (reference: OP_FETCH + HOLD)
+}
+void VM::nest() {
+    query_ = false;
+    while (ip_ && !stop_) {
+        const uint32_t ix = cell(ip_);
+        const int op = ix >> 28; const uint32_t ioff = ix & 0xFFFFFFu;
+        const bool udf = (ix >> 27) & 1, exitf = (ix >> 26) & 1;
+        ip_ += 4;
+        switch (op) {
+        case P_EXIT: ip_ = (uint32_t)rs_pop(); break;
+        case P_NEXT:
+            if (IS_OBJ(tos_) && !rs_.empty() && IS_OBJ(RS(-1))) ds_next(ioff);
+            else if (((RS(-1) -= 1.0f) - (-1.0f)) > DU_EPS) ip_ = ioff;
+            else rs_pop();
+            break;
+        case P_LOOP:
+            if ((RS(-2) - (RS(-1) += 1.0f)) > DU_EPS) ip_ = ioff;
+            else { rs_pop(); rs_pop(); }
+            break;
+        case P_LIT:
+            ss_.push_back(tos_); tos_ = DUP(mem_du(ip_)); ip_ += 4;
+            if (exitf) ip_ = (uint32_t)rs_pop();
+            break;
+        case P_VAR:
+            PUSH((DU)ALIGN4(ip_));
+            if (ioff) ip_ = ioff; else ip_ = (uint32_t)rs_pop();
+            break;
+        case P_STR:  PUSH((DU)ip_); PUSH((DU)ioff); ip_ += ioff; break;
+        case P_DOTQ: pstr((const char *)&pmem_[ip_]); ip_ += ioff; break;
+        case P_BRAN: ip_ = ioff; break;
+        case P_ZBRAN: if (ZEQ(POP())) ip_ = ioff; break;
+        case P_FOR:  rs_.push_back(POP()); break;
+        case P_DO:   { DU lim = ss_pop(); rs_.push_back(lim); rs_.push_back(POP()); } break;
+        case P_KEY:  PUSH((DU)getchar()); break;
+        default:
+            if (udf) { rs_.push_back((DU)ip_); ip_ = ioff; }
+            else dict_[ioff].xt();
+        }
+    }
+}
+void VM::call(int w) {
+    Word &c = dict_[w];
+    if (c.udf) { rs_.push_back((DU)ip_); ip_ = c.pfa; nest(); }
+    else c.xt();
+}
+
+// ---------------------------------------------------------------- outer interpreter
+DU VM::number(const char *idiom, bool &ok) {             // ForthVM::number eforth.cpp:459-483
+    int b = base();
+    switch (*idiom) {
+    case '%': b = 2; idiom++; break;
+    case '&': case '#': b = 10; idiom++; break;
+    case '$': b = 16; idiom++; break;
+    }
+    char *p = nullptr;
+    double d = (b == 10 && strchr(idiom, '.')) ? strtof(idiom, &p) : (double)strtol(idiom, &p, b);
+    ok = (*idiom != '\0') && p && *p == '\0';
+    return (DU)d;
+}
+int VM::process(const char *idiom) {                     // TensorVM::process tenvm.cpp:16-40
+    query_ = true;
+    int w = find(idiom);
+    if (w) {
+        if (compile_ && !dict_[w].immd) add_w(w);
+        else { ip_ = 0; call(w); }
+        return 1;
+    }
+    bool ok; DU n = number(idiom, ok);
+    if (!ok) return 0;
+    n = SCALAR(n);
+    if (compile_) add_lit(n);
+    else if (ten_lvl_ > 0) {                             // literal goes into the tensor on TOS
+        if (ten_stage_.size() <= ten_off_ - ten_base_) ten_stage_.resize(ten_off_ - ten_base_ + 1);
+        ten_stage_[ten_off_ - ten_base_] = n; ten_off_++;
+    } else PUSH(n);
+    return 1;
+}
+bool VM::eval(const std::string &line) {
+    line_ = line; pos_ = 0;
+    const char *idiom;
+    while (!stop_ && (idiom = fetch()) != nullptr) {
+        std::string tk = idiom;
+        if (!process(tk.c_str())) {
+            pstr(tk); pstr("? \n");
+            compile_ = false; pos_ = line_.size();
+            break;
+        }
+    }
+    if (!compile_ && !stop_) ss_dump();
+    st().sweep();                                        // objects marked by `.` are released once per line
+    return !stop_;
+}
+
+// ---------------------------------------------------------------- output
+void VM::dot_obj(DU v) {
+    Obj &o = st().du2obj(v);
+    if (o.type == T_MODEL) pstr(fmt_model((Model &)o)); else pstr(fmt_tensor((Tensor &)o));
+}
+void VM::dot(DU v) {
+    if (IS_OBJ(v)) { dot_obj(v); pstr(" "); st().mark_free(v); return; }
+    char buf[48]; snprintf(buf, sizeof(buf), "%g", v);   // ostream << float, default precision 6
+    std::string s = buf;
+    if (fmt_w_ > (int)s.size()) s = std::string(fmt_w_ - s.size(), ' ') + s;
+    fmt_w_ = 0;
+    pstr(s); pstr(" ");
+}
+void VM::ss_dump() {                                     // Debug::ss_dump debug.cpp:63-81
+    auto show = [&](DU v) {
+        if (IS_OBJ(v)) pstr(fmt_objname(st().du2obj(v), IS_VIEW(v))); else pstr(fmt_scalar(v, base()));
+        pstr(" ");
+    };
+    for (DU v : ss_) show(v);
+    show(tos_);
+    pstr("-> ok\n");
+}
+void VM::words() {
+    int sz = 0;
+    for (auto &w : dict_) {
+        pstr("  "); pstr(w.name);
+        sz += w.name[0] == '\n' ? 72 : (int)w.name.size() + 2;
+        if (sz >= 72) { pstr("\n"); sz = 0; }
+    }
+    pstr("\n");
+}
+void VM::see(int w) {
+    Word &c = dict_[w];
+    pstr(": "); pstr(c.name);
+    if (!c.udf) { pstr(" ( built-in ) ;\n"); return; }
+    static const char *pn[] = {";", "next", "loop", "lit", "var", "str", "dotq", "bran", "0bran", "for", "do", "key"};
+    uint32_t end = (w + 1 < (int)dict_.size() && dict_[w + 1].udf) ? dict_[w + 1].pfa : here_;
+    for (uint32_t a = c.pfa; a + 4 <= end;) {
+        uint32_t ix = cell(a); int op = ix >> 28; uint32_t ioff = ix & 0xFFFFFFu; a += 4;
+        char buf[96];
+        if (op == P_WORD) {
+            const char *nm = "?";
+            if ((ix >> 27) & 1) { for (auto &d : dict_) if (d.udf && d.pfa == ioff) nm = d.name.c_str(); }
+            else if (ioff < dict_.size()) nm = dict_[ioff].name.c_str();
+            snprintf(buf, sizeof(buf), "\n  %04x: %s", a - 4, nm);
+        } else if (op == P_LIT) { snprintf(buf, sizeof(buf), "\n  %04x: lit %g", a - 4, mem_du(a)); a += 4; }
+        else if (op == P_STR || op == P_DOTQ) { snprintf(buf, sizeof(buf), "\n  %04x: %s \"%s\"", a - 4, pn[op], (const char *)&pmem_[a]); a += ioff; }
+        else if (op == P_VAR) { snprintf(buf, sizeof(buf), "\n  %04x: var %g", a - 4, mem_du(a)); a = end; }
+        else snprintf(buf, sizeof(buf), "\n  %04x: %s %04x", a - 4, op < 12 ? pn[op] : "?", ioff);
+        pstr(buf);
+        if (op == P_EXIT) break;
+    }
+    pstr("\n");
+}
+
+// ---------------------------------------------------------------- scalar ALU (VM::xop1/xop2 vm.cpp:66-105)
+void VM::sxop1(int op) {
+    DU t = tos_;
+    switch (op) {
+    case T4K_ABS: t = fabsf(t); break;
+    case T4K_NEG: t = -t; break;
+    case T4K_EXP: t = expf(t); break;
+    case T4K_LN:  t = t > DU_EPS ? logf(t) : 0.0f; break;
+    case T4K_LOG: t = t > DU_EPS ? log10f(t) : 0.0f; break;
+    case T4K_TANH: t = tanhf(t); break;
+    case T4K_RELU: t = fmaxf(t, 0.0f); break;
+    case T4K_SIGM: t = 1.0f / (1.0f + expf(-t)); break;
+    case T4K_SQRT: t = sqrtf(t); break;
+    case T4K_RCP: t = 1.0f / t; break;
+    case T4K_SAT: t = fminf(1.0f, fmaxf(0.0f, t)); break;
+    case T4K_SIN: t = sinf(t); break;
+    case T4K_COS: t = cosf(t); break;
+    default: pstr("method not supported: op=%d?\n"); break;
+    }
+    tos_ = SCALAR(t);
+}
+void VM::sxop2(int op) {
+    DU t = tos_, n = ss_pop();
+    switch (op) {
+    case T4K_ADD: t = n + t; break;
+    case T4K_MUL: t = n * t; break;
+    case T4K_SUB: t = n - t; break;
+    case T4K_DIV: t = n / t; break;
+    case T4K_MOD: t = fmodf(n, t); break;
+    case T4K_MAX: t = fmaxf(n, t); break;
+    case T4K_MIN: t = fminf(n, t); break;
+    case T4K_POW: t = powf(t, n); break;
+    default: pstr("method not supported: op=%d?\n"); break;
+    }
+    tos_ = SCALAR(t);
+}
+
+// ---------------------------------------------------------------- core vocabulary
+void VM::init_core() {
+    auto CODE = [this](const char *n, std::function<void()> f) { add(n, std::move(f), false); };
+    auto IMMD = [this](const char *n, std::function<void()> f) { add(n, std::move(f), true); };
+    CODE("\nForth::", [] {});
+    CODE("nop", [] {});
+    // stack
+    CODE("dup",  [this] { PUSH(DUP(tos_)); });
+    CODE("drop", [this] { DROP(tos_); tos_ = ss_pop(); });
+    CODE("over", [this] { DU v = DUP(SS(-1)); PUSH(v); });
+    CODE("swap", [this] { DU n = ss_pop(); PUSH(n); });
+    CODE("rot",  [this] { DU n = ss_pop(); DU m = ss_pop(); ss_.push_back(n); PUSH(m); });
+    CODE("-rot", [this] { DU n = ss_pop(); DU m = ss_pop(); PUSH(m); PUSH(n); });
+    CODE("pick", [this] { int i = (int)tos_; tos_ = DUP(SS(-i)); });
+    CODE("nip",  [this] { ss_.pop_back(); });
+    CODE("?dup", [this] { if (tos_ != 0.0f) PUSH(tos_); });
+    CODE("2dup", [this] { DU v = DUP(SS(-1)); PUSH(v); v = DUP(SS(-1)); PUSH(v); });
+    CODE("2drop", [this] { DU s = ss_pop(); DROP(s); DROP(tos_); tos_ = ss_pop(); });
+    CODE("2over", [this] { DU v = DUP(SS(-3)); PUSH(v); v = DUP(SS(-3)); PUSH(v); });
+    CODE("2swap", [this] { DU n = ss_pop(); DU m = ss_pop(); DU l = ss_pop();
+                           ss_.push_back(n); PUSH(l); PUSH(m); });
+    // arithmetic
+    CODE("+", [this] { xop2(T4K_ADD, true); });
+    CODE("-", [this] { xop2(T4K_SUB, true); });
+    CODE("*", [this] { xop2(T4K_MUL, true); });
+    CODE("/", [this] { xop2(T4K_DIV, true); });
+    CODE("mod",  [this] { DU n = ss_pop(); DU m = (DU)((int)n % (int)tos_); tos_ = SCALAR(m); });
+    CODE("fmod", [this] { DU n = ss_pop(); DU m = fmodf(n, tos_); tos_ = SCALAR(m); });
+    CODE("/mod", [this] { DU n = ss_pop(); DU m = fmodf(n, tos_); ss_.push_back(m); DU v = n / tos_; tos_ = SCALAR(v); });
+    CODE("*/",   [this] { double a = ss_pop(); double b = ss_pop(); DU v = (DU)(a * b / tos_); tos_ = SCALAR(v); });
+    CODE("*/mod", [this] { double a = ss_pop(); double b = ss_pop(); double n2 = a * b;
+                           DU m = (DU)fmod(n2, (double)tos_); ss_.push_back(SCALAR(m)); DU v = floorf((DU)(n2 / tos_)); tos_ = SCALAR(v); });
+    CODE("and", [this] { DU n = ss_pop(); tos_ = (DU)((int)tos_ & (int)n); });
+    CODE("or",  [this] { DU n = ss_pop(); tos_ = (DU)((int)tos_ | (int)n); });
+    CODE("xor", [this] { DU n = ss_pop(); tos_ = (DU)((int)tos_ ^ (int)n); });
+    CODE("abs", [this] { xop1(T4K_ABS); });
+    CODE("negate", [this] { xop1(T4K_NEG); });
+    CODE("invert", [this] { tos_ = (DU)(~(int)tos_); });
+    CODE("rshift", [this] { DU n = ss_pop(); tos_ = (DU)((int)n >> (int)tos_); });
+    CODE("lshift", [this] { DU n = ss_pop(); tos_ = (DU)((int)n << (int)tos_); });
+    CODE("max", [this] { DU n = ss_pop(); tos_ = (tos_ > n) ? tos_ : n; });
+    CODE("min", [this] { DU n = ss_pop(); tos_ = (tos_ < n) ? tos_ : n; });
+    CODE("2*", [this] { tos_ *= 2.0f; });
+    CODE("2/", [this] { tos_ /= 2.0f; });
+    CODE("1+", [this] { tos_ += 1.0f; });
+    CODE("1-", [this] { tos_ -= 1.0f; });
+    CODE("f>s",   [this] { tos_ = (DU)(int)tos_; });
+    CODE("round", [this] { tos_ = roundf(tos_); });
+    CODE("ceil",  [this] { tos_ = ceilf(tos_); });
+    CODE("floor", [this] { tos_ = floorf(tos_); });
+    // logic (epsilon compares, booleans 0 / -1: ten4_types.h:85-90)
+    CODE("0=", [this] { tos_ = BOOL(ZEQ(tos_)); });
+    CODE("0<", [this] { tos_ = BOOL(tos_ < -DU_EPS); });
+    CODE("0>", [this] { tos_ = BOOL(tos_ > DU_EPS); });
+    CODE("=",  [this] { DU n = ss_pop(); tos_ = BOOL(ZEQ(n - tos_)); });
+    CODE(">",  [this] { DU n = ss_pop(); tos_ = BOOL((n - tos_) > DU_EPS); });
+    CODE("<",  [this] { DU n = ss_pop(); tos_ = BOOL((n - tos_) < -DU_EPS); });
+    CODE("<>", [this] { DU n = ss_pop(); tos_ = BOOL(!ZEQ(n - tos_)); });
+    CODE(">=", [this] { DU n = ss_pop(); tos_ = BOOL(!((n - tos_) < -DU_EPS)); });
+    CODE("<=", [this] { DU n = ss_pop(); tos_ = BOOL(!((n - tos_) > DU_EPS)); });
+    CODE("u<", [this] { DU n = ss_pop(); tos_ = BOOL((uint32_t)(int)n < (uint32_t)(int)tos_); });
+    CODE("u>", [this] { DU n = ss_pop(); tos_ = BOOL((uint32_t)(int)n > (uint32_t)(int)tos_); });
+    // io
+    CODE("base",    [this] { PUSH(0.0f); });
+    CODE("decimal", [this] { base() = 10; });
+    CODE("hex",     [this] { base() = 16; });
+    CODE("bl",      [this] { PUSH(32.0f); });
+    CODE("cr",      [this] { pstr("\n"); });
+    CODE(".",       [this] { dot(POP()); });
+    CODE("u.",      [this] { char b[24]; snprintf(b, sizeof(b), "%u ", (uint32_t)(int)POP()); pstr(b); });
+    CODE(".r",      [this] { fmt_w_ = POPi(); DU v = POP(); char b[48]; snprintf(b, sizeof(b), "%g", v); std::string s = b;
+                             if (fmt_w_ > (int)s.size()) s = std::string(fmt_w_ - s.size(), ' ') + s; fmt_w_ = 0; pstr(s); });
+    CODE("u.r",     [this] { int w = POPi(); DU v = POP(); char b[48]; snprintf(b, sizeof(b), "%u", (uint32_t)v); std::string s = b;
+                             if (w > (int)s.size()) s = std::string(w - s.size(), ' ') + s; pstr(s); });
+    CODE("type",    [this] { POP(); pstr((const char *)&pmem_[(uint32_t)POPi()]); });
+    IMMD("key",     [this] { if (compile_) add_p(P_KEY); else PUSH((DU)getchar()); });
+    CODE("emit",    [this] { char c = (char)(int)POP(); out_.push_back(c); });
+    CODE("space",   [this] { pstr(" "); });
+    CODE("spaces",  [this] { int n = POPi(); if (n > 0) pstr(std::string(n, ' ')); });
+    // literals
+    IMMD("(",   [this] { scan(')'); });
+    IMMD(".(",  [this] { pstr(scan(')')); });
+    IMMD("\\",  [this] { scan('\n'); });
+    auto quote = [this](int op) {
+        std::string s = scan('"');
+        if (!s.empty() && s[0] == ' ') s = s.substr(1);
+        if (compile_) { add_p(op, ALIGN4((uint32_t)s.size() + 1)); add_str(s); }
+        else {
+            uint32_t h0 = here_; int len = add_str(s);
+            if (op == P_STR) { PUSH((DU)h0); PUSH((DU)len); } else pstr((const char *)&pmem_[h0]);
+            here_ = h0;
+        }
+    };
+    IMMD("s\"", [quote] { quote(P_STR); });
+    IMMD(".\"", [quote] { quote(P_DOTQ); });
+    // branching / loops
+    IMMD("if",    [this] { PUSH((DU)here_); add_p(P_ZBRAN); });
+    IMMD("else",  [this] { uint32_t h = here_; add_p(P_BRAN); setjmp_at((uint32_t)POPi()); PUSH((DU)h); });
+    IMMD("then",  [this] { setjmp_at((uint32_t)POPi()); });
+    IMMD("begin", [this] { PUSH((DU)here_); });
+    IMMD("again", [this] { add_p(P_BRAN, (uint32_t)POPi()); });
+    IMMD("until", [this] { add_p(P_ZBRAN, (uint32_t)POPi()); });
+    IMMD("while", [this] { PUSH((DU)here_); add_p(P_ZBRAN); });
+    IMMD("repeat", [this] { uint32_t t = (uint32_t)POPi(); add_p(P_BRAN, (uint32_t)POPi()); setjmp_at(t); });
+    IMMD("for",   [this] { add_p(P_FOR); PUSH((DU)here_); });
+    IMMD("next",  [this] { add_p(P_NEXT, (uint32_t)POPi()); });
+    IMMD("aft",   [this] { POP(); uint32_t h = here_; add_p(P_BRAN); PUSH((DU)here_); PUSH((DU)h); });
+    IMMD("do",    [this] { add_p(P_DO); PUSH((DU)here_); });
+    CODE("i",     [this] { PUSH(RS(-1)); });
+    CODE("leave", [this] { rs_pop(); rs_pop(); ip_ = (uint32_t)rs_pop(); });
+    IMMD("loop",  [this] { add_p(P_LOOP, (uint32_t)POPi()); });
+    CODE(">r", [this] { rs_.push_back(POP()); });
+    CODE("r>", [this] { PUSH(rs_pop()); });
+    CODE("r@", [this] { PUSH(DUP(RS(-1))); });
+    // compiler
+    CODE("[", [this] { compile_ = false; });
+    CODE("]", [this] { compile_ = true; });
+    CODE(":", [this] { compile_ = new_word(); });
+    IMMD(";", [this] { add_p(P_EXIT); compile_ = false; });
+    CODE("variable", [this] { if (!new_word()) return; add_p(P_VAR, 0, true); add_du(0.0f); });
+    CODE("constant", [this] { if (!new_word()) return; add_lit(POP(), true); });
+    CODE("value",    [this] { if (!new_word()) return; add_p(P_LIT, 0, true, true); add_du(POP()); });
+    IMMD("immediate", [this] { dict_.back().immd = true; });
+    CODE("exit",   [this] { ip_ = (uint32_t)rs_pop(); });
+    CODE("exec",   [this] { int w = (int)POP(); call(w); });
+    CODE("create", [this] { if (!new_word()) return; add_p(P_VAR, 0, true); });
+    CODE("does>",  [this] {
+        uint32_t pfa = dict_.back().pfa;
+        while ((cell(pfa) >> 28) != P_VAR && pfa < here_) pfa += 4;
+        setjmp_at(pfa);
+        add_p(P_BRAN, ip_); ip_ = (uint32_t)rs_pop();
+    });
+    IMMD("to", [this] {
+        int w = query_ ? find(fetch() ? tok_.c_str() : "") : POPi();
+        if (!w) return;
+        if (compile_) { add_lit((DU)w); add_w(find("to")); }
+        else { uint32_t pfa = dict_[w].pfa; if ((cell(pfa) >> 28) == P_LIT) set_du(pfa + 4, POP()); }
+    });
+    IMMD("is", [this] {
+        int w = query_ ? find(fetch() ? tok_.c_str() : "") : POPi();
+        if (!w) return;
+        if (compile_) { add_lit((DU)w); add_w(find("is")); }
+        else { int d = POPi(); dict_[d].xt = dict_[w].xt; dict_[d].udf = dict_[w].udf; dict_[d].pfa = dict_[w].pfa; }
+    });
+    CODE("[to]", [this] {
+        uint32_t a = (cell(ip_) & 0xFFFFFFu) + 4; DU d = POP(); ip_ += 4;
+        if (a < PMEM_SZ) set_du(a, d); else { pstr("is ?"); stop_ = true; }
+    });
+    // memory
+    CODE("@",  [this] { uint32_t i = (uint32_t)POPi(); PUSH(mem_du(i)); });
+    CODE("!",  [this] { uint32_t i = (uint32_t)POPi(); set_du(i, POP()); });
+    CODE("c@", [this] { uint32_t i = (uint32_t)POPi(); PUSH((DU)pmem_[i]); });
+    CODE("c!", [this] { uint32_t i = (uint32_t)POPi(); pmem_[i] = (uint8_t)POPi(); });
+    CODE("+!", [this] { uint32_t i = (uint32_t)POPi(); DU v = mem_du(i) + POP(); set_du(i, SCALAR(v)); });
+    CODE("?",  [this] { uint32_t i = (uint32_t)POPi(); dot(mem_du(i)); });
+    CODE(",",  [this] { add_du(POP()); });
+    CODE("cells", [this] { int i = POPi(); PUSH((DU)(i * 4)); });
+    CODE("allot", [this] { int n = POPi(); for (int i = 0; i < n; i += 4) add_du(0.0f); });
+    CODE("th",    [this] { int i = POPi(); tos_ += i * 4; });
+    // debug / os
+    CODE("abort", [this] { tos_ = -1.0f; ss_.clear(); rs_.clear(); });
+    CODE("here",  [this] { PUSH((DU)here_); });
+    CODE("'",     [this] { const char *n = fetch(); int w = n ? find(n) : 0; if (w) PUSH((DU)w); });
+    CODE(".s",    [this] { ss_dump(); });
+    CODE("depth", [this] { PUSH((DU)((int)SP() - 1)); });
+    CODE("words", [this] { words(); });
+    CODE("dict",  [this] { words(); });
+    CODE("dict_dump", [this] { words(); });
+    CODE("see",   [this] { const char *n = fetch(); int w = n ? find(n) : 0; if (w) see(w); });
+    CODE("dump",  [this] {
+        int n = POPi(); uint32_t a = (uint32_t)POP();
+        for (uint32_t i = a & ~15u; i <= ((a + n + 15) & ~15u) && i + 16 <= PMEM_SZ; i += 16) {
+            char b[96]; int x = snprintf(b, sizeof(b), "%04x: ", i);
+            for (int j = 0; j < 16; j++) x += snprintf(b + x, sizeof(b) - x, "%02x%s", pmem_[i + j], (j % 4 == 3) ? "  " : " ");
+            pstr(b); pstr("\n");
+        }
+    });
+    CODE("forget", [this] {
+        const char *n = fetch(); int w = n ? find(n) : 0; if (!w) return;
+        int b = find("boot") + 1; if (w < b) w = b;
+        if (dict_[w].udf) here_ = dict_[w].pfa;
+        dict_.resize(w);
+    });
+    CODE("trace", [this] { trace_lvl = POPi(); });
+    CODE("mstat", [this] {
+        char b[160]; snprintf(b, sizeof(b), "\\ MMU.stat dict[%d/1024], pmem[%d]=%0.1f%%, obj#used[%d], HBM used=%zu KiB in %zu blocks\n",
+                              (int)dict_.size(), here_, 100.0 * here_ / PMEM_SZ, st().live(), Arena::get().used() >> 10, Arena::get().live());
+        pstr(b);
+    });
+    CODE("ms",    [this] { std::this_thread::sleep_for(std::chrono::milliseconds(POPi())); });
+    CODE("flush", [] { fflush(stdout); });
+    CODE("sprintf", [this] {                             // ( n1 [n2 ..] addr u -- addr' u' )  eforth.cpp:576-611
+        POPi(); std::string buf = (const char *)&pmem_[(uint32_t)POP()];
+        auto t2s = [this](char c) {
+            std::ostringstream n;
+            switch (c) {
+            case 'd': n << (uint32_t)POP(); break;
+            case 'g': case 'f': n << (DU)POP(); break;
+            case 'x': n << "0x" << std::hex << (uint32_t)POP(); break;
+            case 's': POP(); n << (const char *)&pmem_[(uint32_t)POP()]; break;
+            default: n << c << '?'; break;
+            }
+            return n.str();
+        };
+        for (size_t i = buf.find_last_of('%'); i != std::string::npos; i = buf.find_last_of('%', i ? i - 1 : 0)) {
+            if (i && buf[i - 1] == '%') buf.replace(--i, 1, "");
+            else buf.replace(i, 2, t2s(buf[i + 1]));
+            if (i == 0) break;
+        }
+        uint32_t h0 = here_; int len = add_str(buf);
+        PUSH((DU)h0); PUSH((DU)len);
+        here_ = h0;
+    });
+    CODE("clock", [this] { DU t = (DU)now_ms(); PUSH(SCALAR(t)); });
+    CODE("bye",   [this] { stop_ = true; });
+    CODE("boot",  [this] { int b = find("boot") + 1; if ((int)dict_.size() > b) { if (dict_[b].udf) here_ = dict_[b].pfa; dict_.resize(b); } });
+}
+
+void VM::init() {
+    dict_.clear();
+    init_core();
+    init_tensor();
+    init_nn();
+}
+
+} // namespace t4

@@ -1,0 +1,10 @@
+#!/bin/sh
+# Regenerates tests/golden/vm/*.out: the output of the oracle-backed VM (oracle/ten4_oracle, CPU)
+# on the Forth scripts under tests/scripts/ with T4_SEED=1.  test_vm_scripts.py checks (on CPU) that
+# ten4_oracle still reproduces these files and (on the GPU) that the HIP-backed `ten4` matches them.
+cd "$(dirname "$0")/../../.." || exit 1
+make -C oracle ten4_oracle >/dev/null || exit 1
+for s in tests/scripts/*.4th; do
+    n=$(basename "$s" .4th)
+    T4_SEED=1 oracle/ten4_oracle < "$s" > "tests/golden/vm/$n.out" || exit 1
+done

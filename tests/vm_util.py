@@ -1,0 +1,75 @@
+"""Helpers for the script-level (Forth VM) parity tests.
+
+`ten4` is the product (host VM over libt4hip.so, needs a GPU); `ten4_oracle` is the same host
+sources linked against oracle/t4k_on_oracle.cpp (CPU, test infrastructure).  Both read Forth source
+on stdin; outputs are compared token by token - words must match exactly, numbers within the
+tolerance of the 4-decimal / 6-significant-digit formats the printer uses.
+"""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TEN4 = os.path.join(ROOT, "tensorforth_amd", "ten4")
+TEN4_ORACLE = os.path.join(ROOT, "oracle", "ten4_oracle")
+SCRIPTS = os.path.join(ROOT, "tests", "scripts")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "vm")
+
+_NUM = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)(e[+-]?\d+)?$|^[+-]?nan$|^[+-]?inf$", re.I)
+
+
+def run_vm(binary, script_path=None, source=None, seed=1, timeout=300, env_extra=None):
+    if source is None:
+        with open(script_path) as f:
+            source = f.read()
+    env = dict(os.environ, T4_SEED=str(seed))
+    if env_extra:
+        env.update(env_extra)
+    r = subprocess.run([binary], input=source, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, f"{binary} rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
+    return r.stdout
+
+
+def tokens(text):
+    out = []
+    for line in text.splitlines():
+        if line.startswith("tensorForth v4.0") or line.startswith("\\ MMU") or line.startswith("\\ "):
+            continue                                    # banner / mstat lines name the backend
+        for t in line.split():
+            parts = t.split("_")                        # conv filters print as +a_+b_+c groups
+            out.extend(parts if len(parts) > 1 and all(_NUM.match(q) for q in parts) else [t])
+    return out
+
+
+def compare(a_text, b_text, rtol=2e-4, atol=2.5e-4):
+    """Return a list of mismatch descriptions (empty = parity)."""
+    a, b = tokens(a_text), tokens(b_text)
+    bad = []
+    if len(a) != len(b):
+        bad.append(f"token count {len(a)} != {len(b)}")
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x == y:
+            continue
+        if _NUM.match(x) and _NUM.match(y):
+            fx, fy = float(x), float(y)
+            if fx != fx and fy != fy:
+                continue
+            if abs(fx - fy) <= atol + rtol * max(abs(fx), abs(fy)):
+                continue
+        bad.append(f"token {i}: {x!r} != {y!r} (context: {' '.join(a[max(0, i - 4):i + 3])})")
+        if len(bad) > 10:
+            break
+    return bad
+
+
+def numbers_after(text, label, count):
+    """The `count` numbers that follow the first occurrence of `label` in the VM output."""
+    toks = tokens(text)
+    i = toks.index(label)
+    vals = []
+    for t in toks[i + 1:]:
+        if _NUM.match(t):
+            vals.append(float(t))
+            if len(vals) == count:
+                break
+    return vals
