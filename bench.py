@@ -47,54 +47,64 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
-    if world > 1:
+    dp = world > 1 or os.environ.get("T4_BENCH_FORCE_DP") == "1"     # FORCE_DP: exercise the all-reduce path on one GPU
+    if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
-    from tensorforth_amd import pymodel
+    from tensorforth_amd import lib as t4lib, pymodel
+    from tensorforth_amd.vm import VM
     N = args.batch
-    m = pymodel.Model(N, 28, 28, 1, seed=1234, device="cuda:%d" % local)
-    m.k.call("t4k_set_default_stream", None)             # share torch's current (null) stream with RCCL
-    build = pymodel.nn_c if args.net == "nn_c" else pymodel.nn_f
-    build(m).finalize()
-    if world > 1:                                         # identical replicas: broadcast rank 0's weights
-        for L in m.layers:
-            for t in (L.w, L.b):
-                if t is not None:
-                    dist.broadcast(t, 0)
-    # synthetic MNIST-shaped batch, resident in HBM (seed 42; class-dependent blob + noise)
-    rng = np.random.default_rng(42 + rank)
-    lab = rng.integers(0, 10, N).astype(np.uint32)
-    x = rng.random((N, 28, 28, 1)).astype(np.float32) * 0.2
-    for i, l in enumerate(lab):
-        x[i, 2 * l:2 * l + 8, 2 * l:2 * l + 8, 0] += 0.8
-    xd = torch.from_numpy(x).cuda(); labd = torch.from_numpy(lab.view(np.int32)).cuda()
-    m.forward(xd); m.onehot_labels(labd); m.sync()
+    build = pymodel.nn_c if args.net == "nn_c" else pymodel.nn_f      # layer lists shared with the oracle baseline
+    # ---- the product: native C++ eForth VM (libten4.so) driving libt4hip.so; the model, the synthetic HBM-resident
+    # batch and the training step are all plain tensorForth words (same source runs under the stand-alone `ten4`)
+    vm = VM(device=local, seed=1234)
+    NET_WORDS = {"nn_f": "0.5 10 conv2d 2 maxpool relu 0.5 20 conv2d 0.5 dropout 2 maxpool relu flatten 100 linear 0.5 dropout 10 linear softmax",
+                 "nn_c": "0.5 10 conv2d 2 maxpool relu flatten 100 linear relu 10 linear softmax"}
+    vm.eval("0 trace\n%d 28 28 1 nn.model %s constant net\n" % (N, NET_WORDS[args.net]))
+    k = t4lib.load()
+    if world > 1:                                         # replicas are identical (same Philox seed and offsets so far);
+        k.call("t4k_rand_set_offset", (rank + 1) << 36)   # from here each rank draws its own shard and dropout masks
+    out_txt = vm.eval(
+        "%d 28 28 1 tensor rand constant img\n"
+        ": hot ( T -- T ) %d 0 do 1 i 10 * i 7 * %d + 10 mod + t! loop ;\n"
+        "%d vector zeros hot %d 1 10 1 reshape4 constant lbl\n"
+        ": fb ( N -- N ) img forward lbl backprop ;\n"
+        ": opt ( N -- N ) 0.01 0.0 nn.sgd ;\n"
+        ": steps ( N n -- N ) 1- for fb opt next ;\n"
+        "net 2 steps\n" % (N, N, rank, N * 10, N))
+    assert "?" not in out_txt.replace("-> ok", ""), out_txt
+    slab = vm.grad_slab() if dp else None
+    vstream = vm.stream() if dp else None
 
-    def step():
-        m.forward(xd)
-        m.backprop()                                      # against the cached one-hot target
-        if world > 1:
-            dist.all_reduce(m.grad_slab, op=dist.ReduceOp.SUM)
-        m.sgd(0.01, 0.0)
+    def run(n):
+        if not dp:
+            vm.eval("%d steps" % n)                       # the whole loop runs inside the VM
+            return
+        for _ in range(n):
+            vm.eval("fb")
+            with torch.cuda.stream(vstream):              # ordered with the VM's kernels; SUM: raw batch-sum gradients (quirk a-19)
+                dist.all_reduce(slab, op=dist.ReduceOp.SUM)
+            vm.eval("opt")
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tmax = torch.tensor([dt], device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.cpu()[0])
+    loss_txt = vm.eval("lbl loss.ce .")
     ms_step = dt / args.steps * 1e3
     img_s = world * N * args.steps / dt
 
@@ -109,13 +119,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
-                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "python->C-ABI (pymodel)"},
+                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)",
+                       "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                               "traffic": None, "algorithmic_bytes_per_step": step_bytes},
         }
         # ---- GEMM 1024^3 fp32 (word `matmul`), HIP events on the launch stream
-        k = m.k
         g = torch.Generator(device="cuda"); g.manual_seed(1234)
         A = torch.rand(1024, 1024, device="cuda", generator=g); B = torch.rand(1024, 1024, device="cuda", generator=g)
         O = torch.zeros(1024, 1024, device="cuda")
@@ -142,6 +152,9 @@ def main():
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import t4oracle
+            rng = np.random.default_rng(42)
+            lab = rng.integers(0, 10, N).astype(np.uint32)
+            x = rng.random((N, 28, 28, 1)).astype(np.float32)
             om = build(t4oracle.OracleModel(N, 28, 28, 1, seed=1234))
             om.forward(x); om.onehot_labels(lab)
             t0 = time.perf_counter(); nst = 0
@@ -160,7 +173,7 @@ def main():
                                    "gemm_1024_host_blocked_ms": round(gdt * 1e3, 1),
                                    "gemm_1024_host_gflops": round(flops / gdt / 1e9, 2)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier(); dist.destroy_process_group()
 
 

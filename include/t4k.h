@@ -79,8 +79,11 @@ int t4k_memcpy_d2d(void *dst, const void *src, size_t bytes, t4k_stream_t s);
 int t4k_memset(void *dst, int byte, size_t bytes, t4k_stream_t s);   /* Tensor::zeros tensor.cu:558-563 */
 int t4k_sync(t4k_stream_t s);
 
+/* Library streams own a private workspace, so independent work (e.g. dW beside dX) may be forked
+ * onto them and still be captured into one graph through event edges. */
 int t4k_stream_create(t4k_stream_t *s);
 int t4k_stream_destroy(t4k_stream_t s);
+int t4k_stream_wait_event(t4k_stream_t s, t4k_event_t e);   /* fork / join edge (also inside a capture) */
 int t4k_set_default_stream(t4k_stream_t s);        /* adopt an external stream (e.g. torch's current) */
 t4k_stream_t t4k_default_stream(void);
 
@@ -150,6 +153,8 @@ int t4k_logdet(const float *LU, int K, float *logdet_dev, int *sign_dev, t4k_str
 /* ------------------------------------------------------- RNG (util.cu:28-70) */
 /* Counter-based Philox4x32-10 replaces the reference's 1024 cuRAND XORWOW states
  * (distribution parity only; the reference seeds from time(), sys.cpp:37). */
+/* The stream state (seed, counter) is DEVICE resident: a t4k_rand captured in a graph draws a fresh
+ * slice on every replay; t4k_rand_offset()/set_offset() synchronise and read/write that state. */
 int t4k_rand_init(uint64_t seed);
 /* d[i] = scale * (bias + u_i), u uniform (0,1] or N(0,1) (util.cu:58-70) */
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s);
@@ -183,7 +188,8 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
                    int K, int S, int P, t4k_stream_t s);
 /* k_dconv2d<TS,KS,S,P> nmath.tcu:211 (Model::_bconv backprop.cu:152-191):
  * DB[c0] += sum dO; DF += sum I*dO (both only if train);
- * DX (overwritten) scatter (i*S+ky-P, j*S+kx-P) += F[c1,K-1-ky,K-1-kx,c0]*dO  (flipped, quirk a-11) */
+ * DX (overwritten) scatter (i*S+ky-P, j*S+kx-P) += F[c1,K-1-ky,K-1-kx,c0]*dO  (flipped, quirk a-11).
+ * DX == NULL computes dF|dB only, DF == DB == NULL computes dX only (lets the host fork them). */
 int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F,
                    float *DF, float *DB,
                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
@@ -216,7 +222,8 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y,
                    int N, int E0, int E1, t4k_stream_t s);
 /* Model::_blinear backprop.cu:193-254: DB += sum dY; DW += dY^T X (if train); DX = dY @ W.
  * DX may alias X's buffer only when the caller guarantees X is no longer needed: the
- * kernels read X for DW before DX is written (stream order). */
+ * kernels read X for DW before DX is written (stream order).
+ * DX == NULL computes dW|dB only, DW == DB == NULL computes dX only. */
 int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX,
                    float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
 /* multi-tensor optimizer step over a parameter table (one launch for all layers).

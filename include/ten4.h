@@ -1,0 +1,32 @@
+/* ten4.h - embedding API of the host VM (libten4.so): run Forth source in-process.
+ *
+ * The reference is a stand-alone REPL (src/ten4.cu:224-235 feeds stdin lines to the VM); this is the
+ * same outer interpreter behind four C functions, so a launcher that owns the process (one rank per
+ * GPU under torch.distributed) can drive the VM and get at the one buffer data-parallel training
+ * exchanges - the gradient slab.  Plain C ABI, no C++ or torch types.
+ */
+#ifndef TEN4_H
+#define TEN4_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ten4_vm ten4_vm;
+
+/* create a VM (t4k_init on device T4_DEVICE / `device` if >= 0, seed `seed`); NULL when no GPU */
+ten4_vm *ten4_new(int device, unsigned long long seed, int trace_level);
+void ten4_free(ten4_vm *vm);
+/* evaluate Forth source (any number of lines); returns 1 while the VM runs, 0 after `bye` */
+int ten4_eval(ten4_vm *vm, const char *source);
+/* text printed since the last call (valid until the next ten4_* call on this VM) */
+const char *ten4_output(ten4_vm *vm);
+/* gradient slab of the model that ran `forward`/`backprop` last: all dW|dB back to back.
+ * Returns 0 and a device pointer + float count, or -1 when no model has been finalized. */
+int ten4_grad_slab(ten4_vm *vm, float **dev_ptr, long *n_floats);
+/* the stream every kernel of the VM is issued on (a hipStream_t) */
+void *ten4_stream(ten4_vm *vm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

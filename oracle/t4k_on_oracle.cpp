@@ -36,6 +36,7 @@ int t4k_memset(void *d, int b, size_t n, t4k_stream_t) { memset(d, b, n); return
 int t4k_sync(t4k_stream_t) { return T4K_OK; }
 int t4k_stream_create(t4k_stream_t *s) { *s = nullptr; return T4K_OK; }
 int t4k_stream_destroy(t4k_stream_t) { return T4K_OK; }
+int t4k_stream_wait_event(t4k_stream_t, t4k_event_t) { return T4K_OK; }
 int t4k_set_default_stream(t4k_stream_t) { return T4K_OK; }
 t4k_stream_t t4k_default_stream(void) { return nullptr; }
 int t4k_event_create(t4k_event_t *e) { *e = nullptr; return T4K_OK; }
@@ -94,7 +95,13 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B, int
 }
 int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB, int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, int tr, t4k_stream_t) {
-    int r = t4o_conv2d_bwd(I, DO, DX, F, DF, DB, N, H1, W1, C1, H0, W0, C0, K, S, P, tr);
+    // product contract: DX == NULL -> dF|dB only, DF == NULL -> dX only (the oracle always computes both; use scratch for the skipped half)
+    float *dx = DX, *df = DF, *db = DB;
+    if (!dx) dx = (float *)calloc((size_t)N * H1 * W1 * C1, sizeof(float));
+    if (!df) { df = (float *)calloc((size_t)C1 * K * K * C0, sizeof(float)); db = (float *)calloc((size_t)C0, sizeof(float)); }
+    int r = t4o_conv2d_bwd(I, DO, dx, F, df, db, N, H1, W1, C1, H0, W0, C0, K, S, P, tr);
+    if (!DX) free(dx);
+    if (!DF) { free(df); free(db); }
     if (r) snprintf(g_err, sizeof(g_err), "nn#bconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
     return r;
 }
@@ -111,7 +118,11 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int
     return t4o_linear_fwd(X, W, B, Y, N, E0, E1);
 }
 int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t) {
-    return t4o_linear_bwd(X, W, DY, DX, DW, DB, N, E0, E1, tr);
+    float *dx = DX;                                     // product contract: DX == NULL -> dW|dB only, DW == NULL -> dX only
+    if (!dx) dx = (float *)calloc((size_t)N * E1, sizeof(float));
+    int r = t4o_linear_bwd(X, W, DY, dx, DW, DB, N, E0, E1, DW ? tr : 0);
+    if (!DX) free(dx);
+    return r;
 }
 int t4k_opt_multi(int kind, const t4k_param_rec *tab, int nt, long, float lr, float b1, float b2, float wd, t4k_stream_t) {
     for (int i = 0; i < nt; i++) {

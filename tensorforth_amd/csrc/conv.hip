@@ -279,7 +279,7 @@ int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs) {
     long want = (rows + 1023) / 1024; if (want > 64) want = 64; if (want < 1) want = 1;
     const int rpc = (int)((rows + want - 1) / want);
     const int nchunk = (int)((rows + rpc - 1) / rpc);
-    float *part = (float *)st().ws + (8 << 20);            // second 32 MiB half of the workspace
+    float *part = ws_for(hs) + (8 << 20);            // second 32 MiB half of the workspace
     if ((size_t)nchunk * E * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "colsum workspace");
     if (nchunk == 1) {
         hipLaunchKernelGGL(k_colsum_part, dim3(1, (E + 63) / 64), dim3(BLK), 0, hs, X, part, rows, E, rpc, OUT);
@@ -313,17 +313,17 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, f
     T4K_REQUIRE_INIT();
     if (!conv_supported(K, S, P))
         return fail(T4K_ERR_UNSUPPORTED, "nn#bconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
-    if (!I || !DO || !DX || !F || N <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: bad argument");
+    if (!I || !DO || !F || N <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: bad argument");
+    if ((DF == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: DF and DB go together");
     hipStream_t hs = t4k::S(s);
-    if (train) {
-        if (!DF || !DB) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: train needs DF/DB");
+    if (train && DF) {                                  // DF == NULL: dX only (the caller runs dF|dB on another stream)
         // dF | dB first: they read I, which the host layer may let DX overwrite
         const int ntaps = C1 * K * K, nrow1 = ntaps + 1;
         const int rows = N * H0;
         int nslice = (rows + 3) / 4; if (nslice > 128) nslice = 128; if (nslice < 1) nslice = 1;
         const int rpw = (rows + nslice * 4 - 1) / (nslice * 4);
         nslice = (rows + rpw * 4 - 1) / (rpw * 4);
-        float *part = (float *)st().ws;
+        float *part = ws_for(s);
         if ((size_t)nslice * nrow1 * C0 * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "conv dF workspace");
         dim3 g(nslice, (nrow1 + 31) / 32, (C0 + 31) / 32);
         switch ((K << 8) | (S << 4) | P) {
@@ -335,7 +335,7 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, f
         const int ntot = nrow1 * C0;
         hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 63) / 64), dim3(256), 0, hs, part, DF, DB, nslice, ntaps * C0, ntot);
     }
-    {
+    if (DX) {                                           // DX == NULL: dF|dB only
         const long npix1 = (long)N * H1 * W1;
         dim3 g((unsigned)((npix1 + 127) / 128), (unsigned)((C1 + 31) / 32));
         // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1)

@@ -547,7 +547,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     if (!A || !B || !O || M < 0 || N < 0 || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_gemm: bad argument");
     if (M == 0 || N == 0) return T4K_OK;
     GemmP p;
-    p.A = A; p.B = B; p.O = O; p.bias = bias; p.part = (float *)st().ws;
+    p.A = A; p.B = B; p.O = O; p.bias = bias; p.part = ws_for(s);
     p.M = M; p.N = N; p.K = K; p.C = C; p.alpha = alpha; p.beta = beta;
 
     // 16-byte loads need: C == 1, aligned bases, contiguous extents divisible by 4
@@ -626,12 +626,13 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int
 int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
                    int N, int E0, int E1, int train, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
-    if (train) {
-        if (!DW || !DB) return fail(T4K_ERR_ARG, "t4k_linear_bwd: train needs DW/DB");
+    if ((DW == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_linear_bwd: DW and DB go together");
+    if (train && DW) {                                  // DW == NULL: dX only (the caller forks dW|dB to another stream)
         int rc = colsum_add(DY, DB, N, E0, S(s)); if (rc) return rc;              // dB += sum_n dY
         rc = gemm_launch(DY, X, DW, nullptr, 1.0f, 1.0f, 1, 0, E0, E1, N, 1, s);  // dW += dY^T @ X
         if (rc) return rc;
     }
+    if (!DX) return T4K_OK;                             // DX == NULL: dW|dB only
     return gemm_launch(DY, W, DX, nullptr, 1.0f, 0.0f, 0, 0, N, E1, E0, 1, s);   // dX = dY @ W (may overwrite X)
 }
 

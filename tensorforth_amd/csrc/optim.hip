@@ -70,8 +70,11 @@ __global__ void __launch_bounds__(BLK) k_opt_multi(int kind, const t4k_param_rec
     }
 }
 
-// d[i] = scale * (bias + u_i): element i <- Philox(counter = (off+i)/4)[i%4]
-__global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float bias, float scale, uint64_t seed, uint64_t base) {
+// d[i] = scale * (bias + u_i): element i <- Philox(counter = (off+i)/4)[i%4].
+// The stream state (counter, seed) is read from device memory and advanced by the last workgroup to
+// finish, so the same launch captured in a hipGraph draws a fresh slice of the stream on every replay.
+__global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float bias, float scale, uint64_t *state) {
+    const uint64_t base = ((volatile uint64_t *)state)[0], seed = ((volatile uint64_t *)state)[2];
     const long nq = (n + 3) >> 2;
     for (long q = (long)blockIdx.x * BLK + threadIdx.x; q < nq; q += (long)gridDim.x * BLK) {
         uint32_t r[4]; float v[4];
@@ -89,6 +92,16 @@ __global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float b
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) { const long i = q * 4 + k; if (i < n) d[i] = scale * (bias + v[k]); }
+    }
+    __syncthreads();                                    // every thread of this block has read `base`
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd((unsigned *)&state[1], 1u);
+        if (t == gridDim.x - 1) {                       // last block out: all blocks have read `base`
+            ((volatile uint64_t *)state)[1] = 0;
+            ((volatile uint64_t *)state)[0] = base + (uint64_t)nq;
+            __threadfence();
+        }
     }
 }
 
@@ -124,15 +137,30 @@ int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long ma
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
-int t4k_rand_init(uint64_t seed) { st().seed = seed; st().rng_off = 0; return T4K_OK; }
-uint64_t t4k_rand_offset(void) { return st().rng_off; }
-int t4k_rand_set_offset(uint64_t off) { st().rng_off = off & ~3ull; return T4K_OK; }
+static int rng_state_write(uint64_t ctr, const uint64_t *seed) {
+    State &g = st();
+    if (!g.d_rng) { T4K_HIP(hipMalloc((void **)&g.d_rng, 4 * sizeof(uint64_t))); T4K_HIP(hipMemset(g.d_rng, 0, 4 * sizeof(uint64_t))); }
+    T4K_HIP(hipDeviceSynchronize());
+    const uint64_t z[2] = { ctr, 0 };
+    T4K_HIP(hipMemcpy(g.d_rng, z, sizeof(z), hipMemcpyHostToDevice));
+    if (seed) T4K_HIP(hipMemcpy(g.d_rng + 2, seed, sizeof(uint64_t), hipMemcpyHostToDevice));
+    return T4K_OK;
+}
+int t4k_rand_init(uint64_t seed) { T4K_REQUIRE_INIT(); return rng_state_write(0, &seed); }
+uint64_t t4k_rand_offset(void) {                        // synchronous read-back of the device-resident counter
+    State &g = st();
+    if (!g.ready || !g.d_rng) return 0;
+    (void)hipDeviceSynchronize();
+    uint64_t c = 0; (void)hipMemcpy(&c, g.d_rng, sizeof(c), hipMemcpyDeviceToHost);
+    return c * 4;
+}
+int t4k_rand_set_offset(uint64_t off) { T4K_REQUIRE_INIT(); (void)hipDeviceSynchronize(); return rng_state_write(off / 4, nullptr); }
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!d) return fail(T4K_ERR_ARG, "t4k_rand: null");
     State &g = st();
-    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), d, n, opt, bias, scale, g.seed, g.rng_off / 4);
-    g.rng_off += (uint64_t)((n + 3) / 4) * 4;
+    if (!g.d_rng) { uint64_t z = 0; int rc = rng_state_write(0, &z); if (rc) return rc; }
+    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), d, n, opt, bias, scale, g.d_rng);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

@@ -79,7 +79,7 @@ int launch_reduce(const float *X, const float *Y, long n, float avg, float *out,
     if (g <= 1) {
         hipLaunchKernelGGL(k_reduce1<OP>, dim3(1), dim3(BLK), 0, s, X, Y, n, avg, out, vec);
     } else {
-        float *part = (float *)st().ws;
+        float *part = ws_for(s);
         hipLaunchKernelGGL(k_reduce1<OP>, dim3((int)g), dim3(BLK), 0, s, X, Y, n, avg, part, vec);
         hipLaunchKernelGGL(k_reduce2<(OP == R_MAX || OP == R_MIN) ? OP : R_SUM>, dim3(1), dim3(BLK), 0, s, part, (int)g, out);
     }

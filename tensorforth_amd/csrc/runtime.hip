@@ -115,10 +115,23 @@ int t4k_sync(t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipStreamSynchronize(
 
 int t4k_stream_create(t4k_stream_t *s) {
     T4K_REQUIRE_INIT();
+    State &g = st();
+    if (g.n_lane >= 8) return fail(T4K_ERR_NOMEM, "t4k_stream_create: at most 8 library streams");
     hipStream_t h; T4K_HIP(hipStreamCreateWithFlags(&h, hipStreamNonBlocking)); *s = (t4k_stream_t)h;
+    void *ws = nullptr;                                 // every library stream owns a workspace (concurrent split-K / partial slabs)
+    T4K_HIP(hipMalloc(&ws, g.ws_bytes)); T4K_HIP(hipMemsetAsync(ws, 0, g.ws_bytes, h));
+    g.lane[g.n_lane].s = h; g.lane[g.n_lane].ws = ws; g.n_lane++;
     return T4K_OK;
 }
-int t4k_stream_destroy(t4k_stream_t s) { T4K_REQUIRE_INIT(); if (s) T4K_HIP(hipStreamDestroy((hipStream_t)s)); return T4K_OK; }
+int t4k_stream_destroy(t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (!s) return T4K_OK;
+    State &g = st();
+    T4K_HIP(hipStreamSynchronize((hipStream_t)s));
+    for (int i = 0; i < g.n_lane; i++) if (g.lane[i].s == (hipStream_t)s) { (void)hipFree(g.lane[i].ws); g.lane[i] = g.lane[--g.n_lane]; break; }
+    T4K_HIP(hipStreamDestroy((hipStream_t)s));
+    return T4K_OK;
+}
+int t4k_stream_wait_event(t4k_stream_t s, t4k_event_t e) { T4K_REQUIRE_INIT(); T4K_HIP(hipStreamWaitEvent(S(s), (hipEvent_t)e, 0)); return T4K_OK; }
 int t4k_set_default_stream(t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     State &g = st();

@@ -19,8 +19,10 @@ struct State {
     bool        own_stream = false;
     void       *ws      = nullptr;     // device workspace (replaces per-tensor _tmp)
     size_t      ws_bytes = 0;
-    uint64_t    seed    = 0;           // Philox key
-    uint64_t    rng_off = 0;           // Philox element offset (multiple of 4)
+    uint64_t   *d_rng   = nullptr;     // device: [0] Philox counter (element offset / 4), [1] ticket, [2] seed.  The
+                                       //   RNG state lives in HBM so a captured graph draws fresh numbers on every replay.
+    struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
+    int         n_lane  = 0;
     int         cu_count = 256;
     char        err[256] = {0};
 };
@@ -29,6 +31,12 @@ State &st();
 int  fail(int code, const char *fmt, ...);
 int  hip_fail(hipError_t e, const char *what);
 inline hipStream_t S(t4k_stream_t s) { return s ? (hipStream_t)s : st().stream; }
+// workspace of the stream a kernel is launched on: work forked to a side stream must not share partial slabs
+inline float *ws_for(const void *s) {            // accepts a t4k_stream_t or an already resolved hipStream_t
+    State &g = st();
+    if (s) for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) return (float *)g.lane[i].ws;
+    return (float *)g.ws;
+}
 
 #define T4K_REQUIRE_INIT() do { if (!t4k::st().ready) return t4k::fail(T4K_ERR_NODEVICE, "t4k_init not called or no gfx950 device"); } while (0)
 #define T4K_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) return t4k::hip_fail(_e, #call); } while (0)

@@ -86,9 +86,96 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
     default: printf("Model#add layer %d not supported\n", fn); return *this;
     }
     in.grad_fn = fn;
+    invalidate();
     Tensor &out = at(-1);
     NLOG("  } Model::add[%ld] %s => out[%d,%d,%d,%d]\n", (long)layer.size(), LAYER_NAME[fn], out.N(), out.H(), out.W(), out.C());
     return *this;
+}
+
+// ---------------------------------------------------------------- execution engine
+// Both are OFF by default: measured on MI355X (ROCm 7.2, LeNet step, 40 launches) the single in-order stream is the
+// fastest schedule - 0.26 ms/step vs 0.28 (hipGraph replay) vs 0.31 (forked side stream; every cross-queue event edge
+// costs more than the ~4.5 us in-order dispatch it hides).  What pays is fewer launches (fused kernels below).
+Model *Model::current = nullptr;
+bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
+bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
+
+void Model::invalidate() {
+    for (GraphSlot *g : { &g_fwd_, &g_bwd_, &g_opt_ }) { if (g->g) t4k_graph_destroy(g->g); *g = GraphSlot(); }
+    finalized_ = false;
+}
+void Model::finalize() {                                // gradient slab: SURVEY 8(e), one contiguous all-reduce buffer
+    if (finalized_) return;
+    finalized_ = true;
+    auto pad = [](uint64_t n) { return (n + 63) & ~(uint64_t)63; };          // keep every tensor 256 B aligned
+    uint64_t total = 0;
+    capturable_ = true;
+    for (Tensor *t : gx_) if (t) Store::get().free(*t);
+    gx_.assign(layer.size(), nullptr);
+    for (int i = 0; i + 1 < (int)layer.size(); i++) {
+        Tensor &in = at(i);
+        if (in.grad_fn == T4K_L_LOGSMAX) capturable_ = false;               // host round trip inside the layer
+        if (in.grad_fn == T4K_L_BATCHNM) continue;                          // per-channel vectors stay where they are
+        for (int k = 2; k < 4; k++) if (in.grad[k]) total += pad(in.grad[k]->numel);
+        if (use_side && in.grad_fn == T4K_L_LINEAR && i + 2 < (int)layer.size()) gx_[i] = &T4(in.N(), in.H(), in.W(), in.C());
+    }
+    if (total) {
+        Tensor *slab = &VEC(total).zeros();
+        uint64_t off = 0;
+        for (int i = 0; i + 1 < (int)layer.size(); i++) {
+            Tensor &in = at(i);
+            if (in.grad_fn == T4K_L_BATCHNM) continue;
+            for (int k = 2; k < 4; k++) {
+                Tensor *g = in.grad[k]; if (!g) continue;
+                chk(t4k_copy(g->data, slab->data + off, (long)g->numel, stream()), "slab");
+                if (g->owns && g->data) { t4k_sync(stream()); Arena::get().free(g->data); }
+                g->data = slab->data + off; g->owns = false;
+                off += pad(g->numel);
+            }
+        }
+        if (gslab) Store::get().free(*gslab);
+        gslab = slab;
+    }
+    if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }                  // parameter table holds the old pointers
+    if (use_side && !side_) chk(t4k_stream_create(&side_), "side stream");
+    t4k_sync(stream());
+}
+t4k_stream_t Model::fork() {
+    if (!concurrent()) return stream();
+    if (ev_.size() < 16) { ev_.resize(16, nullptr); for (auto &e : ev_) t4k_event_create(&e); }
+    t4k_event_t e = ev_[ev_i_++ % ev_.size()];
+    t4k_event_record(e, stream()); t4k_stream_wait_event(side_, e);
+    side_dirty_ = true;
+    return side_;
+}
+void Model::join() {
+    if (!side_dirty_ || !side_) { side_dirty_ = false; return; }
+    t4k_event_t e = ev_[ev_i_++ % ev_.size()];
+    t4k_event_record(e, side_); t4k_stream_wait_event(stream(), e);
+    side_dirty_ = false;
+}
+void Model::lazy_copy(const float *src, Tensor &dst) {   // bookkeeping copy, off the critical path
+    if (src == dst.data) return;
+    chk(t4k_copy(src, dst.data, (long)dst.numel, fork()), "copy");
+}
+bool Model::replay(GraphSlot &slot, const void *key, int flags, const float *p) {
+    capturing_ = false;
+    if (!use_graphs || !capturable_ || (trace && *trace)) return false;
+    const bool same = slot.key == key && slot.flags == flags && (!p || memcmp(slot.p, p, sizeof(slot.p)) == 0);
+    if (same && slot.g) { chk(t4k_graph_launch(slot.g, stream()), "graph launch"); return true; }
+    if (!same) {                                        // new operands: run eagerly once, capture next time
+        if (slot.g) { t4k_graph_destroy(slot.g); slot.g = nullptr; }
+        slot.key = key; slot.flags = flags; slot.seen = 0;
+        if (p) memcpy(slot.p, p, sizeof(slot.p));
+    }
+    if (slot.seen++ >= 1) capturing_ = t4k_graph_begin(stream()) == T4K_OK;
+    return false;
+}
+void Model::end_capture(GraphSlot &slot, bool capturing) {
+    if (!capturing) return;
+    capturing_ = false;
+    if (chk(t4k_graph_end(stream(), &slot.g), "graph capture") != T4K_OK) { slot.g = nullptr; use_graphs = false; return; }
+    chk(t4k_graph_launch(slot.g, stream()), "graph launch");
 }
 
 // ---------------------------------------------------------------- forward
@@ -99,37 +186,57 @@ Model &Model::forward(Tensor &input) {
                input.N(), input.H(), input.W(), input.C(), n0.N(), n0.H(), n0.W(), n0.C());
         return *this;
     }
-    n0 = input;                                         // layer 0 holds a COPY of the batch (forward.cu:39)
+    finalize(); current = this;
     NLOG("\nModel::forward starts trace=%d {", *trace);
-    for (int i = 0; i + 1 < (int)layer.size(); i++) {
-        Tensor &in = at(i), &out = at(i + 1);
-        if (trace && *trace)
-            printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
-                   in.N(), in.H(), in.W(), in.C(), in.sum() / in.N() / in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
-        fstep(in, out);
-        if (trace && *trace && out.has_nan()) { printf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+    if (!replay(g_fwd_, input.data, (int)train, nullptr)) {
+        const bool cap = capturing_;
+        run_forward(input);
+        end_capture(g_fwd_, cap);
     }
     if (input.type == T_DATASET) { onehot((Dataset &)input); hit_ = hit(true); }
     NLOG("\n} Model::forward\n");
     return *this;
 }
-void Model::fstep(Tensor &in, Tensor &out) {            // _fstep forward.cu:82-113
+void Model::run_forward(Tensor &input) {
+    const int L = (int)layer.size();
+    Tensor &n0 = at(0);
+    lazy_copy(input.data, n0);                          // layer 0 holds a COPY of the batch (forward.cu:39); conv1 reads the batch itself
+    bool masks = false;
+    for (int i = 0; i + 1 < L; i++)                     // dropout masks: drawn up front, in layer order (fixed Philox order)
+        if (at(i).grad_fn == T4K_L_DROPOUT) {
+            Tensor &m = *at(i).grad[4];
+            chk(t4k_rand(m.data, (long)m.numel, T4K_UNIFORM, 0.0f, 1.0f, fork()), "rand"); masks = true;
+        }
+    const float *x = input.data;
+    for (int i = 0; i + 1 < L; i++) {
+        Tensor &in = at(i), &out = at(i + 1);
+        if (trace && *trace)
+            printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
+                   in.N(), in.H(), in.W(), in.C(), in.sum() / in.N() / in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
+        if (masks && in.grad_fn == T4K_L_DROPOUT) { join(); masks = false; }
+        x = fstep(in, out, x);
+        if (trace && *trace && out.has_nan()) { printf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+    }
+    join();
+}
+// one layer forward: reads the activations at `x` (normally in.data), writes out.data, returns where the
+// next layer finds its input (_fstep forward.cu:82-113)
+const float *Model::fstep(Tensor &in, Tensor &out, const float *x) {
     const int fn = in.grad_fn;
     t4k_stream_t s = stream();
     switch (fn) {
     case T4K_L_CONV:
-        chk(t4k_conv2d_fwd(in.data, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
+        chk(t4k_conv2d_fwd(x, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
                            out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], s), "nn#fconv"); break;
     case T4K_L_LINEAR:
-        chk(t4k_linear_fwd(in.data, in.grad[0]->data, in.grad[1]->data, out.data, out.N(), (int)out.HWC(), (int)in.HWC(), s), "nn#flinear"); break;
-    case T4K_L_FLATTEN: out = in; break;
-    case T4K_L_DROPOUT:
-        chk(t4k_rand(in.grad[4]->data, (long)in.grad[4]->numel, T4K_UNIFORM, 0.0f, 1.0f, s), "rand");   /* fall through */
+        chk(t4k_linear_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.N(), (int)out.HWC(), (int)in.HWC(), s), "nn#flinear"); break;
+    case T4K_L_FLATTEN: lazy_copy(x, out); return x;    // a copy in the reference (forward.cu:96); the next layer reads the source
+    case T4K_L_DROPOUT:                                 // mask already drawn by run_forward
     case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SIGMOID: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU:
-        chk(t4k_activate(fn, in.data, out.data, in.grad[4]->data, in.xparm, (long)in.numel, s), "nn#factivate"); break;
-    case T4K_L_SOFTMAX: chk(t4k_softmax(in.data, out.data, in.N(), (int)in.HWC(), s), "nn#fsoftmax"); break;
+        chk(t4k_activate(fn, x, out.data, in.grad[4]->data, in.xparm, (long)in.numel, s), "nn#factivate"); break;
+    case T4K_L_SOFTMAX: chk(t4k_softmax(x, out.data, in.N(), (int)in.HWC(), s), "nn#fsoftmax"); break;
     case T4K_L_LOGSMAX: {                               // _flogsoftmax forward.cu:245-259 (log10 and exp(x) kept: reference bug a-16)
-        out = in; out.map(T4K_EXP);
+        chk(t4k_copy(x, out.data, (long)out.numel, s), "copy"); out.map(T4K_EXP);
         std::vector<float> h; out.to_host(h);
         for (uint32_t n = 0; n < out.N(); n++) {
             DU sum = 0; for (uint64_t i = 0; i < out.HWC(); i++) sum += h[n * out.HWC() + i];
@@ -138,14 +245,15 @@ void Model::fstep(Tensor &in, Tensor &out) {            // _fstep forward.cu:82-
         }
     } break;
     case T4K_L_AVGPOOL: case T4K_L_MAXPOOL: case T4K_L_MINPOOL:
-        chk(t4k_pool(fn, in.data, out.data, out.N(), in.H(), in.W(), out.H(), out.W(), out.C(), in.stride[0], s), "nn#fpool"); break;
+        chk(t4k_pool(fn, x, out.data, out.N(), in.H(), in.W(), out.H(), out.W(), out.C(), in.stride[0], s), "nn#fpool"); break;
     case T4K_L_BATCHNM:
-        chk(t4k_batchnorm_fwd(in.data, out.data, in.grad[4]->data, in.grad[0]->data, in.grad[1]->data, in.mtum[4]->data,
+        chk(t4k_batchnorm_fwd(x, out.data, in.grad[4]->data, in.grad[0]->data, in.grad[1]->data, in.mtum[4]->data,
                               out.N(), out.H() * out.W(), out.C(), s), "nn#fbatchnorm"); break;
     case T4K_L_USAMPLE:                                 // nearest: broadcast each cell to a kxk tile
-        chk(t4k_dpool(T4K_L_USAMPLE, out.data, in.data, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#fupsample"); break;
+        chk(t4k_dpool(T4K_L_USAMPLE, out.data, x, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#fupsample"); break;
     default: printf("nn#fstep layer=%d not supported\n", fn);
     }
+    return out.data;
 }
 
 // ---------------------------------------------------------------- one-hot / hit / loss
@@ -212,50 +320,80 @@ Model &Model::backprop(Tensor &tgt) {
                out.N(), out.H(), out.W(), out.C(), (long)tgt.numel, (long)out.numel);
         return *this;
     }
-    switch (at(-2).grad_fn) {
-    case T4K_L_LINEAR: case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX: Tensor::ten_op(T4K_SUB, out, tgt, out); break;
-    default: out = tgt; break;
-    }
+    finalize();
     NLOG("\nModel::backprop starts trace=%d train=%d {", *trace, (int)train);
+    if (!replay(g_bwd_, tgt.data, (int)train, nullptr)) {
+        const bool cap = capturing_;
+        run_backward(tgt);
+        end_capture(g_bwd_, cap);
+    }
+    NLOG("\n} Model::backprop\n");
+    return *this;
+}
+void Model::run_backward(Tensor &tgt) {
+    Tensor &out = at(-1);
+    t4k_stream_t s = stream();
+    switch (at(-2).grad_fn) {
+    case T4K_L_LINEAR: case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
+        chk(t4k_tt_op(T4K_SUB, out.data, tgt.data, out.data, (long)out.numel, s), "bprep"); break;
+    default: chk(t4k_copy(tgt.data, out.data, (long)out.numel, s), "bprep"); break;
+    }
+    const float *dy = out.data;                         // where the gradient w.r.t. the current layer's output lives
     for (int i = (int)layer.size() - 2, j = 0; i >= 0; i--, j++) {
         Tensor &in = at(i), &o = at(i + 1);
         if (trace && *trace)
             printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.xparm, o.sum() / o.N() / o.C(), o.N(), o.H(), o.W(), o.C());
-        bstep(in, o, j == 0);
+        dy = bstep(i, in, o, dy, j == 0);
         if (trace && *trace && in.has_nan()) { printf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
     }
-    NLOG("\n} Model::backprop\n");
-    return *this;
+    join();
 }
-void Model::bstep(Tensor &in, Tensor &out, bool last) {  // _bstep backprop.cu:111-140
+// one layer backward (_bstep backprop.cu:111-140): reads dY at `dy`, leaves dX in in.data (the reference's
+// in-place convention) and returns where the previous layer finds it.  Parameter gradients and the
+// `in = dX` copies run on the side stream.
+const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool last) {
     const int fn = in.grad_fn;
     t4k_stream_t s = stream();
     switch (fn) {
     case T4K_L_CONV: {
         Tensor &dx = *in.grad[4];
-        chk(t4k_conv2d_bwd(in.data, out.data, dx.data, in.grad[0]->data, in.grad[2]->data, in.grad[3]->data,
-                           in.N(), in.H(), in.W(), in.C(), out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], train, s), "nn#bconv");
-        in = dx;                                        // x = dX (overwrite), backprop.cu:185
-    } break;
-    case T4K_L_LINEAR:
-        if (last) in = out;                             // linear as the last layer: pass dY (backprop.cu:119-121)
-        else chk(t4k_linear_bwd(in.data, in.grad[0]->data, out.data, in.data, in.grad[2]->data, in.grad[3]->data,
-                                in.N(), (int)out.HWC(), (int)in.HWC(), train, s), "nn#blinear");
-        break;
-    case T4K_L_FLATTEN: case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX: in = out; break;   // pass-through (:122,129-131)
+        const int N = in.N(), H1 = in.H(), W1 = in.W(), C1 = in.C(), H0 = out.H(), W0 = out.W(), C0 = out.C();
+        const int K = in.grad[0]->H(), S = in.stride[0], P = in.stride[2];
+        if (train) chk(t4k_conv2d_bwd(in.data, dy, nullptr, in.grad[0]->data, in.grad[2]->data, in.grad[3]->data,
+                                      N, H1, W1, C1, H0, W0, C0, K, S, P, 1, fork()), "nn#bconv dF");
+        chk(t4k_conv2d_bwd(in.data, dy, dx.data, in.grad[0]->data, nullptr, nullptr, N, H1, W1, C1, H0, W0, C0, K, S, P, 0, s), "nn#bconv dX");
+        lazy_copy(dx.data, in);                         // x = dX (overwrite), backprop.cu:185 - after dF has consumed x
+        return dx.data;
+    }
+    case T4K_L_LINEAR: {
+        if (last) { lazy_copy(dy, in); return dy; }     // linear as the last layer: pass dY (backprop.cu:119-121)
+        const int N = in.N(), E0 = (int)out.HWC(), E1 = (int)in.HWC();
+        Tensor *gx = concurrent() ? gx_[i] : nullptr;
+        if (!gx) {                                      // single stream: reference order (dW reads X, then dX overwrites it)
+            chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, in.data, in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#blinear");
+            return in.data;
+        }
+        if (train) chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, nullptr, in.grad[2]->data, in.grad[3]->data, N, E0, E1, 1, fork()), "nn#blinear dW");
+        chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, gx->data, nullptr, nullptr, N, E0, E1, 0, s), "nn#blinear dX");
+        lazy_copy(gx->data, in);                        // dX lands in X's buffer (backprop.cu:240) once dW has read X
+        return gx->data;
+    }
+    case T4K_L_FLATTEN: case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
+        lazy_copy(dy, in); return dy;                   // pass-through (:122,129-131)
     case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU: case T4K_L_DROPOUT:
-        Tensor::ten_op(T4K_MUL, out, *in.grad[4], in); break;
+        chk(t4k_tt_op(T4K_MUL, dy, in.grad[4]->data, in.data, (long)in.numel, s), "nn#bactivate"); break;
     case T4K_L_AVGPOOL: case T4K_L_MAXPOOL: case T4K_L_MINPOOL:
-        chk(t4k_dpool(fn, in.data, out.data, out.N(), in.H(), in.W(), out.H(), out.W(), out.C(), in.stride[0], s), "nn#bpool"); break;
+        chk(t4k_dpool(fn, in.data, dy, out.N(), in.H(), in.W(), out.H(), out.W(), out.C(), in.stride[0], s), "nn#bpool"); break;
     case T4K_L_BATCHNM:
-        chk(t4k_batchnorm_bwd(in.grad[0]->data, out.data, in.grad[4]->data, in.data, in.grad[2]->data, in.grad[3]->data,
+        chk(t4k_batchnorm_bwd(in.grad[0]->data, dy, in.grad[4]->data, in.data, in.grad[2]->data, in.grad[3]->data,
                               in.mtum[4]->data, in.N(), in.H() * in.W(), in.C(), train, s), "nn#bbatchnorm"); break;
     case T4K_L_USAMPLE:                                 // gradient of nearest upsampling = sum over the tile = k*k * avgpool
-        chk(t4k_pool(T4K_L_AVGPOOL, out.data, in.data, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#bupsample");
+        chk(t4k_pool(T4K_L_AVGPOOL, dy, in.data, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#bupsample");
         in.map(T4K_SCALE, (DU)(in.stride[0] * in.stride[0])); break;
     default: printf("nn#bstep layer=%d not supported\n", fn);
     }
+    return in.data;
 }
 
 // ---------------------------------------------------------------- optimizers
@@ -282,6 +420,7 @@ void Model::build_table(Optim op) {                      // one multi-tensor lau
 }
 Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {   // gradient.cu:63-126
     NLOG("\nModel::%s starts (%s) batch_sz=%d, lr=%7.4f, mtum/b1=%6.3f, b2=%6.3f {\n", nm, train ? "trainning" : "testing", at(1).N(), lr, b1, b2);
+    finalize();
     const bool first = (iter++ == 0 && epoch == 0);
     if (first || tab_kind != op) {                      // grad_alloc gradient.cu:19-59 (+ re-allocation when the optimizer is switched mid-run,
         for (int i = 0; i + 1 < (int)layer.size(); i++) {   //   where the reference would read the SGD alias / a null V)
@@ -299,7 +438,12 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     if (!train) return *this;
     if (!tab_dev || tab_kind != op) build_table(op);
     const int kind = (op == OPTI_ADAM) ? 1 : (op == OPTI_ADAMW ? 2 : 0);
-    chk(t4k_opt_multi(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_max, lr, b1, b2, wd, stream()), nm);
+    const float p[4] = { lr, b1, b2, wd };
+    if (!replay(g_opt_, tab_dev, (int)op, p)) {
+        const bool cap = capturing_;
+        chk(t4k_opt_multi(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_max, lr, b1, b2, wd, stream()), nm);
+        end_capture(g_opt_, cap);
+    }
     NLOG("} Model::%s\n", nm);
     return *this;
 }
@@ -308,6 +452,15 @@ Model &Model::adam(DU lr, DU b1, DU b2) { return gradient("adam", OPTI_ADAM, lr,
 Model &Model::adamw(DU lr, DU wd, DU b1, DU b2) { return gradient("adamw", OPTI_ADAMW, lr, b1, b2, wd); }
 
 void Model::free_all() {
+    invalidate();
+    if (current == this) current = nullptr;
+    t4k_sync(stream());
+    if (side_) { t4k_stream_destroy(side_); side_ = nullptr; }
+    for (auto e : ev_) if (e) t4k_event_destroy(e);
+    ev_.clear();
+    for (Tensor *t : gx_) if (t) Store::get().free(*t);
+    gx_.clear();
+    if (gslab) { Store::get().free(*gslab); gslab = nullptr; }
     for (int i = (int)layer.size() - 1; i >= 0; i--) Store::get().free(*layer[i]);
     layer.clear();
     if (hot) { Store::get().free(*hot); hot = nullptr; }

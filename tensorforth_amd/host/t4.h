@@ -201,16 +201,42 @@ struct Model : Obj {
     Model &adam(DU lr, DU b1 = 0.9f, DU b2 = 0.999f);
     Model &adamw(DU lr, DU wd = 0.001f, DU b1 = 0.9f, DU b2 = 0.999f);
     void  free_all();
+    // ---- data-parallel hook: all dW|dB of the model live back-to-back in one slab (one all-reduce)
+    Tensor *gslab = nullptr;
+    static Model *current;                     // model that ran forward/backprop last (embedding API)
+    void  finalize();                          // build the gradient slab + side stream (first forward / backprop)
+    void  invalidate();                        // drop captured graphs (layers added, shapes changed)
+    static bool use_graphs, use_side;          // T4_GRAPH=0 / T4_SIDE=0 switch them off (debugging)
 private:
     Tensor &T4(uint32_t n, uint32_t h, uint32_t w, uint32_t c);
     Tensor &VEC(uint64_t n);
     void RAND(Tensor &t, DU scale);
-    void fstep(Tensor &in, Tensor &out);
-    void bstep(Tensor &in, Tensor &out, bool last);
+    const float *fstep(Tensor &in, Tensor &out, const float *x);
+    const float *bstep(int i, Tensor &in, Tensor &out, const float *dy, bool last);
+    void run_forward(Tensor &input);
+    void run_backward(Tensor &tgt);
     Model &gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd);
     // one-launch optimizer over a device parameter table
     void *tab_dev = nullptr; int tab_n = 0; long tab_max = 0; Optim tab_kind = OPTI_SGD;
     void build_table(Optim op);
+    // ---- execution engine: the critical path (activations fwd, dX chain bwd) runs on the main stream;
+    // copies the reference makes for bookkeeping (n0 = input, flatten, in = dX), dropout-mask generation
+    // and all parameter gradients (dW, dB, dF) are forked to a side stream and joined at the end.  Each
+    // word (forward / backprop / optimizer) is captured into a hipGraph on its second call with the
+    // same operands and replayed afterwards.
+    struct GraphSlot { t4k_graph_t g = nullptr; const void *key = nullptr; float p[4] = {0, 0, 0, 0}; int flags = -1, seen = 0; };
+    GraphSlot g_fwd_, g_bwd_, g_opt_;
+    t4k_stream_t side_ = nullptr;
+    std::vector<t4k_event_t> ev_; size_t ev_i_ = 0;
+    std::vector<Tensor *> gx_;                 // per-layer dX scratch of linear layers
+    bool finalized_ = false, side_dirty_ = false, capturable_ = true;
+    bool concurrent() const { return side_ != nullptr && !(trace && *trace); }
+    t4k_stream_t fork();                       // side stream, ordered after everything issued on main so far
+    void join();                               // main waits for the side stream
+    void lazy_copy(const float *src, Tensor &dst);
+    bool replay(GraphSlot &slot, const void *key, int flags, const float *p);
+    void end_capture(GraphSlot &slot, bool capturing);
+    bool capturing_ = false;
 };
 
 // ---------------------------------------------------------------- printing

@@ -1,0 +1,69 @@
+"""In-process binding of the host VM (libten4.so, include/ten4.h).
+
+`VM.eval(src)` feeds Forth source to the same outer interpreter the stand-alone `ten4` REPL runs and
+returns what it printed.  For data-parallel training `grad_slab()` exposes the model's contiguous
+dW|dB buffer as a zero-copy torch view (CUDA array interface) so torch.distributed can all-reduce it
+over RCCL, and `stream()` wraps the VM's HIP stream so the collective is ordered with the kernels.
+torch is used for exactly that plumbing; all compute goes through libt4hip.so.
+"""
+import ctypes
+import os
+
+from . import lib as _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _DevArray:
+    """Minimal CUDA-array-interface holder around a raw device pointer (zero-copy import into torch)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class VM:
+    def __init__(self, device=0, seed=1234, trace=0):
+        _lib.load()                                      # imports torch first, then libt4hip.so (one HIP runtime)
+        path = os.path.join(_HERE, "libten4.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libten4.so not built: run __graft_entry__.build()")
+        self._so = ctypes.CDLL(path)
+        so = self._so
+        so.ten4_new.restype = ctypes.c_void_p
+        so.ten4_new.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int]
+        so.ten4_free.argtypes = [ctypes.c_void_p]
+        so.ten4_eval.restype = ctypes.c_int
+        so.ten4_eval.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        so.ten4_output.restype = ctypes.c_char_p
+        so.ten4_output.argtypes = [ctypes.c_void_p]
+        so.ten4_grad_slab.restype = ctypes.c_int
+        so.ten4_grad_slab.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long)]
+        so.ten4_stream.restype = ctypes.c_void_p
+        so.ten4_stream.argtypes = [ctypes.c_void_p]
+        self._h = so.ten4_new(device, seed, trace)
+        if not self._h:
+            raise RuntimeError("ten4_new failed: no MI355X visible (the VM has no CPU fallback)")
+        self.device = device
+
+    def eval(self, src):
+        """Run Forth source; returns the text the VM printed."""
+        self._so.ten4_eval(self._h, src.encode())
+        return self._so.ten4_output(self._h).decode(errors="replace")
+
+    def grad_slab(self):
+        """torch view (no copy) of the current model's gradient slab."""
+        import torch
+        p = ctypes.c_void_p()
+        n = ctypes.c_long()
+        if self._so.ten4_grad_slab(self._h, ctypes.byref(p), ctypes.byref(n)) != 0:
+            raise RuntimeError("no finalized model: run `forward` once first")
+        return torch.as_tensor(_DevArray(p.value, n.value), device="cuda:%d" % self.device)
+
+    def stream(self):
+        import torch
+        return torch.cuda.ExternalStream(self._so.ten4_stream(self._h), device="cuda:%d" % self.device)
+
+    def close(self):
+        if self._h:
+            self._so.ten4_free(self._h)
+            self._h = None
