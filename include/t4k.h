@@ -220,6 +220,21 @@ int t4k_u8_normalize(const uint8_t *src_dev, float *dst, long n, float mean, flo
 /* Model::_flinear forward.cu:157-198 in one launch:  Y[N,E0] = X[N,E1] @ W[E0,E1]^T + B[E0] */
 int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y,
                    int N, int E0, int E1, t4k_stream_t s);
+/* A run of element-wise layers around one pooling layer, one launch each way (csrc/fused.hip):
+ *   X --[pre: dropout | activation]--> pre_out --[pool KSxKS]--> pool_out --[post: activation]--> post_out --[flatten]--> copy_out
+ * Absent stages have layer == T4K_L_NONE (KS must be 1 when there is no pooling stage).  Every tensor the
+ * separate layers write (_factivate forward.cu:200-209, _fpool :211-227, flatten copy :96) is written with
+ * identical values; a dropout pre-stage draws the Philox slice t4k_rand would have drawn for its mask. */
+typedef struct t4k_poolblock {
+    int    pre_layer;  float pre_alpha;  float *pre_mask;  float *pre_out;
+    int    pool_layer; int KS;           float *pool_out;
+    int    post_layer; float post_alpha; float *post_mask; float *post_out;
+    float *copy_out;
+} t4k_poolblock;
+int t4k_poolblock_fwd(const float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);
+/* backward of the same run (_bactivate backprop.cu:256-263, _bpool, flatten `in = out`): DY is the gradient
+ * w.r.t. the run's last tensor; each stage's input buffer receives its dX (X receives the run's dX). */
+int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);
 /* Model::_blinear backprop.cu:193-254: DB += sum dY; DW += dY^T X (if train); DX = dY @ W.
  * DX may alias X's buffer only when the caller guarantees X is no longer needed: the
  * kernels read X for DW before DX is written (stream order).

@@ -124,6 +124,37 @@ int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, f
     if (!DX) free(dx);
     return r;
 }
+// fused runs: the oracle composes the unfused layer functions - that composition IS the parity statement
+int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t) {
+    const long n1 = (long)N * H1 * W1 * C, n0 = (long)N * H0 * W0 * C;
+    const float *x = X;
+    if (b->pre_layer) {
+        if (b->pre_layer == T4K_L_DROPOUT) t4o_rand(b->pre_mask, n1, T4K_UNIFORM, 0.0f, 1.0f);
+        int r = t4o_activate(b->pre_layer, x, b->pre_out, b->pre_mask, b->pre_alpha, n1); if (r) return rc(r, "poolblock pre");
+        x = b->pre_out;
+    }
+    if (b->pool_layer) { int r = t4o_pool(b->pool_layer, x, b->pool_out, N, H1, W1, H0, W0, C, b->KS); if (r) return rc(r, "poolblock pool"); x = b->pool_out; }
+    if (b->post_layer) { int r = t4o_activate(b->post_layer, x, b->post_out, b->post_mask, b->post_alpha, n0); if (r) return rc(r, "poolblock post"); x = b->post_out; }
+    if (b->copy_out) t4o_copy(x, b->copy_out, n0);
+    return T4K_OK;
+}
+int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t) {
+    const long n1 = (long)N * H1 * W1 * C, n0 = (long)N * H0 * W0 * C;
+    const float *g = DY;
+    float *last = b->post_layer ? b->post_out : (b->pool_layer ? b->pool_out : (b->pre_layer ? b->pre_out : X));
+    if (b->copy_out) { t4o_copy(g, last, n0); g = last; }                       // flatten: in = out
+    if (b->post_layer) {
+        float *in = b->pool_layer ? b->pool_out : (b->pre_layer ? b->pre_out : X);
+        t4o_tt_op(T4K_MUL, g, b->post_mask, in, n0); g = in;
+    }
+    if (b->pool_layer) {
+        float *in = b->pre_layer ? b->pre_out : X;
+        int r = t4o_dpool(b->pool_layer, in, g, N, H1, W1, H0, W0, C, b->KS); if (r) return rc(r, "poolblock dpool");
+        g = in;
+    }
+    if (b->pre_layer) t4o_tt_op(T4K_MUL, g, b->pre_mask, X, n1);
+    return T4K_OK;
+}
 int t4k_opt_multi(int kind, const t4k_param_rec *tab, int nt, long, float lr, float b1, float b2, float wd, t4k_stream_t) {
     for (int i = 0; i < nt; i++) {
         const t4k_param_rec &r = tab[i];

@@ -100,4 +100,41 @@ __device__ __forceinline__ float u01(uint32_t x) {   // (0,1]
     return __fmaf_rn((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
+
+// One activation element, layer kind chosen at run time (same expressions as elementwise.hip act1<L>, which
+// restates k_activate nmath.cu:37-70): i = input, u = uniform draw (dropout only); o = output, f = derivative mask.
+__device__ __forceinline__ void act_rt(int L, float i, float u, float alpha, float &o, float &f) {
+    switch (L) {
+    case T4K_L_RELU:    if (i > 0.0f) { f = 1.0f; o = i; } else { f = 0.0f; o = 0.0f; } break;
+    case T4K_L_TANH:    o = tanhf(i); f = 1.0f - o * o; break;
+    case T4K_L_SIGMOID: o = 1.0f / (1.0f + expf(-i)); f = o * (1.0f - o); break;
+    case T4K_L_SELU:    if (i > 0.0f) { f = (float)1.0507; o = i; }
+                        else { f = (float)(1.7581 * (double)__expf(i)); o = (float)((double)f - 1.7581); } break;
+    case T4K_L_LEAKYRL: if (i > 0.0f) { f = 1.0f; o = i; } else { f = alpha; o = alpha * i; } break;
+    case T4K_L_ELU:     if (i > 0.0f) { f = 1.0f; o = i; } else { f = alpha * __expf(i); o = f - alpha; } break;
+    case T4K_L_DROPOUT: if (u > alpha) { f = 1.0f; o = i; } else { f = 0.0f; o = 0.0f; } break;
+    default:            o = i; f = 1.0f; break;
+    }
+}
+// element `a` of a tensor whose Philox slice starts at counter `base` (units of 4 elements): the same value
+// t4k_rand(uniform, bias 0, scale 1) would have stored at index a
+__device__ __forceinline__ float philox_u01_at(uint64_t base, uint64_t seed, long a) {
+    uint32_t r[4];
+    philox4x32_10(base + (uint64_t)(a >> 2), seed, r);
+    return u01(r[a & 3]);
+}
+// advance the device-resident stream by nq counters once every workgroup of the launch has read it
+__device__ __forceinline__ void rng_advance_last_block(uint64_t *state, uint64_t base, uint64_t nq) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd((unsigned *)&state[1], 1u);
+        if (t == gridDim.x * gridDim.y * gridDim.z - 1) {
+            ((volatile uint64_t *)state)[1] = 0;
+            ((volatile uint64_t *)state)[0] = base + nq;
+            __threadfence();
+        }
+    }
+}
+
 } // namespace t4k

@@ -97,6 +97,7 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
 // fastest schedule - 0.26 ms/step vs 0.28 (hipGraph replay) vs 0.31 (forked side stream; every cross-queue event edge
 // costs more than the ~4.5 us in-order dispatch it hides).  What pays is fewer launches (fused kernels below).
 Model *Model::current = nullptr;
+bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
 bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
 
@@ -138,7 +139,33 @@ void Model::finalize() {                                // gradient slab: SURVEY
     }
     if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }                  // parameter table holds the old pointers
     if (use_side && !side_) chk(t4k_stream_create(&side_), "side stream");
+    plan_runs();
     t4k_sync(stream());
+}
+// Fused element-wise runs: [dropout|activation] [pool] [activation] [flatten] -> one launch each way (csrc/fused.hip).
+// Only mask-multiply activations qualify (sigmoid is pass-through in the reference's backprop, backprop.cu:129-131).
+void Model::plan_runs() {
+    const int L = (int)layer.size() - 1;                // number of ops
+    run_of_.assign(layer.size(), -1); runs_.clear();
+    if (!use_fusion) return;
+    auto is_mact = [](int f) { return f == T4K_L_RELU || f == T4K_L_TANH || f == T4K_L_SELU || f == T4K_L_LEAKYRL || f == T4K_L_ELU; };
+    auto is_pool = [](int f) { return f == T4K_L_AVGPOOL || f == T4K_L_MAXPOOL || f == T4K_L_MINPOOL; };
+    for (int i = 0; i < L; ) {
+        int j = i, pre = -1, pool = -1, post = -1, flat = -1;
+        if (j < L && (is_mact(at(j).grad_fn) || at(j).grad_fn == T4K_L_DROPOUT)) pre = j++;
+        if (j < L && is_pool(at(j).grad_fn) && (at(j).H() % at(j).stride[0] == 0) && (at(j).W() % at(j).stride[0] == 0)) pool = j++;
+        if (j < L && is_mact(at(j).grad_fn) && (pool >= 0 || pre >= 0)) post = j++;
+        if (j < L && at(j).grad_fn == T4K_L_FLATTEN && j > i) flat = j++;
+        if (j - i < 2) { i++; continue; }
+        Run r; r.first = i; r.count = j - i;
+        t4k_poolblock &b = r.blk; memset(&b, 0, sizeof(b)); b.KS = 1;
+        if (pre >= 0)  { b.pre_layer = at(pre).grad_fn; b.pre_alpha = at(pre).xparm; b.pre_mask = at(pre).grad[4]->data; b.pre_out = at(pre + 1).data; }
+        if (pool >= 0) { b.pool_layer = at(pool).grad_fn; b.KS = at(pool).stride[0]; b.pool_out = at(pool + 1).data; }
+        if (post >= 0) { b.post_layer = at(post).grad_fn; b.post_alpha = at(post).xparm; b.post_mask = at(post).grad[4]->data; b.post_out = at(post + 1).data; }
+        if (flat >= 0) b.copy_out = at(flat + 1).data;
+        run_of_[i] = (int)runs_.size(); runs_.push_back(r);
+        i = j;
+    }
 }
 t4k_stream_t Model::fork() {
     if (!concurrent()) return stream();
@@ -202,11 +229,13 @@ void Model::run_forward(Tensor &input) {
     Tensor &n0 = at(0);
     lazy_copy(input.data, n0);                          // layer 0 holds a COPY of the batch (forward.cu:39); conv1 reads the batch itself
     bool masks = false;
-    for (int i = 0; i + 1 < L; i++)                     // dropout masks: drawn up front, in layer order (fixed Philox order)
-        if (at(i).grad_fn == T4K_L_DROPOUT) {
-            Tensor &m = *at(i).grad[4];
-            chk(t4k_rand(m.data, (long)m.numel, T4K_UNIFORM, 0.0f, 1.0f, fork()), "rand"); masks = true;
-        }
+    const bool fused = use_fusion && !(trace && *trace) && !concurrent();
+    if (concurrent())                                   // side stream: draw every dropout mask up front, in layer order
+        for (int i = 0; i + 1 < L; i++)
+            if (at(i).grad_fn == T4K_L_DROPOUT) {
+                Tensor &m = *at(i).grad[4];
+                chk(t4k_rand(m.data, (long)m.numel, T4K_UNIFORM, 0.0f, 1.0f, fork()), "rand"); masks = true;
+            }
     const float *x = input.data;
     for (int i = 0; i + 1 < L; i++) {
         Tensor &in = at(i), &out = at(i + 1);
@@ -214,6 +243,14 @@ void Model::run_forward(Tensor &input) {
             printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.sum() / in.N() / in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
         if (masks && in.grad_fn == T4K_L_DROPOUT) { join(); masks = false; }
+        if (fused && run_of_[i] >= 0) {                 // one launch for the whole element-wise run
+            const Run &r = runs_[run_of_[i]];
+            Tensor &lastt = at(i + r.count), &pin = (r.blk.pool_layer ? at(i + (r.blk.pre_layer ? 1 : 0)) : in);
+            chk(t4k_poolblock_fwd(x, &r.blk, in.N(), pin.H(), pin.W(), r.blk.pool_layer ? at(i + (r.blk.pre_layer ? 2 : 1)).H() : pin.H(),
+                                  r.blk.pool_layer ? at(i + (r.blk.pre_layer ? 2 : 1)).W() : pin.W(), pin.C(), stream()), "nn#frun");
+            x = lastt.data; i += r.count - 1;
+            continue;
+        }
         x = fstep(in, out, x);
         if (trace && *trace && out.has_nan()) { printf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
     }
@@ -231,7 +268,9 @@ const float *Model::fstep(Tensor &in, Tensor &out, const float *x) {
     case T4K_L_LINEAR:
         chk(t4k_linear_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.N(), (int)out.HWC(), (int)in.HWC(), s), "nn#flinear"); break;
     case T4K_L_FLATTEN: lazy_copy(x, out); return x;    // a copy in the reference (forward.cu:96); the next layer reads the source
-    case T4K_L_DROPOUT:                                 // mask already drawn by run_forward
+    case T4K_L_DROPOUT:                                 // mask = fresh uniform draws (already drawn up front on the side-stream schedule)
+        if (!concurrent()) chk(t4k_rand(in.grad[4]->data, (long)in.grad[4]->numel, T4K_UNIFORM, 0.0f, 1.0f, s), "rand");
+        /* fall through */
     case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SIGMOID: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU:
         chk(t4k_activate(fn, x, out.data, in.grad[4]->data, in.xparm, (long)in.numel, s), "nn#factivate"); break;
     case T4K_L_SOFTMAX: chk(t4k_softmax(x, out.data, in.N(), (int)in.HWC(), s), "nn#fsoftmax"); break;
@@ -339,11 +378,24 @@ void Model::run_backward(Tensor &tgt) {
     default: chk(t4k_copy(tgt.data, out.data, (long)out.numel, s), "bprep"); break;
     }
     const float *dy = out.data;                         // where the gradient w.r.t. the current layer's output lives
+    const bool fused = use_fusion && !(trace && *trace) && !concurrent();
     for (int i = (int)layer.size() - 2, j = 0; i >= 0; i--, j++) {
         Tensor &in = at(i), &o = at(i + 1);
         if (trace && *trace)
             printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.xparm, o.sum() / o.N() / o.C(), o.N(), o.H(), o.W(), o.C());
+        if (fused && j > 0) {                           // does a fused run END at op i?
+            int rf = -1;
+            for (int k = i; k >= 0 && k > i - 4; k--) if (run_of_[k] >= 0 && k + runs_[run_of_[k]].count - 1 == i) { rf = k; break; }
+            if (rf >= 0) {
+                const Run &r = runs_[run_of_[rf]];
+                Tensor &fin = at(rf), &pin = (r.blk.pool_layer ? at(rf + (r.blk.pre_layer ? 1 : 0)) : fin);
+                const int ho = r.blk.pool_layer ? at(rf + (r.blk.pre_layer ? 2 : 1)).H() : pin.H(), wo = r.blk.pool_layer ? at(rf + (r.blk.pre_layer ? 2 : 1)).W() : pin.W();
+                chk(t4k_poolblock_bwd(dy, fin.data, &r.blk, fin.N(), pin.H(), pin.W(), ho, wo, pin.C(), s), "nn#brun");
+                dy = fin.data; j += i - rf; i = rf;
+                continue;
+            }
+        }
         dy = bstep(i, in, o, dy, j == 0);
         if (trace && *trace && in.has_nan()) { printf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
     }

@@ -229,6 +229,11 @@ private:
     t4k_stream_t side_ = nullptr;
     std::vector<t4k_event_t> ev_; size_t ev_i_ = 0;
     std::vector<Tensor *> gx_;                 // per-layer dX scratch of linear layers
+    struct Run { int first = 0, count = 1; t4k_poolblock blk; };   // fused element-wise run starting at layer `first`
+    std::vector<int> run_of_;                  // layer index -> index into runs_ or -1
+    std::vector<Run> runs_;
+    void plan_runs();
+    static bool use_fusion;                    // T4_FUSE=0 keeps one launch per layer
     bool finalized_ = false, side_dirty_ = false, capturable_ = true;
     bool concurrent() const { return side_ != nullptr && !(trace && *trace); }
     t4k_stream_t fork();                       // side stream, ordered after everything issued on main so far

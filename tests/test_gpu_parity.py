@@ -413,3 +413,88 @@ def test_graph_capture_replays_a_launch_sequence(t4k, dev):
     t4k.call("t4k_sync", s)
     assert np.all(x.cpu().numpy() == 15.0)                # ((1*2+1)*2+1)*2+1
     t4k.call("t4k_graph_destroy", g); t4k.call("t4k_stream_destroy", s)
+
+
+# ----------------------------------------------------------------------------- fused element-wise runs
+class PoolBlock(ctypes.Structure):
+    _fields_ = [("pre_layer", ctypes.c_int), ("pre_alpha", ctypes.c_float), ("pre_mask", ctypes.c_void_p), ("pre_out", ctypes.c_void_p),
+                ("pool_layer", ctypes.c_int), ("KS", ctypes.c_int), ("pool_out", ctypes.c_void_p),
+                ("post_layer", ctypes.c_int), ("post_alpha", ctypes.c_float), ("post_mask", ctypes.c_void_p), ("post_out", ctypes.c_void_p),
+                ("copy_out", ctypes.c_void_p)]
+
+
+@pytest.mark.parametrize("pre,pool,post,flat,KS,H1", [
+    ("dropout", "max", "relu", True, 2, 14),      # LeNet block 2: conv -> dropout -> maxpool -> relu -> flatten
+    (None, "max", "relu", False, 2, 28),          # LeNet block 1: conv -> maxpool -> relu
+    ("leaky", "avg", "tanh", True, 3, 9),
+    ("relu", None, "elu", False, 1, 6),
+    ("dropout", None, None, True, 1, 5),
+    (None, "min", "selu", True, 2, 8),
+])
+def test_poolblock_matches_unfused_oracle(t4k, dev, oracle, pre, pool, post, flat, KS, H1):
+    """One fused launch each way == the oracle's separate layers (activate / rand / pool / dpool / mask multiply),
+    every intermediate tensor included.  Dropout masks come from the same Philox slice => bit-exact."""
+    o = oracle.lib(); P = oracle.P
+    LAY = {"dropout": (oracle.L_DROPOUT, 0.5), "relu": (oracle.L_RELU, 0.0), "leaky": (oracle.L_LEAKYRL, 0.1), "tanh": (oracle.L_TANH, 0.0),
+           "elu": (oracle.L_ELU, 1.0), "selu": (oracle.L_SELU, 0.0), "max": oracle.L_MAXPOOL, "avg": oracle.L_AVGPOOL, "min": oracle.L_MINPOOL}
+    rng = np.random.default_rng(H1 * 31 + KS)
+    N, C = 3, 5; H0 = H1 // KS
+    n1, n0 = N * H1 * H1 * C, N * H0 * H0 * C
+    X = rng.standard_normal((N, H1, H1, C)).astype(np.float32)
+    DY = rng.standard_normal((N, H0, H0, C)).astype(np.float32)
+    seed, off = 77, 4096
+    # ---- oracle: separate layers
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    ref = {}; x = X
+    if pre:
+        L, a = LAY[pre]; f = np.zeros(n1, np.float32); y = np.zeros_like(X)
+        if pre == "dropout":
+            o.t4o_rand(P(f), n1, 0, 0.0, 1.0)
+        o.t4o_activate(L, P(x), P(y), P(f), a, n1); ref["pre_mask"] = f; ref["pre_out"] = y; x = y
+    if pool:
+        q = np.zeros((N, H0, H0, C), np.float32); o.t4o_pool(LAY[pool], P(x), P(q), N, H1, H1, H0, H0, C, KS); ref["pool_out"] = q; x = q
+    if post:
+        L, a = LAY[post]; f = np.zeros(n0, np.float32); y = np.zeros((N, H0, H0, C), np.float32)
+        o.t4o_activate(L, P(x), P(y), P(f), a, n0); ref["post_mask"] = f; ref["post_out"] = y; x = y
+    if flat:
+        ref["copy_out"] = x.copy()
+    # ---- GPU: one launch
+    t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+    d = {k: dev.zeros(v.shape) for k, v in ref.items()}
+    dX = dev.up(X)
+    blk = PoolBlock()
+    blk.KS = KS
+    if pre:
+        blk.pre_layer, blk.pre_alpha = LAY[pre]; blk.pre_mask = p(d["pre_mask"]); blk.pre_out = p(d["pre_out"])
+    if pool:
+        blk.pool_layer = LAY[pool]; blk.pool_out = p(d["pool_out"])
+    if post:
+        blk.post_layer, blk.post_alpha = LAY[post]; blk.post_mask = p(d["post_mask"]); blk.post_out = p(d["post_out"])
+    if flat:
+        blk.copy_out = p(d["copy_out"])
+    t4k.call("t4k_poolblock_fwd", p(dX), ctypes.byref(blk), N, H1, H1, H0, H0, C, None)
+    for k_, v in ref.items():
+        got = dev.down(d[k_]).reshape(v.shape)
+        assert rel(got, v) < 1e-6, k_
+    if pre == "dropout":
+        assert np.array_equal(dev.down(d["pre_mask"]).ravel(), ref["pre_mask"])        # masks are 0/1: exact
+        assert t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()                        # stream advanced identically
+    # ---- backward: oracle separate layers (in-place convention), GPU one launch
+    g = DY.copy()
+    bufs = {k_: v.copy() for k_, v in ref.items()}; Xb = X.copy()
+    last = "post_out" if post else ("pool_out" if pool else ("pre_out" if pre else None))
+    if flat:
+        (bufs[last] if last else Xb)[...] = g.reshape((bufs[last] if last else Xb).shape)
+    if post:
+        tgt = bufs["pool_out"] if pool else (bufs["pre_out"] if pre else Xb)
+        t = np.zeros(n0, np.float32); o.t4o_tt_op(oracle.MUL, P(g), P(ref["post_mask"]), P(t), n0); tgt[...] = t.reshape(tgt.shape); g = tgt.copy()
+    if pool:
+        tgt = bufs["pre_out"] if pre else Xb
+        o.t4o_dpool(LAY[pool], P(tgt), P(g), N, H1, H1, H0, H0, C, KS); g = tgt.copy()
+    if pre:
+        t = np.zeros(n1, np.float32); o.t4o_tt_op(oracle.MUL, P(g), P(ref["pre_mask"]), P(t), n1); Xb[...] = t.reshape(Xb.shape)
+    t4k.call("t4k_poolblock_bwd", p(dev.up(DY)), p(dX), ctypes.byref(blk), N, H1, H1, H0, H0, C, None)
+    assert rel(dev.down(dX), Xb) < 1e-6
+    for k_ in ("pre_out", "pool_out", "post_out"):
+        if k_ in bufs and not (k_ == last and not flat):
+            assert rel(dev.down(d[k_]).reshape(bufs[k_].shape), bufs[k_]) < 1e-6, "bwd " + k_
