@@ -119,6 +119,9 @@ int t4k_math(int op, float *A, float v, long n, t4k_stream_t s);
 int t4k_ts_op(int op, const float *A, float v, float *O, long n, t4k_stream_t s);
 /* k_tt_op :222  O = A op B */
 int t4k_tt_op(int op, const float *A, const float *B, float *O, long n, t4k_stream_t s);
+/* same with a second destination O2 (may be NULL): `out -= target` plus the pass-through copy `in = out` of a
+ * final softmax/sigmoid layer (backprop.cu:129-131) in one launch */
+int t4k_tt_op2(int op, const float *A, const float *B, float *O, float *O2, long n, t4k_stream_t s);
 /* k_bce :248  *out_dev = sum t*ln(o+eps) + (1-t)*ln(1-o+eps), eps = 1e-6 */
 int t4k_bce(const float *T, const float *O, long n, float *out_dev, t4k_stream_t s);
 /* k_dot :309  O[c] = alpha*sum_k A[k*C+c]*B[k*C+c] + beta*O[c]  for c in [0,C) */
@@ -194,6 +197,12 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F,
                    float *DF, float *DB,
                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, int train, t4k_stream_t s);
+/* same, with an optional second destination for dX: the reference keeps dX in the layer's scratch tensor and
+ * then copies it over the layer input (`in = dx`, backprop.cu:185); DX2 receives that copy from the same launch */
+int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, const float *F,
+                    float *DF, float *DB,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                    int K, int S, int P, int train, t4k_stream_t s);
 /* k_pool<KS> nmath.tcu:122 (layer in AVGPOOL/MAXPOOL/MINPOOL/USAMPLE), KS in {2,3} */
 int t4k_pool(int layer, const float *I, float *O, int N, int H1, int W1, int H0, int W0, int C,
              int KS, t4k_stream_t s);

@@ -59,6 +59,9 @@ int t4k_identity(float *d, int H, int W, int C, t4k_stream_t) { return t4o_ident
 int t4k_math(int op, float *A, float v, long n, t4k_stream_t) { return rc(t4o_math(op, A, v, n), "k_math op not supported"); }
 int t4k_ts_op(int op, const float *A, float v, float *O, long n, t4k_stream_t) { return rc(t4o_ts_op(op, A, v, O, n), "k_ts_op"); }
 int t4k_tt_op(int op, const float *A, const float *B, float *O, long n, t4k_stream_t) { return rc(t4o_tt_op(op, A, B, O, n), "k_tt_op"); }
+int t4k_tt_op2(int op, const float *A, const float *B, float *O, float *O2, long n, t4k_stream_t) {
+    int r = rc(t4o_tt_op(op, A, B, O, n), "k_tt_op"); if (!r && O2) memcpy(O2, O, sizeof(float) * (size_t)n); return r;
+}
 int t4k_bce(const float *T, const float *O, long n, float *out, t4k_stream_t) { return t4o_bce(T, O, n, out); }
 int t4k_dot(const float *A, const float *B, float *O, float a, float b, int K, int C, t4k_stream_t) { return t4o_dot(A, B, O, a, b, K, C); }
 int t4k_gemm(const float *A, const float *B, float *O, float a, float b, int tA, int tB, int M, int N, int K, int C, t4k_stream_t) {
@@ -103,6 +106,12 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, f
     if (!DX) free(dx);
     if (!DF) { free(df); free(db); }
     if (r) snprintf(g_err, sizeof(g_err), "nn#bconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
+    return r;
+}
+int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, const float *F, float *DF, float *DB, int N, int H1, int W1, int C1,
+                    int H0, int W0, int C0, int K, int S, int P, int tr, t4k_stream_t st) {
+    int r = t4k_conv2d_bwd(I, DO, DX, F, DF, DB, N, H1, W1, C1, H0, W0, C0, K, S, P, tr, st);
+    if (!r && DX && DX2) memcpy(DX2, DX, sizeof(float) * (size_t)N * H1 * W1 * C1);
     return r;
 }
 int t4k_pool(int l, const float *I, float *O, int N, int H1, int W1, int H0, int W0, int C, int KS, t4k_stream_t) { return rc(t4o_pool(l, I, O, N, H1, W1, H0, W0, C, KS), "k_pool"); }

@@ -28,7 +28,7 @@ constexpr int LDS_FILTER_FLOATS = 8192;          // 32 KiB filter slice per work
 // ------------------------------------------------------------------ forward / dX gather-GEMM
 // BWD = false: forward (Cin = C1 of I, Cout = C0);  BWD = true: dX (Cin = C0 of dO, Cout = C1)
 template <int K, int S, int P, bool BWD>
-__global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, float *__restrict__ Y,
+__global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
                                                    const float *__restrict__ F, const float *__restrict__ B,
                                                    int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout,
                                                    int C0 /* filter inner dim */, int pairs_per_chunk) {
@@ -47,9 +47,40 @@ __global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, 
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
+    // per-tap element offsets of this lane's pixel (-1 = outside the image): computed once, so the loads below are
+    // unconditional (clamped address + select) and the compiler can keep a whole chunk of them in flight
+    int off[K * K];
+#pragma unroll
+    for (int ky = 0; ky < K; ky++) {
+        int gi; bool iok;
+        if (!BWD) { gi = iy * S + ky - P; iok = gi >= 0 && gi < Hx; }
+        else { const int ti = iy + P - ky; gi = ti / S; iok = ti >= 0 && (ti % S) == 0 && gi < Hx; }
+#pragma unroll
+        for (int kx = 0; kx < K; kx++) {
+            int gj; bool jok;
+            if (!BWD) { gj = jy * S + kx - P; jok = gj >= 0 && gj < Wx; }
+            else { const int tj = jy + P - kx; gj = tj / S; jok = tj >= 0 && (tj % S) == 0 && gj < Wx; }
+            off[ky * K + kx] = (pok && iok && jok) ? (gi * Wx + gj) * Cin : -1;
+        }
+    }
     const int npairs = (Cin + 1) >> 1;
+    // Small filters (the whole [C1][K][K][C0] tensor fits the LDS stage) are copied verbatim with coalesced 16 B loads -
+    // one round trip - and indexed in place; the per-element gather into MFMA-B order below costs a dependent global
+    // load per LDS entry and dominated the LeNet-size layers.
+    const int nF = (BWD ? Cout : Cin) * K * K * C0;
+    const bool raw = nF <= LDS_FILTER_FLOATS;
+    if (raw) {
+        pairs_per_chunk = npairs;
+        if ((((uintptr_t)F) & 15) == 0) {
+            const int n4 = nF >> 2;
+            for (int e = tid; e < n4; e += 256) reinterpret_cast<float4 *>(Bl)[e] = reinterpret_cast<const float4 *>(F)[e];
+            for (int e = (n4 << 2) + tid; e < nF; e += 256) Bl[e] = F[e];
+        } else for (int e = tid; e < nF; e += 256) Bl[e] = F[e];
+        __syncthreads();
+    }
     for (int cp0 = 0; cp0 < npairs; cp0 += pairs_per_chunk) {
         const int cpn = min(pairs_per_chunk, npairs - cp0);
+        if (!raw) {
         // ---- stage the filter slice: Bl[((cp*K+ky)*K+kx)*2+hh][col] ----
         __syncthreads();
         const int nent = cpn * K * K * 2 * 32;
@@ -66,22 +97,35 @@ __global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, 
             Bl[e] = v;
         }
         __syncthreads();
-        for (int cp = 0; cp < cpn; cp++) {
-            const int ci = 2 * (cp0 + cp) + h;
-            const bool cok = pok && ci < Cin;
+        }
+        for (int cpb = 0; cpb < cpn; cpb += 2) {            // two channel pairs per trip: 2*K*K loads in flight
+            float a[2][K * K];
 #pragma unroll
-            for (int ky = 0; ky < K; ky++) {
-                int gi; bool iok;
-                if (!BWD) { gi = iy * S + ky - P; iok = gi >= 0 && gi < Hx; }
-                else { const int ti = iy + P - ky; gi = ti / S; iok = ti >= 0 && (ti % S) == 0 && gi < Hx; }
+            for (int u = 0; u < 2; u++) {
+                const int ci = 2 * (cp0 + cpb + u) + h;
+                const bool cok = (cpb + u) < cpn && ci < Cin;
 #pragma unroll
-                for (int kx = 0; kx < K; kx++) {
-                    int gj; bool jok;
-                    if (!BWD) { gj = jy * S + kx - P; jok = gj >= 0 && gj < Wx; }
-                    else { const int tj = jy + P - kx; gj = tj / S; jok = tj >= 0 && (tj % S) == 0 && gj < Wx; }
-                    const float a = (cok && iok && jok) ? nX[((long)gi * Wx + gj) * Cin + ci] : 0.f;
-                    const float b = Bl[(((cp * K + ky) * K + kx) * 2 + h) * 32 + l31];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                for (int t = 0; t < K * K; t++) {
+                    const bool ok = cok && off[t] >= 0;
+                    const float v = nX[ok ? off[t] + ci : 0];
+                    a[u][t] = ok ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (cpb + u < cpn) {
+#pragma unroll
+                    for (int t = 0; t < K * K; t++) {
+                        float b;
+                        if (raw) {
+                            const int ci = 2 * (cpb + u) + h, co = co0 + l31;
+                            const bool ok = ci < Cin && co < Cout;
+                            const int idx = !BWD ? (ci * K * K + t) * C0 + co : (co * K * K + (K * K - 1 - t)) * C0 + ci;
+                            const float v = Bl[ok ? idx : 0];
+                            b = ok ? v : 0.f;
+                        } else b = Bl[(((cpb + u) * K * K + t) * 2 + h) * 32 + l31];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b, acc, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -93,7 +137,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, 
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const long p2 = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (p2 < npix) Y[p2 * Cout + co] = acc[r] + bias;
+            if (p2 < npix) { const float v = acc[r] + bias; Y[p2 * Cout + co] = v; if (Y2) Y2[p2 * Cout + co] = v; }
         }
     }
 }
@@ -126,16 +170,28 @@ __global__ void __launch_bounds__(256) k_conv_df_mfma(const float *__restrict__ 
         const int n = row / H0, i0 = row - n * H0;          // wave-uniform
         const int gi = i0 * S + ky - P;
         const bool iok = is_tap && gi >= 0 && gi < H1;
-        const float *rI = I + (((long)n * H1 + gi) * W1) * C1 + c1;
-        const float *rO = DO + ((long)row * W0) * C0 + co;
-        for (int it = 0; it < (W0 + 1) / 2; it++) {         // wave-uniform trip count; lane half h takes pixel 2*it + h
-            const int j0 = 2 * it + h;
-            const bool jv = j0 < W0;
-            const int gj = j0 * S + kx - P;
-            float a = 0.f;
-            if (jv) { if (is_bias) a = 1.f; else if (iok && gj >= 0 && gj < W1) a = rI[(long)gj * C1]; }
-            const float b = (jv && cok) ? rO[(long)j0 * C0] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        const float *rI = iok ? I + (((long)n * H1 + gi) * W1) * C1 + c1 : I;
+        const float *rO = DO + ((long)row * W0) * C0 + (cok ? co : 0);
+        const int nit = (W0 + 1) / 2;                       // wave-uniform trip count; lane half h takes pixel 2*it + h
+        for (int itb = 0; itb < nit; itb += 7) {            // 7 pixel pairs per trip (W0 = 14, 28: no tail): 14 loads in flight
+            float av[7], bv[7]; bool aok[7], jv[7];
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                const int j0 = 2 * (itb + u) + h;
+                jv[u] = (itb + u) < nit && j0 < W0;
+                const int gj = j0 * S + kx - P;
+                aok[u] = jv[u] && iok && gj >= 0 && gj < W1;
+                av[u] = rI[aok[u] ? gj * C1 : 0];           // unconditional (clamped) loads
+                bv[u] = rO[jv[u] ? j0 * C0 : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                if (itb + u < nit) {
+                    const float a = (jv[u] && is_bias) ? 1.f : (aok[u] ? av[u] : 0.f);
+                    const float b = (jv[u] && cok) ? bv[u] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+            }
         }
     }
     // wave -> workgroup reduction through LDS, then one slab entry per (slice, tap, c0)
@@ -150,23 +206,19 @@ __global__ void __launch_bounds__(256) k_conv_df_mfma(const float *__restrict__ 
             part[((long)blockIdx.x * nrow1 + gt) * C0 + gc] = (red[0][tr][tc] + red[1][tr][tc]) + (red[2][tr][tc] + red[3][tr][tc]);
     }
 }
-// fold the slabs in slice order: DF[i] += ..., DB[c0] += ...   (64 outputs x 4 slice-groups per block)
+// fold the slabs: DF[i] += sum_slice part[slice][i], DB likewise.  One wave per output: lane l adds slices l, l+64, ...
+// (all loads of a lane are independent), then a fixed xor-tree across the wave => deterministic, and the
+// ~1000 slices of a LeNet-size layer are summed in two load rounds instead of a 200-deep dependent chain.
 __global__ void __launch_bounds__(256) k_conv_df_fold(const float *__restrict__ part, float *DF, float *DB,
                                                       int nslice, int ndf, int ntot) {
-    __shared__ float sm[4][64];
-    const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + ex;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + w;
+    if (i >= ntot) return;
     float s = 0.f;
-    if (i < ntot) {
-#pragma unroll 8
-        for (int k = g; k < nslice; k += 4) s += part[(long)k * ntot + i];
-    }
-    sm[g][ex] = s;
-    __syncthreads();
-    if (g == 0 && i < ntot) {
-        const float t = (sm[0][ex] + sm[1][ex]) + (sm[2][ex] + sm[3][ex]);
-        if (i < ndf) DF[i] += t; else DB[i - ndf] += t;
-    }
+#pragma unroll 4
+    for (int k = lane; k < nslice; k += 64) s += part[(long)k * ntot + i];
+    s = wave_sum_all(s);
+    if (lane == 0) { if (i < ndf) DF[i] += s; else DB[i - ndf] += s; }
 }
 
 // ------------------------------------------------------------------ generic column sums (dlinear_db)
@@ -259,14 +311,14 @@ bool conv_supported(int K, int S, int P) {
 }
 
 template <bool BWD>
-void launch_conv_gemm(int K, int S, int P, dim3 g, hipStream_t hs, const float *X, float *Y, const float *F, const float *B,
+void launch_conv_gemm(int K, int S, int P, dim3 g, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
                       int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0) {
     const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);            // channel pairs per LDS filter slice
     switch ((K << 8) | (S << 4) | P) {
-    case 0x110: hipLaunchKernelGGL((k_conv_gemm<1, 1, 0, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
-    case 0x311: hipLaunchKernelGGL((k_conv_gemm<3, 1, 1, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
-    case 0x421: hipLaunchKernelGGL((k_conv_gemm<4, 2, 1, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
-    case 0x512: hipLaunchKernelGGL((k_conv_gemm<5, 1, 2, BWD>), g, dim3(256), 0, hs, X, Y, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x110: hipLaunchKernelGGL((k_conv_gemm<1, 1, 0, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x311: hipLaunchKernelGGL((k_conv_gemm<3, 1, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x421: hipLaunchKernelGGL((k_conv_gemm<4, 2, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x512: hipLaunchKernelGGL((k_conv_gemm<5, 1, 2, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
     }
 }
 
@@ -302,7 +354,7 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
     if (!I || !O || !F || !B || N <= 0 || C0 <= 0 || C1 <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_fwd: bad argument");
     const long npix = (long)N * H0 * W0;
     dim3 g((unsigned)((npix + 127) / 128), (unsigned)((C0 + 31) / 32));
-    launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0);
+    launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }
@@ -310,6 +362,12 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
 int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB,
                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, int train, t4k_stream_t s) {
+    return t4k_conv2d_bwd2(I, DO, DX, nullptr, F, DF, DB, N, H1, W1, C1, H0, W0, C0, K, S, P, train, s);
+}
+
+int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, const float *F, float *DF, float *DB,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                    int K, int S, int P, int train, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!conv_supported(K, S, P))
         return fail(T4K_ERR_UNSUPPORTED, "nn#bconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
@@ -319,8 +377,13 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, f
     if (train && DF) {                                  // DF == NULL: dX only (the caller runs dF|dB on another stream)
         // dF | dB first: they read I, which the host layer may let DX overwrite
         const int ntaps = C1 * K * K, nrow1 = ntaps + 1;
+        {
         const int rows = N * H0;
-        int nslice = (rows + 3) / 4; if (nslice > 128) nslice = 128; if (nslice < 1) nslice = 1;
+        // enough slices that ~2000 waves are in flight (each wave then issues only a few batches of loads) without
+        // inflating the partial slab the fold has to read: 512 workgroups in total across the (tap, c0) tiles
+        const int tiles = ((nrow1 + 31) / 32) * ((C0 + 31) / 32);
+        int nslice = (512 + tiles - 1) / tiles; if (nslice > (rows + 3) / 4) nslice = (rows + 3) / 4; if (nslice < 1) nslice = 1;
+        while (nslice > 1 && (size_t)nslice * nrow1 * C0 * sizeof(float) > st().ws_bytes / 8) nslice >>= 1;
         const int rpw = (rows + nslice * 4 - 1) / (nslice * 4);
         nslice = (rows + rpw * 4 - 1) / (rpw * 4);
         float *part = ws_for(s);
@@ -333,13 +396,14 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, f
         case 0x512: hipLaunchKernelGGL((k_conv_df_mfma<5, 1, 2>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
         }
         const int ntot = nrow1 * C0;
-        hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 63) / 64), dim3(256), 0, hs, part, DF, DB, nslice, ntaps * C0, ntot);
+        hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, part, DF, DB, nslice, ntaps * C0, ntot);
+        }
     }
-    if (DX) {                                           // DX == NULL: dF|dB only
+    if (DX) {                                           // DX == NULL: dF|dB only; DX2 = optional second copy from the same launch
         const long npix1 = (long)N * H1 * W1;
         dim3 g((unsigned)((npix1 + 127) / 128), (unsigned)((C1 + 31) / 32));
         // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1)
-        launch_conv_gemm<true>(K, S, P, g, hs, DO, DX, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0);
+        launch_conv_gemm<true>(K, S, P, g, hs, DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0);
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(BLK) k_ts(const float *A, float v, float *O, l
     } else for (long j = tx; j < n; j += step) O[j] = bin<OP>(A[j], v);
 }
 template <int OP>
-__global__ void __launch_bounds__(BLK) k_tt(const float *A, const float *B, float *O, long n, bool vec) {
+__global__ void __launch_bounds__(BLK) k_tt(const float *A, const float *B, float *O, float *O2, long n, bool vec) {
     const long tx = (long)blockIdx.x * BLK + threadIdx.x, step = (long)gridDim.x * BLK;
     if (vec) {
         const long n4 = n >> 2;
@@ -88,9 +88,10 @@ __global__ void __launch_bounds__(BLK) k_tt(const float *A, const float *B, floa
             float4 b = reinterpret_cast<const float4 *>(B)[q];
             a.x = bin<OP>(a.x, b.x); a.y = bin<OP>(a.y, b.y); a.z = bin<OP>(a.z, b.z); a.w = bin<OP>(a.w, b.w);
             reinterpret_cast<float4 *>(O)[q] = a;
+            if (O2) reinterpret_cast<float4 *>(O2)[q] = a;
         }
-        for (long j = (n4 << 2) + tx; j < n; j += step) O[j] = bin<OP>(A[j], B[j]);
-    } else for (long j = tx; j < n; j += step) O[j] = bin<OP>(A[j], B[j]);
+        for (long j = (n4 << 2) + tx; j < n; j += step) { const float v = bin<OP>(A[j], B[j]); O[j] = v; if (O2) O2[j] = v; }
+    } else for (long j = tx; j < n; j += step) { const float v = bin<OP>(A[j], B[j]); O[j] = v; if (O2) O2[j] = v; }
 }
 
 __global__ void __launch_bounds__(BLK) k_copy(const float *__restrict__ src, float *__restrict__ dst, long n, bool vec) {
@@ -223,11 +224,12 @@ int t4k_ts_op(int op, const float *A, float v, float *O, long n, t4k_stream_t s)
     default: return fail(T4K_ERR_UNSUPPORTED, "k_ts_op op=%d not supported", op); }
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
-#define TT_CASE(OP) case OP: hipLaunchKernelGGL(k_tt<OP>, dim3(g), dim3(BLK), 0, S(s), A, B, O, n, vec); break
-int t4k_tt_op(int op, const float *A, const float *B, float *O, long n, t4k_stream_t s) {
+#define TT_CASE(OP) case OP: hipLaunchKernelGGL(k_tt<OP>, dim3(g), dim3(BLK), 0, S(s), A, B, O, O2, n, vec); break
+int t4k_tt_op(int op, const float *A, const float *B, float *O, long n, t4k_stream_t s) { return t4k_tt_op2(op, A, B, O, nullptr, n, s); }
+int t4k_tt_op2(int op, const float *A, const float *B, float *O, float *O2, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!A || !B || !O) return fail(T4K_ERR_ARG, "t4k_tt_op: null");
-    const bool vec = VEC3(A, B, O); const int g = grid_for(n, 4);
+    const bool vec = VEC3(A, B, O) && (!O2 || aligned16(O2)); const int g = grid_for(n, 4);
     switch (op) { TT_CASE(T4K_ADD); TT_CASE(T4K_SUB); TT_CASE(T4K_MUL); TT_CASE(T4K_DIV);
     default: return fail(T4K_ERR_UNSUPPORTED, "k_tt_op op=%d not supported", op); }
     T4K_LAUNCH_CHECK(); return T4K_OK;

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
     const long total = (long)p.N * p.H0 * p.W0 * p.C;
     uint64_t base = 0, seed = 0;
     const bool draw = p.pre == T4K_L_DROPOUT;
-    if (draw) { base = ((volatile uint64_t *)p.rng)[0]; seed = ((volatile uint64_t *)p.rng)[2]; }
+    if (draw) rng_state_read(p.rng, base, seed);
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
         const int c = (int)(z % p.C); long t = z / p.C;
         const int j0 = (int)(t % p.W0); t /= p.W0;

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(BLK) k_opt_multi(int kind, const t4k_param_rec
 // The stream state (counter, seed) is read from device memory and advanced by the last workgroup to
 // finish, so the same launch captured in a hipGraph draws a fresh slice of the stream on every replay.
 __global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float bias, float scale, uint64_t *state) {
-    const uint64_t base = ((volatile uint64_t *)state)[0], seed = ((volatile uint64_t *)state)[2];
+    uint64_t base, seed; rng_state_read(state, base, seed);
     const long nq = (n + 3) >> 2;
     for (long q = (long)blockIdx.x * BLK + threadIdx.x; q < nq; q += (long)gridDim.x * BLK) {
         uint32_t r[4]; float v[4];
@@ -93,16 +93,7 @@ __global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float b
 #pragma unroll
         for (int k = 0; k < 4; k++) { const long i = q * 4 + k; if (i < n) d[i] = scale * (bias + v[k]); }
     }
-    __syncthreads();                                    // every thread of this block has read `base`
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned t = atomicAdd((unsigned *)&state[1], 1u);
-        if (t == gridDim.x - 1) {                       // last block out: all blocks have read `base`
-            ((volatile uint64_t *)state)[1] = 0;
-            ((volatile uint64_t *)state)[0] = base + (uint64_t)nq;
-            __threadfence();
-        }
-    }
+    rng_advance_last_block(state, base, (uint64_t)nq);
 }
 
 } // namespace

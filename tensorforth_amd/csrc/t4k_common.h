@@ -125,16 +125,21 @@ __device__ __forceinline__ float philox_u01_at(uint64_t base, uint64_t seed, lon
 }
 // advance the device-resident stream by nq counters once every workgroup of the launch has read it
 __device__ __forceinline__ void rng_advance_last_block(uint64_t *state, uint64_t base, uint64_t nq) {
+    // No fences: the only ordering needed is "every workgroup has READ state[0] before it is rewritten", and each
+    // workgroup's read has returned (its value was used) before the barrier below.  Relaxed agent-scope atomics keep
+    // the ticket coherent across the 8 XCD L2s without the L2 write-back a release fence would trigger per workgroup.
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned t = atomicAdd((unsigned *)&state[1], 1u);
+        const unsigned t = __hip_atomic_fetch_add((unsigned *)&state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x * gridDim.y * gridDim.z - 1) {
-            ((volatile uint64_t *)state)[1] = 0;
-            ((volatile uint64_t *)state)[0] = base + nq;
-            __threadfence();
+            __hip_atomic_store((unsigned *)&state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[0], base + nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+__device__ __forceinline__ void rng_state_read(const uint64_t *state, uint64_t &base, uint64_t &seed) {
+    base = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seed = __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace t4k

@@ -156,7 +156,7 @@ void Model::plan_runs() {
         if (j < L && is_pool(at(j).grad_fn) && (at(j).H() % at(j).stride[0] == 0) && (at(j).W() % at(j).stride[0] == 0)) pool = j++;
         if (j < L && is_mact(at(j).grad_fn) && (pool >= 0 || pre >= 0)) post = j++;
         if (j < L && at(j).grad_fn == T4K_L_FLATTEN && j > i) flat = j++;
-        if (j - i < 2) { i++; continue; }
+        if (j - i < 2 && !(j - i == 1 && pre >= 0 && at(pre).grad_fn == T4K_L_DROPOUT)) { i++; continue; }   // a lone dropout still fuses its mask draw
         Run r; r.first = i; r.count = j - i;
         t4k_poolblock &b = r.blk; memset(&b, 0, sizeof(b)); b.KS = 1;
         if (pre >= 0)  { b.pre_layer = at(pre).grad_fn; b.pre_alpha = at(pre).xparm; b.pre_mask = at(pre).grad[4]->data; b.pre_out = at(pre + 1).data; }
@@ -372,14 +372,20 @@ Model &Model::backprop(Tensor &tgt) {
 void Model::run_backward(Tensor &tgt) {
     Tensor &out = at(-1);
     t4k_stream_t s = stream();
+    const bool fused = use_fusion && !(trace && *trace) && !concurrent();
+    int skip = 0;                                       // layers already handled by the prep launch
     switch (at(-2).grad_fn) {
-    case T4K_L_LINEAR: case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
+    case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
+        if (fused && layer.size() > 2) {                // out -= target, and the pass-through `in = out` of the last layer, in one launch
+            chk(t4k_tt_op2(T4K_SUB, out.data, tgt.data, out.data, at(-2).data, (long)out.numel, s), "bprep"); skip = 1; break;
+        }
+        /* fall through */
+    case T4K_L_LINEAR:
         chk(t4k_tt_op(T4K_SUB, out.data, tgt.data, out.data, (long)out.numel, s), "bprep"); break;
     default: chk(t4k_copy(tgt.data, out.data, (long)out.numel, s), "bprep"); break;
     }
     const float *dy = out.data;                         // where the gradient w.r.t. the current layer's output lives
-    const bool fused = use_fusion && !(trace && *trace) && !concurrent();
-    for (int i = (int)layer.size() - 2, j = 0; i >= 0; i--, j++) {
+    for (int i = (int)layer.size() - 2 - skip, j = skip; i >= 0; i--, j++) {
         Tensor &in = at(i), &o = at(i + 1);
         if (trace && *trace)
             printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
@@ -412,6 +418,11 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
         Tensor &dx = *in.grad[4];
         const int N = in.N(), H1 = in.H(), W1 = in.W(), C1 = in.C(), H0 = out.H(), W0 = out.W(), C0 = out.C();
         const int K = in.grad[0]->H(), S = in.stride[0], P = in.stride[2];
+        if (!concurrent()) {                            // one stream: dF|dB read x first, then dX lands in the scratch tensor AND over x
+            chk(t4k_conv2d_bwd2(in.data, dy, dx.data, in.data, in.grad[0]->data, train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr,
+                                N, H1, W1, C1, H0, W0, C0, K, S, P, train, s), "nn#bconv");
+            return in.data;
+        }
         if (train) chk(t4k_conv2d_bwd(in.data, dy, nullptr, in.grad[0]->data, in.grad[2]->data, in.grad[3]->data,
                                       N, H1, W1, C1, H0, W0, C0, K, S, P, 1, fork()), "nn#bconv dF");
         chk(t4k_conv2d_bwd(in.data, dy, dx.data, in.grad[0]->data, nullptr, nullptr, N, H1, W1, C1, H0, W0, C0, K, S, P, 0, s), "nn#bconv dX");
