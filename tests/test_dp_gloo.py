@@ -1,0 +1,95 @@
+"""Data-parallel path on CPU: world_size 2 over gloo (127.0.0.1).
+
+Each rank builds the same replica (oracle model, same Philox seed), runs forward/backprop on ITS rows of
+the global batch, all-reduces the flattened gradient slab with tensorforth_amd.dp (the code bench.py
+uses on the GPUs), applies SGD, and the result must equal a single process training on the whole batch:
+gradients are raw batch sums in the reference (gradient.cu:63-126), so SUM over shards is exact up to
+fp32 summation order.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+GLOBAL_N = 8
+
+
+def _build(n):
+    import t4oracle
+    m = t4oracle.OracleModel(n, 12, 12, 1, seed=99)
+    m.conv2d(4, 0.5).maxpool(2).relu().flatten().linear(16).relu().linear(10).softmax()
+    return m
+
+
+def _data():
+    rng = np.random.default_rng(5)
+    x = rng.random((GLOBAL_N, 12, 12, 1)).astype(np.float32)
+    lab = rng.integers(0, 10, GLOBAL_N).astype(np.uint32)
+    return x, lab
+
+
+def _grads(m):
+    return [g for L in m.layers for g in (L.dw, L.db) if g is not None]
+
+
+def _params(m):
+    return [g for L in m.layers for g in (L.w, L.b) if g is not None]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tensorforth_amd import dp
+    x, lab = _data()
+    lo, hi = dp.shard_rows(GLOBAL_N, rank, world)
+    m = _build(hi - lo)
+    for _ in range(2):
+        m.forward(x[lo:hi]); m.onehot_labels(lab[lo:hi]); m.backprop()
+        gs = _grads(m)
+        slab = torch.from_numpy(np.concatenate([g.ravel() for g in gs]))          # the gradient slab
+        dp.allreduce_grad_slab(slab)
+        off = 0
+        for g in gs:
+            g[...] = slab[off:off + g.size].numpy().reshape(g.shape); off += g.size
+        m.sgd(0.05, 0.0)
+    loss_n = float(m.loss_ce()) * (hi - lo) if hasattr(m, "loss_ce") else 0.0
+    tot = dp.allreduce_scalars([loss_n, float(hi - lo)])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), *[p for p in _params(m)], tot=np.array(tot))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_rows_and_offsets():
+    from tensorforth_amd import dp
+    assert [dp.shard_rows(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]
+    with pytest.raises(ValueError):
+        dp.shard_rows(10, 0, 4)
+    offs = {dp.rank_rng_offset(r) for r in range(8)}
+    assert len(offs) == 8 and min(offs) >= 1 << 36 and all(o % 4 == 0 for o in offs)
+
+
+def test_two_rank_gloo_equals_single_process_large_batch(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 400)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    # single process, whole batch
+    x, lab = _data()
+    m = _build(GLOBAL_N)
+    for _ in range(2):
+        m.forward(x); m.onehot_labels(lab); m.backprop(); m.sgd(0.05, 0.0)
+    ref = _params(m)
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz")); r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    for i, p in enumerate(ref):
+        a, b = r0["arr_%d" % i], r1["arr_%d" % i]
+        assert np.array_equal(a, b), "replicas diverged"                            # same slab on both ranks => bit-identical updates
+        np.testing.assert_allclose(a, p, rtol=2e-5, atol=2e-6)                       # == large-batch update up to summation order
+    assert r0["tot"][1] == GLOBAL_N
