@@ -144,9 +144,10 @@ def main():
         avg_ms = tot / reps
         flops = 2.0 * 1024 ** 3
         tf = flops / (avg_ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_gemm_mfma<64,64> (1024^3 fp32 matmul)", "bound": "mfma", "achieved": round(tf, 2),
+        out["roofline"] = {"kernel": "k_gemm_glds8<64> (1024^3 fp32 matmul: 64x64 tiles, 8 waves/WG, LDS-DMA 3-stage pipeline)", "bound": "mfma", "achieved": round(tf, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2), "best_launch_us": round(best * 1e3, 2),
+                           "traffic": GEMM_TRAFFIC_BYTES, "traffic_source": "profiles/r01_bench_pmc_hbm.txt (TCC_EA0_RDREQ*64B x2 gfx950 correction + WRREQ_64B*64B, separate --pmc pass)",
+                           "avg_launch_us": round(avg_ms * 1e3, 2), "best_launch_us": round(best * 1e3, 2),
                            "flop_per_launch": flops}
         # ---- CPU baseline: the oracle ("port"), bounded sample
         if not args.no_cpu_baseline:

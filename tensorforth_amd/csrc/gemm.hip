@@ -43,6 +43,8 @@ struct GemmP {
     int tiles_m, tiles_n;
     int kchunk, nsplit;
     float alpha, beta;
+    int pair;                          // 1: two workgroups per tile (K halves) combine in the epilogue, no fold launch
+    int *sync;                         // [0,2048) tickets, [2048,4096) flags (self-cleaning)
 };
 
 // FULL: every tile is interior (M%BM == N%BN == K-slice%BK == 0, VEC): no predicates, no branches in
@@ -459,10 +461,205 @@ __global__ void __launch_bounds__(256) k_gemm_glds(GemmP p) {
 
     const float alpha = p.alpha, beta = p.beta;
     const int gn = n0 + wn * 32 + l31;
+    float add[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) add[r] = 0.f;
+    if (p.pair) {
+        // Two workgroups own this tile (one K half each) so every SIMD holds two independent waves.  The first to
+        // finish parks its 64x64 partial in the workspace and raises a flag; the second adds it (a+b == b+a, so the
+        // result does not depend on who wins) and runs the epilogue.  Agent-scope release/acquire: the two
+        // workgroups may sit on different XCDs, whose L2s are not coherent with each other.
+        __shared__ int role_s;
+        const int tile_id = tm * p.tiles_n + tn;
+        int *ticket = p.sync + tile_id, *flag = p.sync + 2048 + tile_id;
+        float *slot = p.part + (long)tile_id * (BM * BN);
+        if (tid == 0) role_s = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // The payload moves with agent-scope (write-through / cache-bypassing) stores and loads, so no fence is needed:
+        // a release fence here costs an L2 write-back per workgroup (~1 us each, serialised per XCD - measured +25 us).
+        if (role_s == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) __hip_atomic_store(&slot[r * 256 + tid], acc0[r] + acc1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my stores are acknowledged ...
+            __syncthreads();                                      // ... and so are everybody's
+            if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) add[r] = __hip_atomic_load(&slot[r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = acc0[r] + acc1[r];
+        const float v = (acc0[r] + acc1[r]) + add[r];
+        if (p.nsplit > 1 && !p.pair) p.part[((long)blockIdx.y * M + gm) * N + gn] = v;
+        else {
+            const long z = (long)gm * N + gn;
+            float o = v * alpha;
+            if (beta != 0.f) o += p.O[z] * beta;
+            if (p.bias) o += p.bias[gn];
+            p.O[z] = o;
+        }
+    }
+}
+
+// 8-wave variant: the same pipeline with two waves per SIMD.  Waves 4..7 take the upper half of every stage's k chunks
+// into their own accumulators, so one wave's LDS reads and waits sit under the other's MFMAs; the halves are summed
+// through LDS in the epilogue (fixed order).
+template <int BK, bool AKC, bool BKC>
+__global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
+    constexpr int BM = 64, BN = 64;
+    constexpr int NC = BK / 8, CH = BK / 4, SW = 64 / BK;
+    constexpr int STAGE = (BM + BN) * BK;          // floats per stage buffer
+    constexpr int NI = BK / 4;                     // 1-KiB DMA instructions per operand per stage
+    constexpr int NJ = NI / 8;                     // ... per wave (8 waves)
+    constexpr int NPW = 2 * NJ;                    // DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = w >> 2, w4 = w & 3;               // k-group (which half of every stage's chunks), wave within the 2x2 tile grid
+    const int wm = w4 >> 1, wn = w4 & 1, h = lane >> 5, l31 = lane & 31;
+    constexpr int NCG = NC / 2;                       // chunks per k-group per stage
+    const int c0 = kg * NCG;
+    const int M = p.M, N = p.N, K = p.K;
+
+    const int T = p.tiles_m * p.tiles_n;
+    int L;
+    {
+        const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
+        L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i;
+    }
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int grp = L / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (L % per_group) % gsz, tn = (L % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * p.kchunk;
+    const int kend = min(K, kbeg + p.kchunk);
+    const int nst  = (kend - kbeg) / BK;
+
+    // per-lane DMA source pointers of stage 0
+    const float *srcA[NJ], *srcB[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int i = w * NJ + j;
+        if (AKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
+                   srcA[j] = p.A + (long)(m0 + r) * K + kbeg + q * 4; }
+        else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
+                   srcA[j] = p.A + (long)(kbeg + kk) * M + m0 + ch * 4; }
+        if (BKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
+                   srcB[j] = p.B + (long)(n0 + r) * K + kbeg + q * 4; }
+        else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
+                   srcB[j] = p.B + (long)(kbeg + kk) * N + n0 + ch * 4; }
+    }
+    const long stepA = AKC ? BK : (long)BK * M, stepB = BKC ? BK : (long)BK * N;
+
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        float *base = lds + buf * STAGE + (w * NJ) * 256;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[j] + kt * stepA),
+                                             (__attribute__((address_space(3))) void *)(base + j * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[j] + kt * stepB),
+                                             (__attribute__((address_space(3))) void *)(base + BM * BK + j * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    const int ra_ = wm * 32 + l31, rb_ = wn * 32 + l31;
+    // operand fragments of one 8-deep k chunk (lane half h holds k = 8*ci + 4*h + {0..3})
+    auto rd = [&](const float *a, const float *b, int ci, float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
+        if (AKC) { const v4f t = *reinterpret_cast<const v4f *>(a + ra_ * BK + (((ci * 2 + h) ^ ((ra_ / SW) & (CH - 1))) << 2));
+                   av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3]; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) av[j] = a[(ci * 8 + 4 * h + j) * BM + ra_];
+        }
+        if (BKC) { const v4f t = *reinterpret_cast<const v4f *>(b + rb_ * BK + (((ci * 2 + h) ^ ((rb_ / SW) & (CH - 1))) << 2));
+                   bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3]; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[j] = b[(ci * 8 + 4 * h + j) * BN + rb_];
+        }
+    };
+    auto mm = [&](float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
+    };
+    auto wait_next = [&](bool more) __attribute__((always_inline)) {      // next stage landed; later one may fly
+        if (more) { if (NPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    else          asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }
+        else        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    if (nst > 0) issue(0, 0);
+    if (nst > 1) issue(1, 1);
+    wait_next(nst > 1);
+
+    // Software pipeline: the operands of chunk c+1 are read BEFORE the MFMAs of chunk c are issued,
+    // and the MFMAs of a stage's last chunk are issued after the barrier, behind the first reads of
+    // the next stage - the matrix pipe never waits on an LDS round trip.
+    float ca[4], cb[4];
+    if (nst > 0) rd(lds, lds + BM * BK, c0, ca, cb);
+    int buf = 0;
+    for (int kt = 0; kt < nst; kt++) {
+        int nb = buf + 2; if (nb >= 3) nb -= 3;
+        int b1 = buf + 1; if (b1 >= 3) b1 = 0;
+        if (kt + 2 < nst) issue(kt + 2, nb);                // overwrites the buffer read in stage kt-1
+        const float *a = lds + buf * STAGE, *b = a + BM * BK;
+#pragma unroll
+        for (int ci = 0; ci + 1 < NCG; ci++) {
+            float na[4], nbv[4];
+            rd(a, b, c0 + ci + 1, na, nbv);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
+        }
+        wait_next(kt + 2 < nst);                            // all my reads of stage kt done; stage kt+1 visible
+        float na[4], nbv[4];
+        if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, c0, na, nbv);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ca, cb);
+        if (kt + 1 < nst) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
+        }
+        buf = b1;
+    }
+
+    const float alpha = p.alpha, beta = p.beta;
+    const int gn = n0 + wn * 32 + l31;
+    float add[16];
+    // the two k-groups meet in LDS (the stage buffers are free now): group 1 parks its 32x32 blocks, group 0 adds them
+    __syncthreads();
+    if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[(w4 * 16 + r) * 64 + lane] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) add[r] = lds[(w4 * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = (acc0[r] + acc1[r]) + add[r];
         if (p.nsplit > 1) p.part[((long)blockIdx.y * M + gm) * N + gn] = v;
         else {
             const long z = (long)gm * N + gn;
@@ -489,6 +686,23 @@ void launch_glds(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
     else if (!tA)   hipLaunchKernelGGL((k_gemm_glds<BK, true,  true>),  grid, dim3(256), lds_bytes, s, p);
     else if (!tB)   hipLaunchKernelGGL((k_gemm_glds<BK, false, false>), grid, dim3(256), lds_bytes, s, p);
     else            hipLaunchKernelGGL((k_gemm_glds<BK, false, true>),  grid, dim3(256), lds_bytes, s, p);
+}
+
+template <int BK>
+void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)3 * 128 * BK * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, true, false>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, true, true>),   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, false, true>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_done = true;
+    }
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm_glds8<BK, true,  false>), grid, dim3(512), lds_bytes, s, p);
+    else if (!tA)   hipLaunchKernelGGL((k_gemm_glds8<BK, true,  true>),  grid, dim3(512), lds_bytes, s, p);
+    else if (!tB)   hipLaunchKernelGGL((k_gemm_glds8<BK, false, false>), grid, dim3(512), lds_bytes, s, p);
+    else            hipLaunchKernelGGL((k_gemm_glds8<BK, false, true>),  grid, dim3(512), lds_bytes, s, p);
 }
 
 // fold split-K slabs in slice order, then the alpha/beta epilogue (reference t4math.cu:580)
@@ -536,9 +750,9 @@ void launch_variant(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
     else            launch_one<BM, BN, BK, false, true,  VEC, SKEW, FULL>(p, grid, s);
 }
 
-int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 = BK64, bit1 = SKEW, bit2 = LDS-DMA pipeline (default 5)
+int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 = BK64, bit1 = SKEW, bit2 = LDS-DMA pipeline, bit3 = pair mode, bit4 = 8-wave workgroups (default 21)
     static int v = -1;
-    if (v < 0) { const char *e = getenv("T4K_GEMM_VARIANT"); v = e ? atoi(e) : 5; }
+    if (v < 0) { const char *e = getenv("T4K_GEMM_VARIANT"); v = e ? atoi(e) : 21; }
     return v;
 }
 
@@ -572,11 +786,18 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             if ((size_t)nsplit * M * N * sizeof(float) > st().ws_bytes / 2) { nsplit = 1; kchunk = ((K + KG - 1) / KG) * KG; }
         }
     }
+    const int var = gemm_variant();
+    // pair mode (variant bit 3): an interior 64x64-tiled problem that gives each CU at most one workgroup is split in
+    // two K halves combined in the epilogue => 2 workgroups (8 waves) per CU hide each other's LDS / barrier stalls
+    p.pair = 0; p.sync = st().d_sync;
+    if (!big && vec && nsplit == 1 && C == 1 && (var & 4) && (var & 8) && p.sync && tiles <= st().cu_count && tiles <= 2048 &&
+        M % 64 == 0 && N % 64 == 0 && K % 128 == 0 && K >= 256 && (size_t)tiles * 4096 * sizeof(float) <= st().ws_bytes / 2) {
+        p.pair = 1; nsplit = 2; kchunk = K / 2;
+    }
     p.kchunk = kchunk; p.nsplit = nsplit;
 
     dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)C);
     hipStream_t hs = S(s);
-    const int var = gemm_variant();
     if (big) {
         const bool full = vec && M % 128 == 0 && N % 128 == 0 && kchunk % 32 == 0 && K % kchunk == 0;
         if (full)     launch_variant<128, 128, 32, true, true, true>(p, grid, tA, tB, hs);
@@ -587,7 +808,8 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     } else {
         const bool full = M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
         if (full && (var & 4)) {
-            if (var & 1) launch_glds<64>(p, grid, tA, tB, hs); else launch_glds<32>(p, grid, tA, tB, hs);
+            if ((var & 16) && !p.pair) { if (var & 1) launch_glds8<64>(p, grid, tA, tB, hs); else launch_glds8<32>(p, grid, tA, tB, hs); }
+            else if ((var & 1) && !p.pair) launch_glds<64>(p, grid, tA, tB, hs); else launch_glds<32>(p, grid, tA, tB, hs);   // pair: 2 x 48 KiB LDS per CU
         } else if (full) {
             switch (var & 3) {
             case 0:  launch_variant<64, 64, 32, true, false, true>(p, grid, tA, tB, hs); break;
@@ -597,7 +819,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             }
         } else launch_variant<64, 64, 64, true, true, false>(p, grid, tA, tB, hs);
     }
-    if (nsplit > 1) {
+    if (nsplit > 1 && !p.pair) {
         const long mn = (long)M * N;
         hipLaunchKernelGGL(k_splitk_fold, dim3(grid_for(mn)), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N);
     }

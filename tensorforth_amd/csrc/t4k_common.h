@@ -23,6 +23,7 @@ struct State {
                                        //   RNG state lives in HBM so a captured graph draws fresh numbers on every replay.
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
+    int        *d_sync  = nullptr;     // 4096 zeroed ints: tile tickets / flags of the pair-mode GEMM epilogue
     int         cu_count = 256;
     char        err[256] = {0};
 };
