@@ -4,7 +4,11 @@
 # ten4_oracle still reproduces these files and (on the GPU) that the HIP-backed `ten4` matches them.
 cd "$(dirname "$0")/../../.." || exit 1
 make -C oracle ten4_oracle >/dev/null || exit 1
+ROOT=$(pwd)
+WORK=$(mktemp -d)                       # the dataset words read ./data/MNIST/raw relative to the working directory
+python3 tools/make_synth_mnist.py "$WORK/data/MNIST/raw" 1024 256 >/dev/null || exit 1
 for s in tests/scripts/*.4th; do
     n=$(basename "$s" .4th)
-    T4_SEED=1 oracle/ten4_oracle < "$s" > "tests/golden/vm/$n.out" || exit 1
+    (cd "$WORK" && T4_SEED=1 "$ROOT/oracle/ten4_oracle" < "$ROOT/$s" > "$ROOT/tests/golden/vm/$n.out") || exit 1
 done
+rm -rf "$WORK"

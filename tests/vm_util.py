@@ -18,14 +18,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "vm")
 _NUM = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)(e[+-]?\d+)?$|^[+-]?nan$|^[+-]?inf$", re.I)
 
 
-def run_vm(binary, script_path=None, source=None, seed=1, timeout=300, env_extra=None):
+def run_vm(binary, script_path=None, source=None, seed=1, timeout=300, env_extra=None, cwd=None):
     if source is None:
         with open(script_path) as f:
             source = f.read()
     env = dict(os.environ, T4_SEED=str(seed))
     if env_extra:
         env.update(env_extra)
-    r = subprocess.run([binary], input=source, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    r = subprocess.run([binary], input=source, capture_output=True, text=True, timeout=timeout, env=env, cwd=cwd or ROOT)
     assert r.returncode == 0, f"{binary} rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
     return r.stdout
 
@@ -73,3 +73,11 @@ def numbers_after(text, label, count):
             if len(vals) == count:
                 break
     return vals
+
+
+def synth_mnist_dir(tmp_path_factory):
+    """Working directory holding ./data/MNIST/raw with the synthetic MNIST-shaped corpus (seed 42)."""
+    d = tmp_path_factory.mktemp("t4data")
+    subprocess.run(["python3", os.path.join(ROOT, "tools", "make_synth_mnist.py"), os.path.join(str(d), "data", "MNIST", "raw"), "1024", "256"],
+                   check=True, capture_output=True)
+    return str(d)
