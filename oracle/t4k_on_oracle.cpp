@@ -126,6 +126,10 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int
     memset(Y, 0, sizeof(float) * (size_t)N * E0);
     return t4o_linear_fwd(X, W, B, Y, N, E0, E1);
 }
+int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, t4k_stream_t st) {
+    int r = t4k_linear_fwd(X, W, B, Y, N, E0, E1, st); if (r) return r;
+    return t4o_softmax(Y, P, N, E0);
+}
 int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t) {
     float *dx = DX;                                     // product contract: DX == NULL -> dW|dB only, DW == NULL -> dX only
     if (!dx) dx = (float *)calloc((size_t)N * E1, sizeof(float));

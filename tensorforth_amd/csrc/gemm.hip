@@ -829,7 +829,13 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
 
 } // namespace
 
-namespace t4k { int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs); }
+namespace t4k {
+int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
+// linear_small.hip: classifier-head sized layers on the vector ALUs, one launch each way
+bool linear_small_ok(int E0, int E1);
+int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs);
+bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, bool train, hipStream_t hs);
+}
 
 extern "C" {
 
@@ -842,13 +848,25 @@ int t4k_gemm(const float *A, const float *B, float *O, float alpha, float beta,
 // Model::_flinear src/nn/forward.cu:157-198: Y[N,E0] = X[N,E1] @ W[E0,E1]^T + B[E0], bias fused
 int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int N, int E0, int E1, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
+    if (!X || !W || !Y || N < 0) return fail(T4K_ERR_ARG, "t4k_linear_fwd: bad argument");
+    if (N > 0 && linear_small_ok(E0, E1)) { linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s)); T4K_LAUNCH_CHECK(); return T4K_OK; }
     return gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s);
+}
+// linear followed by a softmax layer: Y = X W^T + b, P = softmax(Y); one launch when the head is small
+int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X || !W || !Y || !P || N < 0) return fail(T4K_ERR_ARG, "t4k_linear_softmax_fwd: bad argument");
+    if (N == 0) return T4K_OK;
+    if (linear_small_ok(E0, E1)) { linear_small_fwd(X, W, B, Y, P, N, E0, E1, S(s)); T4K_LAUNCH_CHECK(); return T4K_OK; }
+    int rc = gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s); if (rc) return rc;
+    return t4k_softmax(Y, P, N, E0, s);
 }
 // Model::_blinear src/nn/backprop.cu:193-254
 int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
                    int N, int E0, int E1, int train, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if ((DW == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_linear_bwd: DW and DB go together");
+    if (N > 0 && linear_small_ok(E0, E1) && linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, S(s))) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (train && DW) {                                  // DW == NULL: dX only (the caller forks dW|dB to another stream)
         int rc = colsum_add(DY, DB, N, E0, S(s)); if (rc) return rc;              // dB += sum_n dY
         rc = gemm_launch(DY, X, DW, nullptr, 1.0f, 1.0f, 1, 0, E0, E1, N, 1, s);  // dW += dY^T @ X

@@ -1,0 +1,203 @@
+// linear_small.hip - classifier-head sized linear layers (E0 <= 64 outputs, E1 <= 512 inputs) on the vector ALUs.
+//
+// A 100->10 layer on a batch of 128 is 0.26 MFLOP: as an MFMA GEMM it costs three latency-bound launches backward
+// (column sum, dW, dX) and two forward (GEMM, softmax), ~5 us each.  Here it is one launch each way:
+//   forward  Y = X W^T + b, and - when the next layer is a softmax - P = softmax(Y) from the same registers;
+//   backward dB += sum_n dY, dW += dY^T X, dX = dY W.  The reference writes dX over X (backprop.cu:240), so the
+//            dX workgroups compute first, then wait on an arrival counter until every dW workgroup has finished
+//            reading X, and only then store (all workgroups are co-resident: grid <= CU count).
+// Every dot product is one fmaf chain in ascending k, i.e. bit-identical to the CPU oracle's GEMM; the softmax uses
+// the same max-shift / __expf / xor-tree as k_softmax (reduce.hip).  Reference: _flinear forward.cu:157-198,
+// _blinear backprop.cu:193-254, k_softmax nmath.cu:74-169.
+#include "t4k_common.h"
+#include <float.h>
+
+using namespace t4k;
+
+namespace {
+
+constexpr int LS_MAX_FLOATS = 12288;          // 48 KiB of dynamic LDS
+
+// rows per wave = 64 / LG, lanes of a group = output index e0
+template <int LG>
+__global__ void __launch_bounds__(256) k_linsmall_fwd(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ B,
+                                                      float *__restrict__ Y, float *__restrict__ P, int N, int E0, int E1) {
+    extern __shared__ float sm[];
+    constexpr int RPW = 64 / LG, RPB = 4 * RPW;
+    const int ldw = E1 + 1;                                      // odd-ish stride: lanes (= rows of W) hit different banks
+    float *Ws = sm, *Xs = sm + E0 * ldw;
+    const int tid = threadIdx.x;
+    for (int r = tid / 64; r < E0; r += 4)                       // one wave per row of W: coalesced reads
+        for (int k = tid & 63; k < E1; k += 64) Ws[r * ldw + k] = W[(long)r * E1 + k];
+    const int row0 = blockIdx.x * RPB;
+    for (int r = tid / 64; r < RPB; r += 4) {
+        const int n = row0 + r;
+        for (int k = tid & 63; k < E1; k += 64) Xs[r * E1 + k] = n < N ? X[(long)n * E1 + k] : 0.f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6, e0 = lane % LG, rloc = w * RPW + lane / LG, n = row0 + rloc;
+    const bool live = e0 < E0 && n < N;
+    float acc = 0.f;
+    if (live) {
+        const float *xs = Xs + rloc * E1, *ws = Ws + e0 * ldw;
+        for (int k = 0; k < E1; k++) acc = fmaf(xs[k], ws[k], acc);
+        acc += B ? B[e0] : 0.f;
+        Y[(long)n * E0 + e0] = acc;
+    }
+    if (P) {                                                     // softmax over the LG lanes of this row
+        float mx = live ? acc : -FLT_MAX;
+#pragma unroll
+        for (int off = LG / 2; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float e = live ? __expf(acc - mx) : 0.f;
+        float s = e;
+#pragma unroll
+        for (int off = LG / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (live) P[(long)n * E0 + e0] = e / s;
+    }
+}
+
+// blocks [0, nB): dW | dB for output row e0 = blockIdx.x; blocks [nB, nB+nA): dX for RA rows each
+__global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const float *__restrict__ W, const float *__restrict__ DY,
+                                                      float *DX, float *DW, float *DB, int N, int E0, int E1,
+                                                      int nB, int nA, int RA, int *sync, int alias) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < nB) {
+        // one output row e0 per workgroup: CL lanes cover the E1 + 1 columns (column E1 = bias gradient), the 256 / CL
+        // lane groups split the batch; all loads of a trip are independent (16 rows in flight), partial sums meet in LDS
+        const int e0 = blockIdx.x;
+        int CL = 32; while (CL < E1 + 1 && CL < 256) CL <<= 1;
+        const int NG = 256 / CL, c0 = tid % CL, ng = tid / CL;
+        float *dys = sm;                                         // dY[:, e0] for the whole batch
+        for (int n = tid; n < N; n += 256) dys[n] = DY[(long)n * E0 + e0];
+        __syncthreads();
+        float acc[3] = {0.f, 0.f, 0.f};                          // columns c0, c0 + 256, c0 + 512 when E1 + 1 > 256
+#pragma unroll 1
+        for (int nb = ng; nb < N; nb += NG * 16) {
+            float xv[16][3]; float dv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int n = nb + u * NG;
+                const bool ok = n < N;
+                dv[u] = ok ? dys[n] : 0.f;
+                const float *xr = X + (long)(ok ? n : 0) * E1;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int c = c0 + q * 256;
+                    xv[u][q] = (q == 0 || CL == 256) ? (c < E1 ? xr[c] : 1.f) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) acc[q] = fmaf(dv[u], xv[u][q], acc[q]);
+        }
+        __syncthreads();
+        if (alias && tid == 0) __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // X fully consumed
+        float *red = sm + N;                                     // [NG][CL][3]
+        if (NG > 1) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) red[(ng * CL + c0) * 3 + q] = acc[q];
+            __syncthreads();
+            if (ng == 0)
+                for (int g2 = 1; g2 < NG; g2++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) acc[q] += red[(g2 * CL + c0) * 3 + q];
+        }
+        if (ng == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int c = c0 + q * 256;
+                if (q > 0 && CL < 256) break;
+                if (c < E1) DW[(long)e0 * E1 + c] += acc[q];
+                else if (c == E1) DB[e0] += acc[q];
+            }
+        }
+        return;
+    }
+    // ---- dX[n, e1] = sum_e0 dY[n, e0] * W[e0, e1]
+    float *Ws = sm, *Ds = sm + E0 * E1;                          // W verbatim, then RA rows of dY
+    for (int e = tid; e < E0 * E1; e += 256) Ws[e] = W[e];
+    const int row0 = ((int)blockIdx.x - nB) * RA;
+    for (int e = tid; e < RA * E0; e += 256) { const int n = row0 + e / E0; Ds[e] = n < N ? DY[(long)n * E0 + e % E0] : 0.f; }
+    __syncthreads();
+    const int total = RA * E1;
+    float out[4];                                                // RA * E1 <= 1024 outputs per block
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int z = tid + q * 256;
+        float acc = 0.f;
+        if (z < total) {
+            const int r = z / E1, c = z - r * E1;
+            for (int e0 = 0; e0 < E0; e0++) acc = fmaf(Ds[r * E0 + e0], Ws[e0 * E1 + c], acc);
+        }
+        out[q] = acc;
+    }
+    if (alias) {                                                 // DX overwrites X: wait until every dW workgroup is done reading it
+        if (tid == 0) while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nB) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int z = tid + q * 256;
+        if (z < total) { const int r = z / E1, n = row0 + r; if (n < N) DX[(long)n * E1 + (z - r * E1)] = out[q]; }
+    }
+    if (alias) {                                                 // last dX workgroup re-arms the counters for the next launch
+        __syncthreads();
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == nA - 1) {
+                __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+} // namespace
+
+namespace t4k {
+
+bool linear_small_ok(int E0, int E1) {
+    return E0 >= 1 && E0 <= 64 && E1 >= 1 && E1 <= 512 && E0 * (E1 + 1) + 16 * E1 <= LS_MAX_FLOATS && E0 * E1 + 64 * E0 <= LS_MAX_FLOATS;
+}
+
+int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs) {
+    const int LG = E0 <= 16 ? 16 : (E0 <= 32 ? 32 : 64);
+    const int RPB = 4 * (64 / LG);
+    const size_t lds = sizeof(float) * (size_t)(E0 * (E1 + 1) + RPB * E1);
+    const dim3 g((N + RPB - 1) / RPB), b(256);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_fwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_fwd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_fwd<64>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4);
+        attr = true;
+    }
+    if (LG == 16)      hipLaunchKernelGGL(k_linsmall_fwd<16>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1);
+    else if (LG == 32) hipLaunchKernelGGL(k_linsmall_fwd<32>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1);
+    else               hipLaunchKernelGGL(k_linsmall_fwd<64>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1);
+    return T4K_OK;
+}
+
+// returns false when the shape does not qualify (caller falls back to the GEMM path)
+bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
+                      int N, int E0, int E1, bool train, hipStream_t hs) {
+    const int nB = (train && DW) ? E0 : 0;
+    int RA = 1024 / E1; if (RA > 64) RA = 64; if (RA < 1) RA = 1;        // rows of dX per workgroup (<= 1024 outputs, <= 64 rows of dY in LDS)
+    const int nA = DX ? (N + RA - 1) / RA : 0;
+    if (nA + nB == 0) return true;
+    const bool alias = DX && nB > 0 && (const float *)DX == X;
+    State &g = st();
+    if (alias && (nA + nB > g.cu_count || !g.d_sync)) return false;       // the arrival counter needs every workgroup resident
+    size_t lds = sizeof(float) * (size_t)(E0 * E1 + RA * E0);
+    if (nB > 0 && sizeof(float) * (size_t)(N + 768) > lds) lds = sizeof(float) * (size_t)(N + 768);
+    if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, g.d_sync + 4090, alias ? 1 : 0);
+    return true;
+}
+
+} // namespace t4k

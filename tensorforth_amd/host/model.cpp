@@ -116,7 +116,6 @@ void Model::finalize() {                                // gradient slab: SURVEY
     for (int i = 0; i + 1 < (int)layer.size(); i++) {
         Tensor &in = at(i);
         if (in.grad_fn == T4K_L_LOGSMAX) capturable_ = false;               // host round trip inside the layer
-        if (in.grad_fn == T4K_L_BATCHNM) continue;                          // per-channel vectors stay where they are
         for (int k = 2; k < 4; k++) if (in.grad[k]) total += pad(in.grad[k]->numel);
         if (use_side && in.grad_fn == T4K_L_LINEAR && i + 2 < (int)layer.size()) gx_[i] = &T4(in.N(), in.H(), in.W(), in.C());
     }
@@ -125,7 +124,6 @@ void Model::finalize() {                                // gradient slab: SURVEY
         uint64_t off = 0;
         for (int i = 0; i + 1 < (int)layer.size(); i++) {
             Tensor &in = at(i);
-            if (in.grad_fn == T4K_L_BATCHNM) continue;
             for (int k = 2; k < 4; k++) {
                 Tensor *g = in.grad[k]; if (!g) continue;
                 chk(t4k_copy(g->data, slab->data + off, (long)g->numel, stream()), "slab");
@@ -249,6 +247,12 @@ void Model::run_forward(Tensor &input) {
             chk(t4k_poolblock_fwd(x, &r.blk, in.N(), pin.H(), pin.W(), r.blk.pool_layer ? at(i + (r.blk.pre_layer ? 2 : 1)).H() : pin.H(),
                                   r.blk.pool_layer ? at(i + (r.blk.pre_layer ? 2 : 1)).W() : pin.W(), pin.C(), stream()), "nn#frun");
             x = lastt.data; i += r.count - 1;
+            continue;
+        }
+        if (fused && in.grad_fn == T4K_L_LINEAR && i + 2 < L && out.grad_fn == T4K_L_SOFTMAX) {     // classifier head: linear + softmax in one launch
+            Tensor &prob = at(i + 2);
+            chk(t4k_linear_softmax_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, prob.data, out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+softmax");
+            x = prob.data; i++;
             continue;
         }
         x = fstep(in, out, x);

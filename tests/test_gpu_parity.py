@@ -498,3 +498,36 @@ def test_poolblock_matches_unfused_oracle(t4k, dev, oracle, pre, pool, post, fla
     for k_ in ("pre_out", "pool_out", "post_out"):
         if k_ in bufs and not (k_ == last and not flat):
             assert rel(dev.down(d[k_]).reshape(bufs[k_].shape), bufs[k_]) < 1e-6, "bwd " + k_
+
+
+@pytest.mark.parametrize("N,E0,E1", [(128, 10, 100), (7, 3, 17), (256, 1, 256), (64, 40, 200), (33, 48, 130)])
+def test_small_linear_head_is_bit_identical_to_oracle(t4k, dev, oracle, N, E0, E1):
+    """Classifier-head path (linear_small.hip): fmaf chains in ascending k, the oracle's order => exact equality
+    for Y and dX (dX written over X, as the host does); dW, dB (batch split over lane groups) and the fused softmax within 1e-6."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N * 3 + E0)
+    X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(E0).astype(np.float32)
+    Y = np.zeros((N, E0), np.float32); o.t4o_linear_fwd(P(X), P(W), P(b), P(Y), N, E0, E1)
+    Pr = np.zeros_like(Y); o.t4o_softmax(P(Y), P(Pr), N, E0)
+    dX, dW, db, dY, dP = dev.up(X), dev.up(W), dev.up(b), dev.zeros((N, E0)), dev.zeros((N, E0))
+    t4k.call("t4k_linear_softmax_fwd", p(dX), p(dW), p(db), p(dY), p(dP), N, E0, E1, None)
+    assert np.array_equal(dev.down(dY), Y)
+    assert rel(dev.down(dP), Pr) < 1e-6
+    G = rng.standard_normal((N, E0)).astype(np.float32)
+    DW = rng.standard_normal((E0, E1)).astype(np.float32); DB = rng.standard_normal(E0).astype(np.float32)
+    DX = np.zeros_like(X)
+    dG, dDW, dDB = dev.up(G), dev.up(DW), dev.up(DB)
+    o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)
+    t4k.call("t4k_linear_bwd", p(dX), p(dW), p(dG), p(dX), p(dDW), p(dDB), N, E0, E1, 1, None)
+    assert np.array_equal(dev.down(dX), DX) and rel(dev.down(dDW), DW) < 1e-6 and rel(dev.down(dDB), DB) < RTOL
+    # second launch on fresh buffers (counter re-armed), separate DX buffer (no aliasing)
+    dXb, dDXb = dev.up(X), dev.zeros(X.shape)
+    DW2 = np.zeros((E0, E1), np.float32); DB2 = np.zeros(E0, np.float32); DXb = np.zeros_like(X)
+    o.t4o_linear_bwd(P(X), P(W), P(G), P(DXb), P(DW2), P(DB2), N, E0, E1, 1)
+    dDW2, dDB2 = dev.zeros((E0, E1)), dev.zeros(E0)
+    t4k.call("t4k_linear_bwd", p(dXb), p(dW), p(dG), p(dDXb), p(dDW2), p(dDB2), N, E0, E1, 1, None)
+    assert np.array_equal(dev.down(dDXb), DXb) and rel(dev.down(dDW2), DW2) < 1e-6 and rel(dev.down(dDB2), DB2) < RTOL
+    dXc = dev.up(X)
+    t4k.call("t4k_linear_bwd", p(dXc), p(dW), p(dG), p(dXc), p(dDW2), p(dDB2), N, E0, E1, 1, None)   # aliasing again
+    assert np.array_equal(dev.down(dXc), DX)
