@@ -77,17 +77,46 @@ def main():
         ": steps ( N n -- N ) 1- for fb opt next ;\n"
         "net 2 steps\n" % (N, N, rank, N * 10, N))
     assert "?" not in out_txt.replace("-> ok", ""), out_txt
-    slab = vm.grad_slab() if dp else None
-    vstream = vm.stream() if dp else None
+    # ---- data parallel: the VM owns an RCCL communicator (t4k_comm_*) and sums its gradient slab in-order on its own
+    # stream inside `nn.sgd`, so the training loop stays inside the VM exactly as on one GPU.  torch.distributed only
+    # carries the 128-byte communicator id to the ranks (and the barrier / max-time reduction of the bench contract).
+    native = False
+    if dp and os.environ.get("T4_DP_NATIVE", "1") == "1":
+        idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        ok = torch.ones(1, device="cuda")
+        if rank == 0:
+            raw = (ctypes.c_ubyte * 128)()
+            if k.lib.t4k_comm_unique_id(raw) == 0:
+                idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+            else:
+                ok.zero_()
+        dist.broadcast(idbuf, 0); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            raw = (ctypes.c_ubyte * 128)(*idbuf.cpu().tolist())
+            good = torch.tensor([1.0 if k.lib.t4k_comm_init(raw, rank, world) == 0 else 0.0], device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            native = float(good.item()) > 0
+            if not native:
+                k.lib.t4k_comm_destroy()
+    slab = vm.grad_slab() if (dp and not native) else None
+    vstream = vm.stream() if (dp and not native) else None
+    reducer = None
+    if slab is not None and os.environ.get("T4_DP_OVERLAP", "0") == "1":   # torch path only: reduce the slab's tail under conv backprop
+        from tensorforth_amd.dp import OverlappedSlabReducer
+        reducer = OverlappedSlabReducer(slab, vstream)
+        vm.set_grad_hook(reducer.on_layer)
 
     def run(n):
-        if not dp:
-            vm.eval("%d steps" % n)                       # the whole loop runs inside the VM
+        if not dp or native:
+            vm.eval("%d steps" % n)                       # the whole loop runs inside the VM (all-reduce included when native)
             return
         for _ in range(n):
             vm.eval("fb")
-            with torch.cuda.stream(vstream):              # ordered with the VM's kernels; SUM: raw batch-sum gradients (quirk a-19)
-                dist.all_reduce(slab, op=dist.ReduceOp.SUM)
+            if reducer:
+                reducer.finish()                          # tail already in flight since mid-backprop
+            else:
+                with torch.cuda.stream(vstream):          # ordered with the VM's kernels; SUM: raw batch-sum gradients (quirk a-19)
+                    dist.all_reduce(slab, op=dist.ReduceOp.SUM)
             vm.eval("opt")
 
     def barrier():
@@ -120,7 +149,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
-                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)",
+                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
                        "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
@@ -176,6 +205,8 @@ def main():
                                    "gemm_1024_host_gflops": round(flops / gdt / 1e9, 2)}
         print(json.dumps(out), flush=True)
     if dp:
+        if native:
+            k.lib.t4k_comm_destroy()
         dist.barrier(); dist.destroy_process_group()
 
 

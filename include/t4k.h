@@ -93,6 +93,17 @@ int t4k_event_sync(t4k_event_t e);
 int t4k_event_elapsed_ms(t4k_event_t start, t4k_event_t stop, float *ms);
 int t4k_event_destroy(t4k_event_t e);
 
+/* ---------------------------------------------------------------- data-parallel exchange
+ * One process per GPU.  Rank 0 makes a 128-byte id, the launcher hands it to every rank (any side channel), each
+ * rank joins; afterwards t4k_allreduce_sum() sums a device buffer in place over all ranks on the given stream
+ * (RCCL over xGMI).  The host VM calls it on the model's gradient slab between `backprop` and the optimizer. */
+int t4k_comm_unique_id(void *id128);
+int t4k_comm_init(const void *id128, int rank, int world);
+int t4k_comm_world(void);                          /* 0 = no communicator */
+int t4k_comm_rank(void);
+int t4k_allreduce_sum(float *buf, long n, t4k_stream_t s);
+int t4k_comm_destroy(void);
+
 /* hipGraph capture of a launch sequence (replaces ~40 launch+sync pairs per training
  * step of the reference).  begin..end captures every t4k_* kernel call
  * issued on `s`; launch replays it. */

@@ -25,6 +25,12 @@ const char *ten4_output(ten4_vm *vm);
 int ten4_grad_slab(ten4_vm *vm, float **dev_ptr, long *n_floats);
 /* the stream every kernel of the VM is issued on (a hipStream_t) */
 void *ten4_stream(ten4_vm *vm);
+/* Called during `backprop`, on the calling thread, right after the kernels that complete one layer's dW|dB have been
+ * enqueued on the VM stream: `off`/`n` locate that layer's segment in the gradient slab (floats).  Layers finish in
+ * reverse order, so [off, slab end) is complete (stream-ordered) at each call - a data-parallel launcher can start
+ * all-reducing the tail of the slab while the earlier layers are still back-propagating.  NULL disables. */
+typedef void (*ten4_grad_hook_fn)(int layer, long off, long n, void *user);
+void ten4_set_grad_hook(ten4_vm *vm, ten4_grad_hook_fn fn, void *user);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,12 @@ int t4k_event_record(t4k_event_t, t4k_stream_t) { return T4K_OK; }
 int t4k_event_sync(t4k_event_t) { return T4K_OK; }
 int t4k_event_elapsed_ms(t4k_event_t, t4k_event_t, float *ms) { *ms = 0; return T4K_OK; }
 int t4k_event_destroy(t4k_event_t) { return T4K_OK; }
+int t4k_comm_unique_id(void *) { return T4K_ERR_UNSUPPORTED; }
+int t4k_comm_init(const void *, int, int) { return T4K_ERR_UNSUPPORTED; }
+int t4k_comm_world(void) { return 0; }
+int t4k_comm_rank(void) { return 0; }
+int t4k_allreduce_sum(float *, long, t4k_stream_t) { return T4K_OK; }
+int t4k_comm_destroy(void) { return T4K_OK; }
 int t4k_graph_begin(t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
 int t4k_graph_end(t4k_stream_t, t4k_graph_t *) { return T4K_ERR_UNSUPPORTED; }
 int t4k_graph_launch(t4k_graph_t, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }

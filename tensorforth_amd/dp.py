@@ -46,3 +46,44 @@ def allreduce_scalars(values, group=None, device=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.tolist()
+
+
+class OverlappedSlabReducer:
+    """Gradient all-reduce overlapped with backprop.
+
+    Layers finish their dW|dB in reverse order, and the slab is laid out in layer order, so the TAIL of the slab is
+    complete first - for CNNs that is the fully-connected part, i.e. almost all of the bytes (97 % for the LeNet
+    net).  `on_layer` is installed as the VM's gradient hook: as soon as the completed tail covers `tail_frac` of
+    the slab it is all-reduced on a side stream (ordered after the VM stream by an event) while the convolution
+    layers are still back-propagating; `finish()` reduces the small remaining head and makes the VM stream wait for
+    both, so the optimizer word that follows sees the summed gradients."""
+
+    def __init__(self, slab, vm_stream, group=None, tail_frac=0.5):
+        self.slab, self.vs, self.group, self.tail_frac = slab, vm_stream, group, tail_frac
+        self.side = torch.cuda.Stream(device=slab.device) if slab.is_cuda else None
+        self.cut = None                      # slab[cut:] already reducing
+
+    def on_layer(self, layer, off, n):
+        if self.cut is not None or (self.slab.numel() - off) < self.tail_frac * self.slab.numel():
+            return
+        self.cut = off
+        if self.side is None:                # CPU tensors (gloo tests): no streams
+            dist.all_reduce(self.slab[off:], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.vs)                   # everything backprop has enqueued so far
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(self.slab[off:], op=dist.ReduceOp.SUM, group=self.group)
+
+    def finish(self):
+        head = self.slab.numel() if self.cut is None else self.cut
+        if head > 0:
+            if self.side is None:
+                dist.all_reduce(self.slab[:head], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                with torch.cuda.stream(self.vs):
+                    dist.all_reduce(self.slab[:head], op=dist.ReduceOp.SUM, group=self.group)
+        if self.side is not None and self.cut is not None:
+            self.vs.wait_stream(self.side)
+        self.cut = None

@@ -31,5 +31,6 @@ int ten4_grad_slab(ten4_vm *, float **p, long *n) {
     return 0;
 }
 void *ten4_stream(ten4_vm *) { return (void *)t4k_default_stream(); }
+void ten4_set_grad_hook(ten4_vm *, ten4_grad_hook_fn fn, void *user) { t4::Model::grad_hook = fn; t4::Model::grad_hook_user = user; }
 
 } // extern "C"

@@ -97,6 +97,8 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
 // fastest schedule - 0.26 ms/step vs 0.28 (hipGraph replay) vs 0.31 (forked side stream; every cross-queue event edge
 // costs more than the ~4.5 us in-order dispatch it hides).  What pays is fewer launches (fused kernels below).
 Model *Model::current = nullptr;
+void (*Model::grad_hook)(int, long, long, void *) = nullptr;
+void *Model::grad_hook_user = nullptr;
 bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
 bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
@@ -407,6 +409,11 @@ void Model::run_backward(Tensor &tgt) {
             }
         }
         dy = bstep(i, in, o, dy, j == 0);
+        if (grad_hook && train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns) {
+            const long off = (long)(in.grad[2]->data - gslab->data);
+            const long end = (long)(in.grad[3]->data - gslab->data) + (long)((in.grad[3]->numel + 63) & ~(uint64_t)63);
+            grad_hook(i, off, end - off, grad_hook_user);
+        }
         if (trace && *trace && in.has_nan()) { printf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
     }
     join();
@@ -506,6 +513,9 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     if (!tab_dev || tab_kind != op) build_table(op);
     const int kind = (op == OPTI_ADAM) ? 1 : (op == OPTI_ADAMW ? 2 : 0);
     const float p[4] = { lr, b1, b2, wd };
+    // data parallel: every rank holds a shard of the batch; SUM the gradient slab (raw batch sums, quirk a-19) in-order
+    // on the VM stream right before the update, so N ranks x batch B reproduce one rank x batch N*B
+    if (gslab && t4k_comm_world() > 0) chk(t4k_allreduce_sum(gslab->data, (long)gslab->numel, stream()), "allreduce");
     if (!replay(g_opt_, tab_dev, (int)op, p)) {
         const bool cap = capturing_;
         chk(t4k_opt_multi(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_max, lr, b1, b2, wd, stream()), nm);

@@ -204,6 +204,11 @@ struct Model : Obj {
     // ---- data-parallel hook: all dW|dB of the model live back-to-back in one slab (one all-reduce)
     Tensor *gslab = nullptr;
     static Model *current;                     // model that ran forward/backprop last (embedding API)
+    // called from backprop right after the kernels that complete a layer's dW|dB have been enqueued: (layer, offset and
+    // length of that layer's segment in the gradient slab).  Lets a data-parallel launcher start reducing the tail of
+    // the slab (the big linear layers finish first) while the convolution layers are still back-propagating.
+    static void (*grad_hook)(int layer, long off, long n, void *user);
+    static void *grad_hook_user;
     void  finalize();                          // build the gradient slab + side stream (first forward / backprop)
     void  invalidate();                        // drop captured graphs (layers added, shapes changed)
     static bool use_graphs, use_side;          // T4_GRAPH=0 / T4_SIDE=0 switch them off (debugging)

@@ -40,6 +40,9 @@ class VM:
         so.ten4_grad_slab.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long)]
         so.ten4_stream.restype = ctypes.c_void_p
         so.ten4_stream.argtypes = [ctypes.c_void_p]
+        self._HOOK = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_void_p)
+        so.ten4_set_grad_hook.argtypes = [ctypes.c_void_p, self._HOOK, ctypes.c_void_p]
+        self._hook_ref = None
         self._h = so.ten4_new(device, seed, trace)
         if not self._h:
             raise RuntimeError("ten4_new failed: no MI355X visible (the VM has no CPU fallback)")
@@ -62,6 +65,12 @@ class VM:
     def stream(self):
         import torch
         return torch.cuda.ExternalStream(self._so.ten4_stream(self._h), device="cuda:%d" % self.device)
+
+    def set_grad_hook(self, fn):
+        """fn(layer, offset, n_floats) is called during `backprop` as each layer's slab segment becomes complete
+        (stream-ordered); None removes the hook."""
+        self._hook_ref = self._HOOK(lambda layer, off, n, _user: fn(layer, off, n)) if fn else self._HOOK(0)
+        self._so.ten4_set_grad_hook(self._h, self._hook_ref, None)
 
     def close(self):
         if self._h:

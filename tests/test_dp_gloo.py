@@ -52,11 +52,19 @@ def _worker(rank, world, port, out_dir):
     x, lab = _data()
     lo, hi = dp.shard_rows(GLOBAL_N, rank, world)
     m = _build(hi - lo)
-    for _ in range(2):
+    for it in range(2):
         m.forward(x[lo:hi]); m.onehot_labels(lab[lo:hi]); m.backprop()
         gs = _grads(m)
         slab = torch.from_numpy(np.concatenate([g.ravel() for g in gs]))          # the gradient slab
-        dp.allreduce_grad_slab(slab)
+        if it == 0:
+            dp.allreduce_grad_slab(slab)                                            # one collective after backprop
+        else:                                                                       # overlapped: tail first (as the VM's hook reports it), head last
+            red = dp.OverlappedSlabReducer(slab, None)
+            offs = np.cumsum([0] + [g.size for g in gs])
+            for k in range(len(gs) - 2, -1, -2):                                    # layers complete in reverse order: (dW, dB) pairs
+                red.on_layer(k // 2, int(offs[k]), int(offs[k + 2] - offs[k]))
+            assert red.cut is not None and 0 < red.cut < slab.numel()
+            red.finish()
         off = 0
         for g in gs:
             g[...] = slab[off:off + g.size].numpy().reshape(g.shape); off += g.size
