@@ -23,7 +23,7 @@ struct State {
                                        //   RNG state lives in HBM so a captured graph draws fresh numbers on every replay.
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
-    int        *d_sync  = nullptr;     // 4096 zeroed ints: tile tickets / flags of the pair-mode GEMM epilogue
+    int        *d_sync  = nullptr;     // 8192 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags + linear_small, [4096,8192) skinny split-K tickets
     int         cu_count = 256;
     char        err[256] = {0};
 };
