@@ -305,6 +305,199 @@ __global__ void __launch_bounds__(BLK) k_dpool(int layer, float *I, const float 
     }
 }
 
+// ------------------------------------------------------------------ forward / dX for few channels (Cin, Cout <= 32)
+// LeNet-class layers (1->10, 10->20 channels) are HBM/latency bound; padding 10 channels to the 32-wide MFMA tile and
+// gathering one float per MFMA wastes the matrix unit.  A thread owns one output pixel x G output channels (G = 4 or 12
+// accumulators; the channel group is uniform per workgroup, so filter reads are 16 B LDS broadcasts).  With < 1 wave per
+// SIMD there is nothing to hide a load behind, so per image row of taps the thread first issues ALL its input loads
+// (K taps x CH channels, unconditional: clamped address + select) and only then the FMAs: a 3x3x10 layer makes 6 memory
+// round trips per pixel instead of 45.  Outputs leave through an LDS transpose so every store instruction is contiguous.
+// The filter is staged once per workgroup as Wl[tap][ci][co] (taps flipped for dX, nmath.tcu:304-324).
+template <int K, int S, int P, bool BWD, int G, int CH, int VW>
+__global__ void __launch_bounds__(256) k_conv_few(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
+                                                  const float *__restrict__ F, const float *__restrict__ B,
+                                                  int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, int NG) {
+    __shared__ __attribute__((aligned(16))) float Wl[LDS_FILTER_FLOATS];
+    __shared__ float Os[256 * G];
+    constexpr int KK = K * K;
+    const int COPT = NG * G;
+    {
+        const int nF = (BWD ? Cout : Cin) * KK * C0f;
+        for (int e = threadIdx.x; e < KK * Cin * COPT; e += 256) Wl[e] = 0.f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nF; e += 256) {
+            const int c0 = e % C0f; const int r = e / C0f; const int t = r % KK; const int c1 = r / KK;   // F[c1][t][c0]
+            if (!BWD) Wl[(t * Cin + c1) * COPT + c0] = F[e];                  // ci = c1, co = c0
+            else      Wl[((KK - 1 - t) * Cin + c0) * COPT + c1] = F[e];       // ci = c0, co = c1, taps flipped
+        }
+        __syncthreads();
+    }
+    const int g = blockIdx.y, co0 = g * G;
+    const int gv = min(G, Cout - co0);                           // valid channels of this group
+    const long npix = (long)N * Hy * Wy;
+    for (long pix0 = (long)blockIdx.x * 256; pix0 < npix; pix0 += (long)gridDim.x * 256) {
+        const long pix = pix0 + threadIdx.x;
+        const bool live = pix < npix;
+        const long pc = live ? pix : 0;
+        const int x = (int)(pc % Wy); long tq = pc / Wy; const int y = (int)(tq % Hy); const int n = (int)(tq / Hy);
+        float acc[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) acc[u] = 0.f;
+        const float *nX = X + (long)n * Hx * Wx * Cin;
+#pragma unroll
+        for (int ky = 0; ky < K; ky++) {
+            int gi; bool iok;
+            if (!BWD) { gi = y * S + ky - P; iok = gi >= 0 && gi < Hx; }
+            else { const int ti = y + P - ky; gi = ti / S; iok = ti >= 0 && (ti % S) == 0 && gi < Hx; }
+            const float *d[K]; bool ok[K];
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) {
+                int gj; bool jok;
+                if (!BWD) { gj = x * S + kx - P; jok = gj >= 0 && gj < Wx; }
+                else { const int tj = x + P - kx; gj = tj / S; jok = tj >= 0 && (tj % S) == 0 && gj < Wx; }
+                ok[kx] = live && iok && jok;
+                d[kx] = nX + (ok[kx] ? ((long)gi * Wx + gj) * Cin : 0);
+            }
+            for (int ci0 = 0; ci0 < Cin; ci0 += CH) {
+                float v[K][CH];
+#pragma unroll
+                for (int kx = 0; kx < K; kx++)
+#pragma unroll
+                    for (int q = 0; q < CH; q += VW) {
+                        const int ci = (ci0 + q < Cin) ? ci0 + q : 0;          // clamped: the load is unconditional
+                        if (VW == 4)      { const float4 t4 = *reinterpret_cast<const float4 *>(d[kx] + ci); v[kx][q] = t4.x; v[kx][(q + 1) % CH] = t4.y; v[kx][(q + 2) % CH] = t4.z; v[kx][(q + 3) % CH] = t4.w; }
+                        else if (VW == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(d[kx] + ci); v[kx][q] = t2.x; v[kx][(q + 1) % CH] = t2.y; }
+                        else              v[kx][q] = d[kx][ci];
+                    }
+#pragma unroll
+                for (int kx = 0; kx < K; kx++)
+#pragma unroll
+                    for (int q = 0; q < CH; q++) {
+                        const float xv = (ok[kx] && ci0 + q < Cin) ? v[kx][q] : 0.f;
+                        const float *wq = Wl + (((ky * K + kx) * Cin) + min(ci0 + q, Cin - 1)) * COPT + co0;
+#pragma unroll
+                        for (int u4 = 0; u4 < G; u4 += 4) {
+                            const float4 f4 = *reinterpret_cast<const float4 *>(wq + u4);
+                            acc[u4] = fmaf(xv, f4.x, acc[u4]); acc[u4 + 1] = fmaf(xv, f4.y, acc[u4 + 1]);
+                            acc[u4 + 2] = fmaf(xv, f4.z, acc[u4 + 2]); acc[u4 + 3] = fmaf(xv, f4.w, acc[u4 + 3]);
+                        }
+                    }
+            }
+        }
+        // transpose through LDS: the workgroup's 256 x gv results leave as contiguous runs
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < G; u++) Os[threadIdx.x * G + u] = acc[u] + ((!BWD && B && co0 + u < Cout) ? B[co0 + u] : 0.f);
+        __syncthreads();
+        const int nval = (int)min((long)256, npix - pix0) * gv;
+        for (int e = threadIdx.x; e < nval; e += 256) {
+            const int pp = e / gv, u = e - pp * gv;
+            const float r = Os[pp * G + u];
+            const long o = (pix0 + pp) * Cout + co0 + u;
+            Y[o] = r; if (Y2) Y2[o] = r;
+        }
+    }
+}
+bool conv_few_ok(int K, int Cin, int Cout, int *G_out, int *NG_out) {
+    // measured on MI355X: wins for image-input layers (1->10: 6.1 vs 8.4 us); at 10<->20 channels the thread-per-pixel
+    // kernel is FMA/LDS bound with < 1 wave per SIMD and loses to the MFMA implicit GEMM (13.9 vs 10.3 us)
+    if (Cin > 4 || Cout > 32 || (K != 3 && K != 5)) return false;
+    const int G = Cout <= 4 ? 4 : 12;
+    const int NG = (Cout + G - 1) / G;
+    if (K * K * Cin * NG * G > LDS_FILTER_FLOATS) return false;
+    *G_out = G; *NG_out = NG;
+    return true;
+}
+template <bool BWD, int G, int CH, int VW>
+void launch_conv_few3(int K, dim3 g, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
+                      int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, int NG) {
+    const dim3 b(256);
+    if (K == 3) hipLaunchKernelGGL((k_conv_few<3, 1, 1, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
+    else        hipLaunchKernelGGL((k_conv_few<5, 1, 2, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
+}
+template <bool BWD>
+void launch_conv_few(int K, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
+                     int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, int G, int NG) {
+    const long npix = (long)N * Hy * Wy;
+    long gx = (npix + 255) / 256; if (gx > 8192) gx = 8192;
+    const dim3 g((unsigned)gx, (unsigned)NG);
+    const bool v2 = (Cin & 1) == 0 && (((uintptr_t)X) & 7) == 0;
+#define FEW(GG) do { if (Cin == 1)      launch_conv_few3<BWD, GG, 1, 1>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
+                     else if (Cin <= 4) { if (v2) launch_conv_few3<BWD, GG, 4, 2>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
+                                          else    launch_conv_few3<BWD, GG, 4, 1>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); } \
+                     else               { if (v2) launch_conv_few3<BWD, GG, 8, 2>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
+                                          else    launch_conv_few3<BWD, GG, 8, 1>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); } } while (0)
+    if (G == 4) FEW(4); else FEW(12);
+#undef FEW
+}
+
+// ------------------------------------------------------------------ dX for very few input channels (C1 <= 4)
+// The first layer of an image net has 1 (MNIST) or 3 (CIFAR) input channels: as an implicit GEMM its dX would use 1/32
+// of the matrix unit's N dimension and gather one float per MFMA.  Here a thread owns one pixel of the input grid and its
+// CO accumulators, reads the C0 contiguous gradients of each tap's output pixel (adjacent lanes = adjacent pixels, so a
+// wave streams a contiguous span of dO) and takes the flipped filter (nmath.tcu:304-324) from LDS at a wave-uniform address.
+template <int K, int S, int P, int CO>
+__global__ void __launch_bounds__(256) k_conv_dx_few(const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2,
+                                                     const float *__restrict__ F, int N, int H0, int W0, int C0, int H1, int W1) {
+    __shared__ float Fl[LDS_FILTER_FLOATS];
+    const int nF = CO * K * K * C0;
+    for (int e = threadIdx.x; e < nF; e += 256) Fl[e] = F[e];
+    __syncthreads();
+    const long npix = (long)N * H1 * W1;
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
+        const int x = (int)(pix % W1); long t = pix / W1; const int y = (int)(t % H1); const int n = (int)(t / H1);
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; c++) acc[c] = 0.f;
+        const float *nD = DO + (long)n * H0 * W0 * C0;
+#pragma unroll
+        for (int ky = 0; ky < K; ky++) {
+            const int ti = y + P - ky, gi = ti / S;
+            const bool iok = ti >= 0 && (ti % S) == 0 && gi < H0;
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) {
+                const int tj = x + P - kx, gj = tj / S;
+                const bool ok = iok && tj >= 0 && (tj % S) == 0 && gj < W0;
+                const float *d = nD + (ok ? ((long)gi * W0 + gj) * C0 : 0);
+                const float *f = Fl + ((K - 1 - ky) * K + (K - 1 - kx)) * C0;     // F[c1][K-1-ky][K-1-kx][c0]
+                const float msk = ok ? 1.f : 0.f;                 // loads are unconditional (clamped pixel), masked by a multiply-free select
+                if ((C0 & 1) == 0) {                              // even channel count: 8 B loads (pixel rows are 8 B aligned)
+#pragma unroll 5
+                    for (int c0 = 0; c0 < C0; c0 += 2) {
+                        const float2 v2 = *reinterpret_cast<const float2 *>(d + c0);
+                        const float v0 = ok ? v2.x : 0.f, v1 = ok ? v2.y : 0.f;
+#pragma unroll
+                        for (int c = 0; c < CO; c++) { acc[c] = fmaf(v0, f[c * K * K * C0 + c0], acc[c]); acc[c] = fmaf(v1, f[c * K * K * C0 + c0 + 1], acc[c]); }
+                    }
+                } else {
+                    for (int c0 = 0; c0 < C0; c0++) {
+                        const float v0 = d[c0], v = ok ? v0 : 0.f;
+#pragma unroll
+                        for (int c = 0; c < CO; c++) acc[c] = fmaf(v, f[c * K * K * C0 + c0], acc[c]);
+                    }
+                }
+                (void)msk;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CO; c++) { DX[pix * CO + c] = acc[c]; if (DX2) DX2[pix * CO + c] = acc[c]; }
+    }
+}
+template <int CO>
+void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, float *DX, float *DX2, const float *F,
+                        int N, int H0, int W0, int C0, int H1, int W1) {
+    const long npix = (long)N * H1 * W1;
+    long gx = (npix + 255) / 256; if (gx > 8192) gx = 8192;
+    const dim3 g((unsigned)gx), b(256);
+    switch ((K << 8) | (S << 4) | P) {
+    case 0x110: hipLaunchKernelGGL((k_conv_dx_few<1, 1, 0, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+    case 0x311: hipLaunchKernelGGL((k_conv_dx_few<3, 1, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+    case 0x421: hipLaunchKernelGGL((k_conv_dx_few<4, 2, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+    case 0x512: hipLaunchKernelGGL((k_conv_dx_few<5, 1, 2, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+    }
+}
+
+bool conv_few_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_FEW"); v = e ? atoi(e) : 1; } return v != 0; }
 bool conv_supported(int K, int S, int P) {
     return (K == 1 && S == 1 && P == 0) || (K == 3 && S == 1 && P == 1) ||
            (K == 4 && S == 2 && P == 1) || (K == 5 && S == 1 && P == 2);
@@ -352,6 +545,12 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
     if (!conv_supported(K, S, P))
         return fail(T4K_ERR_UNSUPPORTED, "nn#fconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
     if (!I || !O || !F || !B || N <= 0 || C0 <= 0 || C1 <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_fwd: bad argument");
+    int fG, fNG;
+    if (conv_few_on() && conv_few_ok(K, C1, C0, &fG, &fNG)) {
+        launch_conv_few<false>(K, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0, fG, fNG);
+        T4K_LAUNCH_CHECK();
+        return T4K_OK;
+    }
     const long npix = (long)N * H0 * W0;
     dim3 g((unsigned)((npix + 127) / 128), (unsigned)((C0 + 31) / 32));
     launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
@@ -399,7 +598,16 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, part, DF, DB, nslice, ntaps * C0, ntot);
         }
     }
-    if (DX) {                                           // DX == NULL: dF|dB only; DX2 = optional second copy from the same launch
+    if (DX && C1 <= 4 && C1 * K * K * C0 <= LDS_FILTER_FLOATS) {   // image-input layer: direct kernel, one thread per input pixel
+        switch (C1) {
+        case 1: launch_conv_dx_few<1>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+        case 2: launch_conv_dx_few<2>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+        case 3: launch_conv_dx_few<3>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+        default: launch_conv_dx_few<4>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+        }
+    } else if (int fG = 0, fNG = 0; DX && conv_few_on() && conv_few_ok(K, C0, C1, &fG, &fNG)) {
+        launch_conv_few<true>(K, hs, DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, fG, fNG);
+    } else if (DX) {                                    // DX == NULL: dF|dB only; DX2 = optional second copy from the same launch
         const long npix1 = (long)N * H1 * W1;
         dim3 g((unsigned)((npix1 + 127) / 128), (unsigned)((C1 + 31) / 32));
         // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1)
