@@ -22,17 +22,36 @@ struct PB {                                   // device copy of t4k_poolblock + 
     uint64_t *rng;
 };
 
-template <int KS>
+// VW channels per thread (1, 2 or 4; C % VW == 0 and 4*VW-byte aligned tensors): vector loads / stores, and one
+// Philox call serves all VW dropout draws of a pixel (they share the 4-element counter block).
+template <int VW> struct Vec { float v[VW]; };
+template <int VW> __device__ __forceinline__ Vec<VW> vload(const float *p) {
+    Vec<VW> r;
+    if (VW == 4)      { const float4 t = *reinterpret_cast<const float4 *>(p); r.v[0] = t.x; r.v[1 % VW] = t.y; r.v[2 % VW] = t.z; r.v[3 % VW] = t.w; }
+    else if (VW == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r.v[0] = t.x; r.v[1 % VW] = t.y; }
+    else              r.v[0] = *p;
+    return r;
+}
+template <int VW> __device__ __forceinline__ void vstore(float *p, const Vec<VW> &r) {
+    if (VW == 4)      *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1 % VW], r.v[2 % VW], r.v[3 % VW]);
+    else if (VW == 2) *reinterpret_cast<float2 *>(p) = make_float2(r.v[0], r.v[1 % VW]);
+    else              *p = r.v[0];
+}
+
+template <int KS, int VW>
 __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
-    const long total = (long)p.N * p.H0 * p.W0 * p.C;
+    const int CV = p.C / VW;
+    const long total = (long)p.N * p.H0 * p.W0 * CV;
     uint64_t base = 0, seed = 0;
     const bool draw = p.pre == T4K_L_DROPOUT;
     if (draw) rng_state_read(p.rng, base, seed);
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
-        const int c = (int)(z % p.C); long t = z / p.C;
+        const int c = (int)(z % CV) * VW; long t = z / CV;
         const int j0 = (int)(t % p.W0); t /= p.W0;
         const int i0 = (int)(t % p.H0); const int n = (int)(t / p.H0);
-        float v = 0.f; bool first = true;
+        Vec<VW> acc; bool first = true;
+#pragma unroll
+        for (int q = 0; q < VW; q++) acc.v[q] = 0.f;
 #pragma unroll
         for (int y = 0; y < KS; y++)
 #pragma unroll
@@ -40,21 +59,36 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
                 const int gi = i0 * KS + y, gj = j0 * KS + x;
                 if (gi >= p.H1 || gj >= p.W1) continue;
                 const long a = (((long)n * p.H1 + gi) * p.W1 + gj) * p.C + c;
-                float e = p.X[a];
+                Vec<VW> e = vload<VW>(p.X + a);
                 if (p.pre) {
-                    float o, f;
-                    act_rt(p.pre, e, draw ? philox_u01_at(base, seed, a) : 0.f, p.a_pre, o, f);
-                    p.Fpre[a] = f; p.P[a] = o; e = o;
+                    Vec<VW> o, f;
+                    uint32_t r[4] = {0, 0, 0, 0};
+                    if (draw) philox4x32_10(base + (uint64_t)(a >> 2), seed, r);   // a .. a+VW-1 sit in one counter block
+#pragma unroll
+                    for (int q = 0; q < VW; q++) act_rt(p.pre, e.v[q], draw ? u01(r[(a + q) & 3]) : 0.f, p.a_pre, o.v[q], f.v[q]);
+                    vstore<VW>(p.Fpre + a, f); vstore<VW>(p.P + a, o); e = o;
                 }
-                if (p.pool == T4K_L_MAXPOOL)      v = first ? e : fmaxf(e, v);
-                else if (p.pool == T4K_L_MINPOOL) v = first ? e : fminf(e, v);
-                else                              v += e;
+#pragma unroll
+                for (int q = 0; q < VW; q++) {
+                    if (p.pool == T4K_L_MAXPOOL)      acc.v[q] = first ? e.v[q] : fmaxf(e.v[q], acc.v[q]);
+                    else if (p.pool == T4K_L_MINPOOL) acc.v[q] = first ? e.v[q] : fminf(e.v[q], acc.v[q]);
+                    else                              acc.v[q] += e.v[q];
+                }
                 first = false;
             }
-        if (p.pool == T4K_L_AVGPOOL) v /= (float)(KS * KS);
-        if (p.pool) p.Q[z] = v;
-        if (p.post) { float o, f; act_rt(p.post, v, 0.f, p.a_post, o, f); p.Fpost[z] = f; p.R[z] = o; v = o; }
-        if (p.R2) p.R2[z] = v;
+        const long zo = (((long)n * p.H0 + i0) * p.W0 + j0) * p.C + c;
+        if (p.pool == T4K_L_AVGPOOL) {
+#pragma unroll
+            for (int q = 0; q < VW; q++) acc.v[q] /= (float)(KS * KS);
+        }
+        if (p.pool) vstore<VW>(p.Q + zo, acc);
+        if (p.post) {
+            Vec<VW> o, f;
+#pragma unroll
+            for (int q = 0; q < VW; q++) act_rt(p.post, acc.v[q], 0.f, p.a_post, o.v[q], f.v[q]);
+            vstore<VW>(p.Fpost + zo, f); vstore<VW>(p.R + zo, o); acc = o;
+        }
+        if (p.R2) vstore<VW>(p.R2 + zo, acc);
     }
     if (draw) rng_advance_last_block(p.rng, base, (uint64_t)(((long)p.N * p.H1 * p.W1 * p.C + 3) >> 2));
 }
@@ -67,45 +101,70 @@ struct PBB {
     int pre, pool, post;
     int N, H1, W1, H0, W0, C;
 };
-template <int KS>
+template <int KS, int VW>
 __global__ void __launch_bounds__(BLK) k_poolblock_bwd(PBB p) {
-    const long total = (long)p.N * p.H0 * p.W0 * p.C;
+    const int CV = p.C / VW;
+    const long total = (long)p.N * p.H0 * p.W0 * CV;
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
-        const int c = (int)(z % p.C); long t = z / p.C;
+        const int c = (int)(z % CV) * VW; long t = z / CV;
         const int j0 = (int)(t % p.W0); t /= p.W0;
         const int i0 = (int)(t % p.H0); const int n = (int)(t / p.H0);
-        float g = p.DY[z];
-        if (p.Rb) p.Rb[z] = g;                                    // flatten: in = out
-        if (p.post) { g = g * p.Fpost[z]; p.Qb[z] = g; }           // activation: in = out (*) mask
+        const long zo = (((long)n * p.H0 + i0) * p.W0 + j0) * p.C + c;
+        Vec<VW> g = vload<VW>(p.DY + zo);
+        if (p.Rb) vstore<VW>(p.Rb + zo, g);                       // flatten: in = out
+        if (p.post) {                                             // activation: in = out (*) mask
+            const Vec<VW> f = vload<VW>(p.Fpost + zo);
+#pragma unroll
+            for (int q = 0; q < VW; q++) g.v[q] *= f.v[q];
+            vstore<VW>(p.Qb + zo, g);
+        }
         if (!p.pool) {                                            // no pooling in this run (KS == 1)
-            if (p.pre) p.Xb[z] = g * p.Fpre[z];
+            if (p.pre) {
+                const Vec<VW> f = vload<VW>(p.Fpre + zo);
+                Vec<VW> o;
+#pragma unroll
+                for (int q = 0; q < VW; q++) o.v[q] = g.v[q] * f.v[q];
+                vstore<VW>(p.Xb + zo, o);
+            }
             continue;
         }
-        float best = 0.f; long arg = -1;
-        float dv[KS * KS]; long av[KS * KS];
+        float best[VW]; int arg[VW];
+        Vec<VW> ev[KS * KS]; long av[KS * KS];
+#pragma unroll
+        for (int q = 0; q < VW; q++) { best[q] = 0.f; arg[q] = -1; }
 #pragma unroll
         for (int y = 0; y < KS; y++)
 #pragma unroll
             for (int x = 0; x < KS; x++) {
-                const int q = y * KS + x;
+                const int w = y * KS + x;
                 const int gi = i0 * KS + y, gj = j0 * KS + x;
-                av[q] = -1; dv[q] = 0.f;
+                av[w] = -1;
                 if (gi >= p.H1 || gj >= p.W1) continue;
                 const long a = (((long)n * p.H1 + gi) * p.W1 + gj) * p.C + c;
-                av[q] = a;
-                if (p.pool == T4K_L_AVGPOOL) dv[q] = g / (float)(KS * KS);
-                else {
-                    const float e = p.Pb[a];
-                    const bool better = (p.pool == T4K_L_MAXPOOL) ? (e > best) : (e < best);
-                    if (arg < 0 || better) { best = e; arg = a; }  // first extreme wins
+                av[w] = a;
+                if (p.pool != T4K_L_AVGPOOL) {
+                    ev[w] = vload<VW>(p.Pb + a);
+#pragma unroll
+                    for (int q = 0; q < VW; q++) {
+                        const float e = ev[w].v[q];
+                        const bool better = (p.pool == T4K_L_MAXPOOL) ? (e > best[q]) : (e < best[q]);
+                        if (arg[q] < 0 || better) { best[q] = e; arg[q] = w; }   // first extreme wins
+                    }
                 }
             }
 #pragma unroll
-        for (int q = 0; q < KS * KS; q++) {
-            const long a = av[q]; if (a < 0) continue;
-            const float d = (p.pool == T4K_L_AVGPOOL) ? dv[q] : (a == arg ? g : 0.f);
-            p.Pb[a] = d;
-            if (p.pre) p.Xb[a] = d * p.Fpre[a];
+        for (int w = 0; w < KS * KS; w++) {
+            const long a = av[w]; if (a < 0) continue;
+            Vec<VW> d;
+#pragma unroll
+            for (int q = 0; q < VW; q++) d.v[q] = (p.pool == T4K_L_AVGPOOL) ? g.v[q] / (float)(KS * KS) : (arg[q] == w ? g.v[q] : 0.f);
+            vstore<VW>(p.Pb + a, d);
+            if (p.pre) {
+                const Vec<VW> f = vload<VW>(p.Fpre + a);
+#pragma unroll
+                for (int q = 0; q < VW; q++) d.v[q] *= f.v[q];
+                vstore<VW>(p.Xb + a, d);
+            }
         }
     }
 }
@@ -113,6 +172,18 @@ __global__ void __launch_bounds__(BLK) k_poolblock_bwd(PBB p) {
 bool is_act(int l)  { return l == T4K_L_RELU || l == T4K_L_TANH || l == T4K_L_SIGMOID || l == T4K_L_SELU || l == T4K_L_LEAKYRL || l == T4K_L_ELU || l == T4K_L_DROPOUT; }
 bool is_pool(int l) { return l == T4K_L_AVGPOOL || l == T4K_L_MAXPOOL || l == T4K_L_MINPOOL; }
 
+// widest channel vector every tensor of the run supports (C % VW == 0, all pointers 4*VW-byte aligned)
+int vec_width(int C, const float *X, const t4k_poolblock *b) {
+    for (int vw = 4; vw > 1; vw >>= 1) {
+        if (C % vw) continue;
+        const uintptr_t m = (uintptr_t)(4 * vw - 1);
+        const void *ptrs[] = { X, b->pre_mask, b->pre_out, b->pool_out, b->post_mask, b->post_out, b->copy_out };
+        bool ok = true;
+        for (const void *q : ptrs) if (q && (((uintptr_t)q) & m)) ok = false;
+        if (ok) return vw;
+    }
+    return 1;
+}
 int check_block(const t4k_poolblock *b, const char *who) {
     if (!b) return fail(T4K_ERR_ARG, "%s: null block", who);
     if (b->pre_layer && !is_act(b->pre_layer))   return fail(T4K_ERR_UNSUPPORTED, "%s: pre layer %d", who, b->pre_layer);
@@ -140,12 +211,13 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
     p.X = X; p.P = b->pre_out; p.Q = b->pool_out; p.R = b->post_out; p.R2 = b->copy_out; p.Fpre = b->pre_mask; p.Fpost = b->post_mask;
     p.pre = b->pre_layer; p.pool = b->pool_layer; p.post = b->post_layer; p.a_pre = b->pre_alpha; p.a_post = b->post_alpha;
     p.N = N; p.H1 = H1; p.W1 = W1; p.H0 = H0; p.W0 = W0; p.C = C; p.rng = g.d_rng;
-    const dim3 grid(grid_for(total)), blk(BLK);
-    switch (b->KS) {
-    case 1: hipLaunchKernelGGL(k_poolblock_fwd<1>, grid, blk, 0, S(s), p); break;
-    case 2: hipLaunchKernelGGL(k_poolblock_fwd<2>, grid, blk, 0, S(s), p); break;
-    default: hipLaunchKernelGGL(k_poolblock_fwd<3>, grid, blk, 0, S(s), p); break;
-    }
+    const int VW = vec_width(C, X, b);
+    const dim3 grid(grid_for(total / VW)), blk(BLK);
+#define PBF(KS_) do { if (VW == 4) hipLaunchKernelGGL((k_poolblock_fwd<KS_, 4>), grid, blk, 0, S(s), p); \
+                      else if (VW == 2) hipLaunchKernelGGL((k_poolblock_fwd<KS_, 2>), grid, blk, 0, S(s), p); \
+                      else hipLaunchKernelGGL((k_poolblock_fwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
+    switch (b->KS) { case 1: PBF(1); break; case 2: PBF(2); break; default: PBF(3); break; }
+#undef PBF
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
@@ -161,12 +233,13 @@ int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *b, int N, 
     p.Xb = X; p.Fpre = b->pre_mask; p.Fpost = b->post_mask;
     p.pre = b->pre_layer; p.pool = b->pool_layer; p.post = b->post_layer;
     p.N = N; p.H1 = H1; p.W1 = W1; p.H0 = H0; p.W0 = W0; p.C = C;
-    const dim3 grid(grid_for(total)), blk(BLK);
-    switch (b->KS) {
-    case 1: hipLaunchKernelGGL(k_poolblock_bwd<1>, grid, blk, 0, S(s), p); break;
-    case 2: hipLaunchKernelGGL(k_poolblock_bwd<2>, grid, blk, 0, S(s), p); break;
-    default: hipLaunchKernelGGL(k_poolblock_bwd<3>, grid, blk, 0, S(s), p); break;
-    }
+    int VW = vec_width(C, X, b); if (VW > 1 && (((uintptr_t)DY) & (4 * VW - 1))) VW = 1;
+    const dim3 grid(grid_for(total / VW)), blk(BLK);
+#define PBB_(KS_) do { if (VW == 4) hipLaunchKernelGGL((k_poolblock_bwd<KS_, 4>), grid, blk, 0, S(s), p); \
+                       else if (VW == 2) hipLaunchKernelGGL((k_poolblock_bwd<KS_, 2>), grid, blk, 0, S(s), p); \
+                       else hipLaunchKernelGGL((k_poolblock_bwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
+    switch (b->KS) { case 1: PBB_(1); break; case 2: PBB_(2); break; default: PBB_(3); break; }
+#undef PBB_
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

@@ -423,6 +423,7 @@ class PoolBlock(ctypes.Structure):
                 ("copy_out", ctypes.c_void_p)]
 
 
+@pytest.mark.parametrize("C", [5, 6, 8])             # scalar, 8-byte and 16-byte channel vectors
 @pytest.mark.parametrize("pre,pool,post,flat,KS,H1", [
     ("dropout", "max", "relu", True, 2, 14),      # LeNet block 2: conv -> dropout -> maxpool -> relu -> flatten
     (None, "max", "relu", False, 2, 28),          # LeNet block 1: conv -> maxpool -> relu
@@ -431,14 +432,14 @@ class PoolBlock(ctypes.Structure):
     ("dropout", None, None, True, 1, 5),
     (None, "min", "selu", True, 2, 8),
 ])
-def test_poolblock_matches_unfused_oracle(t4k, dev, oracle, pre, pool, post, flat, KS, H1):
+def test_poolblock_matches_unfused_oracle(t4k, dev, oracle, pre, pool, post, flat, KS, H1, C):
     """One fused launch each way == the oracle's separate layers (activate / rand / pool / dpool / mask multiply),
     every intermediate tensor included.  Dropout masks come from the same Philox slice => bit-exact."""
     o = oracle.lib(); P = oracle.P
     LAY = {"dropout": (oracle.L_DROPOUT, 0.5), "relu": (oracle.L_RELU, 0.0), "leaky": (oracle.L_LEAKYRL, 0.1), "tanh": (oracle.L_TANH, 0.0),
            "elu": (oracle.L_ELU, 1.0), "selu": (oracle.L_SELU, 0.0), "max": oracle.L_MAXPOOL, "avg": oracle.L_AVGPOOL, "min": oracle.L_MINPOOL}
     rng = np.random.default_rng(H1 * 31 + KS)
-    N, C = 3, 5; H0 = H1 // KS
+    N = 3; H0 = H1 // KS
     n1, n0 = N * H1 * H1 * C, N * H0 * H0 * C
     X = rng.standard_normal((N, H1, H1, C)).astype(np.float32)
     DY = rng.standard_normal((N, H0, H0, C)).astype(np.float32)
