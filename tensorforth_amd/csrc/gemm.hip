@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(256) k_gemm_glds(GemmP p) {
 // 8-wave variant: the same pipeline with two waves per SIMD.  Waves 4..7 take the upper half of every stage's k chunks
 // into their own accumulators, so one wave's LDS reads and waits sit under the other's MFMAs; the halves are summed
 // through LDS in the epilogue (fixed order).
-template <int BK, bool AKC, bool BKC>
+template <int BK, bool AKC, bool BKC, bool PRIO = false>   // PRIO: s_setprio around the MFMA burst - measured +1.2 us at 1024^3, kept off
 __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     constexpr int BM = 64, BN = 64;
     constexpr int NC = BK / 8, CH = BK / 4, SW = 64 / BK;
@@ -594,10 +594,12 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
         }
     };
     auto mm = [&](float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
+        if (PRIO) __builtin_amdgcn_s_setprio(2);                 // keep the matrix pipe fed: the MFMA burst outranks the other wave's loads
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto wait_next = [&](bool more) __attribute__((always_inline)) {      // next stage landed; later one may fly
         if (more) { if (NPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
