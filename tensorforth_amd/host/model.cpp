@@ -528,6 +528,56 @@ Model &Model::sgd(DU lr, DU b) { return gradient("sgd", ZEQ(b) ? OPTI_SGD : OPTI
 Model &Model::adam(DU lr, DU b1, DU b2) { return gradient("adam", OPTI_ADAM, lr, b1, b2, 0); }
 Model &Model::adamw(DU lr, DU wd, DU b1, DU b2) { return gradient("adamw", OPTI_ADAMW, lr, b1, b2, wd); }
 
+// ---------------------------------------------------------------- persistence (.t4 model file, aio_model.cpp)
+// Layout written by the reference: a `\\ tensorForth v4.0 model` line, one `<params><layer name>` line per layer, a blank
+// line, then for every conv / linear (w, b) and batchnorm (w) tensor a `--- w.<layer>` marker line followed by the raw
+// fp32 values, and a closing `---`.  Loading into an already built model skips the layer section and reads the blobs in
+// layer order (the reference's own reload of the layer section is unfinished: `_parm` text is not Forth source).
+int model_save(Model &m, const char *fname) {
+    FILE *f = fopen(fname, "wb");
+    if (!f) { printf("} => failed to open for output\n"); return 1; }
+    fprintf(f, "\\ tensorForth v4.0 model\n");
+    const int L = (int)m.layer.size();
+    for (int i = 0; i + 1 < L; i++) { Tensor &in = m.at(i), &out = m.at(i + 1); fprintf(f, "%s%s\n", fmt_parm(in, out).c_str(), LAYER_NAME[in.grad_fn]); }
+    std::vector<float> h;
+    auto dump = [&](char pn, const char *nm, Tensor &t) {
+        fprintf(f, "\n--- %c.%s\n", pn, nm);
+        t.to_host(h); fwrite(h.data(), sizeof(float), t.numel, f);
+    };
+    for (int i = 0; i + 1 < L; i++) {
+        Tensor &in = m.at(i); const int fn = in.grad_fn;
+        if ((fn == T4K_L_CONV || fn == T4K_L_LINEAR || fn == T4K_L_DCONV) && in.grad[0] && in.grad[1]) { if (fn != T4K_L_DCONV) { dump('w', LAYER_NAME[fn], *in.grad[0]); dump('b', LAYER_NAME[fn], *in.grad[1]); } }
+        else if (fn == T4K_L_BATCHNM && in.grad[0]) dump('w', LAYER_NAME[fn], *in.grad[0]);
+    }
+    fprintf(f, "\n---\n");
+    fclose(f);
+    return 0;
+}
+int model_load(Model &m, const char *fname) {
+    FILE *f = fopen(fname, "rb");
+    if (!f) { printf("} => failed to open for input\n"); return 1; }
+    auto getline_ = [&](std::string &line) { line.clear(); int c; bool any = false; while ((c = fgetc(f)) != EOF) { any = true; if (c == '\n') break; line.push_back((char)c); } return any; };
+    std::string line;
+    while (getline_(line) && line.length()) {}           // skip the layer section (model already built)
+    std::vector<float> h;
+    int err = 0;
+    auto rd = [&](Tensor &t) {
+        while (getline_(line) && !line.length()) {}      // skip blank lines
+        if (line.size() < 3 || line[0] != '-' || line[1] != '-' || line[2] != '-') { printf(" model format error\n"); err = 1; return; }
+        h.resize(t.numel);
+        if (fread(h.data(), sizeof(float), t.numel, f) != t.numel) { printf(" model format error (short read)\n"); err = 1; return; }
+        t.from_host(h.data(), t.numel);
+    };
+    const int L = (int)m.layer.size();
+    for (int i = 0; i + 1 < L && !err; i++) {
+        Tensor &in = m.at(i); const int fn = in.grad_fn;
+        if ((fn == T4K_L_CONV || fn == T4K_L_LINEAR) && in.grad[0] && in.grad[1]) { rd(*in.grad[0]); if (!err) rd(*in.grad[1]); }
+        else if (fn == T4K_L_BATCHNM && in.grad[0]) rd(*in.grad[0]);
+    }
+    fclose(f);
+    return err;
+}
+
 void Model::free_all() {
     invalidate();
     if (current == this) current = nullptr;

@@ -105,6 +105,7 @@ static std::string parm_s(Tensor &in, Tensor &out) {     // aio_model.cpp:103-14
     }
     return o.str();
 }
+std::string fmt_parm(Tensor &in, Tensor &out) { return parm_s(in, out); }
 std::string fmt_model(Model &m) {                        // aio_model.cpp:65-99
     std::ostringstream o;
     const int n = (int)m.layer.size();

@@ -254,5 +254,8 @@ std::string fmt_scalar(DU v, int base);                 // src/io/aio.cpp:38-57
 std::string fmt_objname(Obj &o, bool view);             // "T2[2,3]" etc, src/io/aio_tensor.cpp:16-58
 std::string fmt_tensor(Tensor &t);                      // src/io/aio_tensor.cpp:141-226
 std::string fmt_model(Model &m);                        // src/io/aio_model.cpp:65-141
+std::string fmt_parm(Tensor &in, Tensor &out);          // src/io/aio_model.cpp:103-141 (layer parameter text)
+int model_save(Model &m, const char *fname);            // src/io/aio_model.cpp:16-35,143-181 (.t4 model file)
+int model_load(Model &m, const char *fname);            // src/io/aio_model.cpp:38-60,206-238 (parameter section)
 
 } // namespace t4

@@ -452,9 +452,11 @@ void VM::init_nn() {
     CODE("nn.b=", [this] { set_parm(1); });
     CODE("flatten", [this] { nnop(T4K_L_FLATTEN); });
     auto pickle = [this](bool save) {                    // ( N adr len [mode] -- N )  model persistence is a "next" row
-        if (SP() > 2 && IS_OBJ(SS(-3))) POPi();
-        POPi(); POPi();
-        pstr(save ? "  nn.save: n/a in this build\n" : "  nn.load: n/a in this build\n");
+        if (SP() > 2 && IS_OBJ(SS(-3))) POPi();          // optional mode (raw formats: TODO in the reference too)
+        POPi(); const uint32_t adr = (uint32_t)POPi();
+        const char *fn = (const char *)&pmem_[adr];
+        if (!is_m(tos_)) return;
+        if (save) model_save(MTOS(), fn); else model_load(MTOS(), fn);
     };
     CODE("save", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(true); else { int w = 0; for (int i = 1; i < (int)dict_.size(); i++) if (dict_[i].name == "save") { w = i; break; } if (w) dict_[w].xt(); } });
     CODE("load", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(false); else { int w = 0; for (int i = 1; i < (int)dict_.size(); i++) if (dict_[i].name == "load") { w = i; break; } if (w) dict_[w].xt(); } });
