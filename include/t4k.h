@@ -255,6 +255,10 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *blk, int N, int H1, i
 /* backward of the same run (_bactivate backprop.cu:256-263, _bpool, flatten `in = out`): DY is the gradient
  * w.r.t. the run's last tensor; each stage's input buffer receives its dX (X receives the run's dX). */
 int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);
+/* linear layer followed by an element-wise layer (t4k_layer: relu ... dropout; _flinear + _factivate forward.cu:157-209):
+ * Y as above, ACT_O / ACT_F = activation output / derivative mask of Y; dropout draws the Philox slice t4k_rand would */
+int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y, int layer, float alpha,
+                       float *ACT_F, float *ACT_O, int N, int E0, int E1, t4k_stream_t s);
 /* linear layer followed by a softmax layer (_flinear + _fsoftmax forward.cu:157-198, 229-243): Y as above,
  * P[N,E0] = row softmax of Y; both tensors are written */
 int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P,

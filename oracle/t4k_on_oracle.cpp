@@ -132,6 +132,11 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int
     memset(Y, 0, sizeof(float) * (size_t)N * E0);
     return t4o_linear_fwd(X, W, B, Y, N, E0, E1);
 }
+int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y, int layer, float alpha, float *F, float *A, int N, int E0, int E1, t4k_stream_t st) {
+    int r = t4k_linear_fwd(X, W, B, Y, N, E0, E1, st); if (r) return r;
+    if (layer == T4K_L_DROPOUT) t4o_rand(F, (long)N * E0, T4K_UNIFORM, 0.0f, 1.0f);
+    return rc(t4o_activate(layer, Y, A, F, alpha, (long)N * E0), "k_activate");
+}
 int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, t4k_stream_t st) {
     int r = t4k_linear_fwd(X, W, B, Y, N, E0, E1, st); if (r) return r;
     return t4o_softmax(Y, P, N, E0);

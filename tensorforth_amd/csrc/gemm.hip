@@ -708,8 +708,15 @@ void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
 }
 
 // fold split-K slabs in slice order, then the alpha/beta epilogue (reference t4math.cu:580)
+// Optional activation epilogue (the layer that follows a linear layer: relu / tanh / ... / dropout): O keeps the linear
+// output, ACT_O / ACT_F receive the activation output and derivative mask (k_activate nmath.cu:37-70); dropout draws its
+// Philox slice here, exactly the values t4k_rand would have stored in the mask tensor.
+struct ActEpi { int layer; float alpha; float *F, *A; uint64_t *rng; };
 __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ part, float *O, long mn, int nsplit,
-                                                     float alpha, float beta, const float *__restrict__ bias, int N) {
+                                                     float alpha, float beta, const float *__restrict__ bias, int N, ActEpi ep) {
+    uint64_t base = 0, seed = 0;
+    const bool draw = ep.layer == T4K_L_DROPOUT;
+    if (draw) rng_state_read(ep.rng, base, seed);
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < mn; z += (long)gridDim.x * BLK) {
         float s = 0.f;
 #pragma unroll 4
@@ -718,7 +725,9 @@ __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ p
         if (beta != 0.f) o += O[z] * beta;
         if (bias) o += bias[z % N];
         O[z] = o;
+        if (ep.layer) { float a, f; act_rt(ep.layer, o, draw ? philox_u01_at(base, seed, z) : 0.f, ep.alpha, a, f); ep.F[z] = f; ep.A[z] = a; }
     }
+    if (draw) rng_advance_last_block(ep.rng, base, (uint64_t)((mn + 3) >> 2));
 }
 
 // words gemm1/gemm2 (k_gemm src/t4math.cu:370, k_gemm_claude :411): double accumulator
@@ -759,7 +768,8 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
 }
 
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,
-                int tA, int tB, int M, int N, int K, int C, t4k_stream_t s) {
+                int tA, int tB, int M, int N, int K, int C, t4k_stream_t s, const ActEpi *epi = nullptr, bool *epi_done = nullptr) {
+    if (epi_done) *epi_done = false;
     if (!A || !B || !O || M < 0 || N < 0 || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_gemm: bad argument");
     if (M == 0 || N == 0) return T4K_OK;
     GemmP p;
@@ -823,7 +833,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     }
     if (nsplit > 1 && !p.pair) {
         const long mn = (long)M * N;
-        hipLaunchKernelGGL(k_splitk_fold, dim3(grid_for(mn)), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N);
+        ActEpi ep = {0, 0.f, nullptr, nullptr, nullptr};
+        if (epi && epi->layer) { ep = *epi; if (epi_done) *epi_done = true; }
+        hipLaunchKernelGGL(k_splitk_fold, dim3(grid_for(mn)), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N, ep);
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;
@@ -853,6 +865,29 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int
     if (!X || !W || !Y || N < 0) return fail(T4K_ERR_ARG, "t4k_linear_fwd: bad argument");
     if (N > 0 && linear_small_ok(E0, E1)) { linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s)); T4K_LAUNCH_CHECK(); return T4K_OK; }
     return gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s);
+}
+// linear followed by an element-wise layer (relu, tanh, ..., dropout): Y = X W^T + b; ACT_O, ACT_F = activation(Y).
+// When the GEMM is split-K the activation rides in the fold launch; otherwise it is a second launch.
+int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y, int layer, float alpha, float *ACT_F, float *ACT_O,
+                       int N, int E0, int E1, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X || !W || !Y || !ACT_F || !ACT_O || N < 0) return fail(T4K_ERR_ARG, "t4k_linear_act_fwd: bad argument");
+    if (N == 0) return T4K_OK;
+    State &g = st();
+    if (layer == T4K_L_DROPOUT && !g.d_rng) { int rc = t4k_rand_init(0); if (rc) return rc; }
+    bool done = false;
+    if (linear_small_ok(E0, E1)) linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s));
+    else {
+        ActEpi ep = { layer, alpha, ACT_F, ACT_O, g.d_rng };
+        int rc = gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s, &ep, &done); if (rc) return rc;
+    }
+    if (!done) {
+        const long n = (long)N * E0;
+        if (layer == T4K_L_DROPOUT) { int rc = t4k_rand(ACT_F, n, T4K_UNIFORM, 0.0f, 1.0f, s); if (rc) return rc; }
+        return t4k_activate(layer, Y, ACT_O, ACT_F, alpha, n, s);
+    }
+    T4K_LAUNCH_CHECK();
+    return T4K_OK;
 }
 // linear followed by a softmax layer: Y = X W^T + b, P = softmax(Y); one launch when the head is small
 int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, t4k_stream_t s) {

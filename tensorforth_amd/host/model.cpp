@@ -144,6 +144,7 @@ void Model::finalize() {                                // gradient slab: SURVEY
 }
 // Fused element-wise runs: [dropout|activation] [pool] [activation] [flatten] -> one launch each way (csrc/fused.hip).
 // Only mask-multiply activations qualify (sigmoid is pass-through in the reference's backprop, backprop.cu:129-131).
+static bool is_eltwise(int f) { return f == T4K_L_RELU || f == T4K_L_TANH || f == T4K_L_SIGMOID || f == T4K_L_SELU || f == T4K_L_LEAKYRL || f == T4K_L_ELU || f == T4K_L_DROPOUT; }
 void Model::plan_runs() {
     const int L = (int)layer.size() - 1;                // number of ops
     run_of_.assign(layer.size(), -1); runs_.clear();
@@ -249,6 +250,14 @@ void Model::run_forward(Tensor &input) {
             chk(t4k_poolblock_fwd(x, &r.blk, in.N(), pin.H(), pin.W(), r.blk.pool_layer ? at(i + (r.blk.pre_layer ? 2 : 1)).H() : pin.H(),
                                   r.blk.pool_layer ? at(i + (r.blk.pre_layer ? 2 : 1)).W() : pin.W(), pin.C(), stream()), "nn#frun");
             x = lastt.data; i += r.count - 1;
+            continue;
+        }
+        if (fused && in.grad_fn == T4K_L_LINEAR && i + 2 < L && is_eltwise(out.grad_fn) &&
+            (run_of_[i + 1] < 0 || runs_[run_of_[i + 1]].count == 1)) {   // linear + lone activation / dropout: the activation rides in the GEMM's fold launch
+            Tensor &act = at(i + 2);
+            chk(t4k_linear_act_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.grad_fn, out.xparm, out.grad[4]->data, act.data,
+                                   out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+act");
+            x = act.data; i++;
             continue;
         }
         if (fused && in.grad_fn == T4K_L_LINEAR && i + 2 < L && out.grad_fn == T4K_L_SOFTMAX) {     // classifier head: linear + softmax in one launch
