@@ -200,6 +200,11 @@ int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t s);
 int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, t4k_stream_t s);
+/* same, plus the copy of the batch the model's layer 0 keeps (`n0 = input`, forward.cu:39): ICOPY (may be NULL) receives
+ * I, from the same launch when the layer takes the few-input-channel direct kernel */
+int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, const float *B,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                    int K, int S, int P, t4k_stream_t s);
 /* k_dconv2d<TS,KS,S,P> nmath.tcu:211 (Model::_bconv backprop.cu:152-191):
  * DB[c0] += sum dO; DF += sum I*dO (both only if train);
  * DX (overwritten) scatter (i*S+ky-P, j*S+kx-P) += F[c1,K-1-ky,K-1-kx,c0]*dO  (flipped, quirk a-11).

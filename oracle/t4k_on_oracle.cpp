@@ -102,6 +102,10 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B, int
     if (r) snprintf(g_err, sizeof(g_err), "nn#fconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
     return r;
 }
+int t4k_conv2d_fwd2(const float *I, float *IC, float *O, const float *F, const float *B, int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t st) {
+    if (IC) memcpy(IC, I, sizeof(float) * (size_t)N * H1 * W1 * C1);
+    return t4k_conv2d_fwd(I, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, st);
+}
 int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB, int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, int tr, t4k_stream_t) {
     // product contract: DX == NULL -> dF|dB only, DF == NULL -> dX only (the oracle always computes both; use scratch for the skipped half)

@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(BLK) k_dpool(int layer, float *I, const float 
 // round trips per pixel instead of 45.  Outputs leave through an LDS transpose so every store instruction is contiguous.
 // The filter is staged once per workgroup as Wl[tap][ci][co] (taps flipped for dX, nmath.tcu:304-324).
 template <int K, int S, int P, bool BWD, int G, int CH, int VW>
-__global__ void __launch_bounds__(256) k_conv_few(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
+__global__ void __launch_bounds__(256) k_conv_few(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2, float *__restrict__ XC,
                                                   const float *__restrict__ F, const float *__restrict__ B,
                                                   int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, int NG) {
     __shared__ __attribute__((aligned(16))) float Wl[LDS_FILTER_FLOATS];
@@ -384,6 +384,8 @@ __global__ void __launch_bounds__(256) k_conv_few(const float *__restrict__ X, f
                     }
             }
         }
+        if (XC && g == 0 && live)                               // layer 0 keeps a COPY of the batch (forward.cu:39): same-size conv, pixel index is shared
+            for (int ci = 0; ci < Cin; ci++) XC[pix * Cin + ci] = X[pix * Cin + ci];
         // transpose through LDS: the workgroup's 256 x gv results leave as contiguous runs
         __syncthreads();
 #pragma unroll
@@ -409,24 +411,24 @@ bool conv_few_ok(int K, int Cin, int Cout, int *G_out, int *NG_out) {
     return true;
 }
 template <bool BWD, int G, int CH, int VW>
-void launch_conv_few3(int K, dim3 g, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
+void launch_conv_few3(int K, dim3 g, hipStream_t hs, const float *X, float *Y, float *Y2, float *XC, const float *F, const float *B,
                       int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, int NG) {
     const dim3 b(256);
-    if (K == 3) hipLaunchKernelGGL((k_conv_few<3, 1, 1, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
-    else        hipLaunchKernelGGL((k_conv_few<5, 1, 2, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
+    if (K == 3) hipLaunchKernelGGL((k_conv_few<3, 1, 1, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
+    else        hipLaunchKernelGGL((k_conv_few<5, 1, 2, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
 }
 template <bool BWD>
-void launch_conv_few(int K, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
+void launch_conv_few(int K, hipStream_t hs, const float *X, float *Y, float *Y2, float *XC, const float *F, const float *B,
                      int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, int G, int NG) {
     const long npix = (long)N * Hy * Wy;
     long gx = (npix + 255) / 256; if (gx > 8192) gx = 8192;
     const dim3 g((unsigned)gx, (unsigned)NG);
     const bool v2 = (Cin & 1) == 0 && (((uintptr_t)X) & 7) == 0;
-#define FEW(GG) do { if (Cin == 1)      launch_conv_few3<BWD, GG, 1, 1>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
-                     else if (Cin <= 4) { if (v2) launch_conv_few3<BWD, GG, 4, 2>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
-                                          else    launch_conv_few3<BWD, GG, 4, 1>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); } \
-                     else               { if (v2) launch_conv_few3<BWD, GG, 8, 2>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
-                                          else    launch_conv_few3<BWD, GG, 8, 1>(K, g, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); } } while (0)
+#define FEW(GG) do { if (Cin == 1)      launch_conv_few3<BWD, GG, 1, 1>(K, g, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
+                     else if (Cin <= 4) { if (v2) launch_conv_few3<BWD, GG, 4, 2>(K, g, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
+                                          else    launch_conv_few3<BWD, GG, 4, 1>(K, g, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); } \
+                     else               { if (v2) launch_conv_few3<BWD, GG, 8, 2>(K, g, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); \
+                                          else    launch_conv_few3<BWD, GG, 8, 1>(K, g, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG); } } while (0)
     if (G == 4) FEW(4); else FEW(12);
 #undef FEW
 }
@@ -541,16 +543,23 @@ extern "C" {
 int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, t4k_stream_t s) {
+    return t4k_conv2d_fwd2(I, nullptr, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, s);
+}
+int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, const float *B,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                    int K, int S, int P, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!conv_supported(K, S, P))
         return fail(T4K_ERR_UNSUPPORTED, "nn#fconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
     if (!I || !O || !F || !B || N <= 0 || C0 <= 0 || C1 <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_fwd: bad argument");
     int fG, fNG;
     if (conv_few_on() && conv_few_ok(K, C1, C0, &fG, &fNG)) {
-        launch_conv_few<false>(K, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0, fG, fNG);
+        launch_conv_few<false>(K, t4k::S(s), I, O, nullptr, (H0 == H1 && W0 == W1) ? ICOPY : nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0, fG, fNG);
+        if (ICOPY && !(H0 == H1 && W0 == W1)) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, t4k::S(s)));
         T4K_LAUNCH_CHECK();
         return T4K_OK;
     }
+    if (ICOPY) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, t4k::S(s)));
     const long npix = (long)N * H0 * W0;
     dim3 g((unsigned)((npix + 127) / 128), (unsigned)((C0 + 31) / 32));
     launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
@@ -606,7 +615,7 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         default: launch_conv_dx_few<4>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
         }
     } else if (int fG = 0, fNG = 0; DX && conv_few_on() && conv_few_ok(K, C0, C1, &fG, &fNG)) {
-        launch_conv_few<true>(K, hs, DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, fG, fNG);
+        launch_conv_few<true>(K, hs, DO, DX, DX2, nullptr, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, fG, fNG);
     } else if (DX) {                                    // DX == NULL: dF|dB only; DX2 = optional second copy from the same launch
         const long npix1 = (long)N * H1 * W1;
         dim3 g((unsigned)((npix1 + 127) / 128), (unsigned)((C1 + 31) / 32));

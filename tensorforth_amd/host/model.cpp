@@ -228,9 +228,11 @@ Model &Model::forward(Tensor &input) {
 void Model::run_forward(Tensor &input) {
     const int L = (int)layer.size();
     Tensor &n0 = at(0);
-    lazy_copy(input.data, n0);                          // layer 0 holds a COPY of the batch (forward.cu:39); conv1 reads the batch itself
-    bool masks = false;
     const bool fused = use_fusion && !(trace && *trace) && !concurrent();
+    // layer 0 holds a COPY of the batch (forward.cu:39); a first conv layer reads the batch itself and writes the copy from its own launch
+    const bool copy_in_conv = fused && L > 1 && n0.grad_fn == T4K_L_CONV && input.data != n0.data;
+    if (!copy_in_conv) lazy_copy(input.data, n0);
+    bool masks = false;
     if (concurrent())                                   // side stream: draw every dropout mask up front, in layer order
         for (int i = 0; i + 1 < L; i++)
             if (at(i).grad_fn == T4K_L_DROPOUT) {
@@ -264,6 +266,12 @@ void Model::run_forward(Tensor &input) {
             Tensor &prob = at(i + 2);
             chk(t4k_linear_softmax_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, prob.data, out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+softmax");
             x = prob.data; i++;
+            continue;
+        }
+        if (i == 0 && copy_in_conv) {
+            chk(t4k_conv2d_fwd2(x, n0.data, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
+                                out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], stream()), "nn#fconv");
+            x = out.data;
             continue;
         }
         x = fstep(in, out, x);
