@@ -221,7 +221,7 @@ Model &Model::forward(Tensor &input) {
         run_forward(input);
         end_capture(g_fwd_, cap);
     }
-    if (input.type == T_DATASET) { onehot((Dataset &)input); hit_ = hit(true); }
+    if (input.type == T_DATASET) { onehot((Dataset &)input); hit_lazy(); }
     NLOG("\n} Model::forward\n");
     return *this;
 }
@@ -340,14 +340,20 @@ Tensor &Model::onehot(Dataset &d) {                     // loss.cpp:47-72
     chk(t4k_onehot(d.label, hot->data, d.batch_sz, E, stream()), "nn#onehot");
     return *hot;
 }
-int Model::hit(bool recalc) {                           // loss.cpp:75-107
-    if (!recalc) return hit_;
-    if (!hot) return 0;
+void Model::hit_lazy() {                                 // count on the GPU now, read it back only if somebody asks (`nn.hit`)
+    if (!hot) { hit_ = 0; hit_pending_ = false; return; }
     Tensor &out = at(-1);
     if (!hit_dev) { void *p; t4k_malloc(&p, 64); hit_dev = (int *)p; }
     chk(t4k_hit(out.data, hot->data, out.N(), (int)out.HWC(), hit_dev, stream()), "nn#hit");
-    int c = 0; t4k_memcpy_d2h(&c, hit_dev, sizeof(int), stream()); t4k_sync(stream());
-    return c;
+    hit_pending_ = true;
+}
+int Model::hit(bool recalc) {                           // loss.cpp:75-107
+    if (recalc) hit_lazy();
+    if (hit_pending_) {
+        int c = 0; t4k_memcpy_d2h(&c, hit_dev, sizeof(int), stream()); t4k_sync(stream());
+        hit_ = c; hit_pending_ = false;
+    }
+    return hit_;
 }
 DU Model::loss(Loss op) { return hot ? loss(op, *hot) : 0.0f; }
 DU Model::loss(Loss op, Tensor &tgt) {                  // loss.cpp:119-136: non-destructive (works on a copy)

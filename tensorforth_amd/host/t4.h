@@ -153,12 +153,23 @@ struct Corpus {
     std::string name, f_data, f_label;
     int N = 0, H = 0, W = 0, C = 0, corpus_sz = 0, batch_sz = 0;
     bool eof = false;
-    std::vector<uint8_t> data, label;
     FILE *fd = nullptr, *fl = nullptr;
     bool init(int batch);                      // src/ld/mnist.cpp:21-62 (IDX header, big endian)
-    bool fetch(int batch_id);
+    bool fetch(int batch_id);                  // batch -> staging slot (batch_id & 1); the next batch is read ahead by a worker thread
     void rewind();
     bool cifar = false;
+    // double-buffered pinned staging: slot s = batch & 1 holds u8 pixels + u32 labels of one batch, so the
+    // H2D copies are truly asynchronous and the file read of batch b+1 overlaps the GPU work of batch b
+    uint8_t  *pix[2] = {nullptr, nullptr};
+    uint32_t *lab[2] = {nullptr, nullptr};
+    t4k_event_t copied[2] = {nullptr, nullptr};  // recorded after a slot's H2D copies: the reader waits on it before refilling the slot
+    int  ahead_bid = -1, ahead_n = 0;          // batch the worker is reading / has read, and its sample count
+    void *worker = nullptr;                    // persistent reader thread (dataset.cpp)
+    int  read_into(int bid, int slot);         // blocking file read (runs on the worker thread)
+    void cancel_ahead();
+    uint8_t  *cur_pix() { return pix[cur_slot]; }
+    uint32_t *cur_lab() { return lab[cur_slot]; }
+    int cur_slot = 0;
 };
 struct Dataset : Tensor {
     uint64_t dataset_size = 0;
@@ -195,6 +206,8 @@ struct Model : Obj {
     Tensor &onehot(Tensor &t);
     Tensor &onehot(Dataset &d);
     int  hit(bool recalc = true);
+    void hit_lazy();                           // forward(dataset): enqueue the count, defer the read-back
+    bool hit_pending_ = false;
     DU   loss(Loss op);
     DU   loss(Loss op, Tensor &tgt);
     Model &sgd(DU lr, DU b = 0.9f);
