@@ -28,16 +28,16 @@ constexpr int LDS_FILTER_FLOATS = 8192;          // 32 KiB filter slice per work
 // ------------------------------------------------------------------ forward / dX gather-GEMM
 // BWD = false: forward (Cin = C1 of I, Cout = C0);  BWD = true: dX (Cin = C0 of dO, Cout = C1)
 template <int K, int S, int P, bool BWD>
-__global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
-                                                   const float *__restrict__ F, const float *__restrict__ B,
-                                                   int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout,
-                                                   int C0 /* filter inner dim */, int pairs_per_chunk) {
+__device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
+                                               const float *__restrict__ F, const float *__restrict__ B,
+                                               int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout,
+                                               int C0 /* filter inner dim */, int pairs_per_chunk, int bx, int by) {
     __shared__ float Bl[LDS_FILTER_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const long npix = (long)N * Hy * Wy;
-    const long tile = (long)blockIdx.x * 4 + w;
+    const long tile = (long)bx * 4 + w;
     const long pix  = tile * 32 + l31;                       // this lane's A-row pixel
-    const int  co0  = blockIdx.y * 32;                       // output-channel tile
+    const int  co0  = by * 32;                               // output-channel tile
     const bool pok  = pix < npix;
     int jy = 0, iy = 0, n = 0;
     if (pok) { jy = (int)(pix % Wy); long t = pix / Wy; iy = (int)(t % Hy); n = (int)(t / Hy); }
@@ -142,24 +142,31 @@ __global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, 
     }
 }
 
+template <int K, int S, int P, bool BWD>
+__global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
+                                                   const float *__restrict__ F, const float *__restrict__ B,
+                                                   int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0, int pairs_per_chunk) {
+    conv_gemm_body<K, S, P, BWD>(X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, pairs_per_chunk, blockIdx.x, blockIdx.y);
+}
+
 // ------------------------------------------------------------------ dF | dB
 // grid = (slices, m_tiles, c0_tiles); each wave accumulates D[tap][c0] over its output rows
 template <int K, int S, int P>
-__global__ void __launch_bounds__(256) k_conv_df_mfma(const float *__restrict__ I, const float *__restrict__ DO,
-                                                      float *__restrict__ part,
-                                                      int N, int H1, int W1, int C1, int H0, int W0, int C0,
-                                                      int rows_per_wave) {
+__device__ __forceinline__ void conv_df_body(const float *__restrict__ I, const float *__restrict__ DO,
+                                             float *__restrict__ part,
+                                             int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                                             int rows_per_wave, int bx, int by, int bz) {
     __shared__ float red[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ntaps = C1 * K * K;                           // row `ntaps` is the bias row (all ones)
-    const int tap = blockIdx.y * 32 + l31;
-    const int co  = blockIdx.z * 32 + l31;
+    const int tap = by * 32 + l31;
+    const int co  = bz * 32 + l31;
     int c1 = 0, ky = 0, kx = 0;
     const bool is_tap = tap < ntaps, is_bias = tap == ntaps;
     if (is_tap) { kx = tap % K; ky = (tap / K) % K; c1 = tap / (K * K); }
     const bool cok = co < C0;
     const int rows = N * H0;
-    const int row_beg = (blockIdx.x * 4 + w) * rows_per_wave;
+    const int row_beg = (bx * 4 + w) * rows_per_wave;
     const int row_end = min(rows, row_beg + rows_per_wave);
 
     f32x16 acc;
@@ -201,24 +208,43 @@ __global__ void __launch_bounds__(256) k_conv_df_mfma(const float *__restrict__ 
     const int nrow1 = ntaps + 1;
     for (int e = tid; e < 1024; e += 256) {
         const int tr = e >> 5, tc = e & 31;
-        const int gt = blockIdx.y * 32 + tr, gc = blockIdx.z * 32 + tc;
+        const int gt = by * 32 + tr, gc = bz * 32 + tc;
         if (gt < nrow1 && gc < C0)
-            part[((long)blockIdx.x * nrow1 + gt) * C0 + gc] = (red[0][tr][tc] + red[1][tr][tc]) + (red[2][tr][tc] + red[3][tr][tc]);
+            part[((long)bx * nrow1 + gt) * C0 + gc] = (red[0][tr][tc] + red[1][tr][tc]) + (red[2][tr][tc] + red[3][tr][tc]);
     }
+}
+template <int K, int S, int P>
+__global__ void __launch_bounds__(256) k_conv_df_mfma(const float *__restrict__ I, const float *__restrict__ DO, float *__restrict__ part,
+                                                      int N, int H1, int W1, int C1, int H0, int W0, int C0, int rows_per_wave) {
+    conv_df_body<K, S, P>(I, DO, part, N, H1, W1, C1, H0, W0, C0, rows_per_wave, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 // fold the slabs: DF[i] += sum_slice part[slice][i], DB likewise.  One wave per output: lane l adds slices l, l+64, ...
 // (all loads of a lane are independent), then a fixed xor-tree across the wave => deterministic, and the
 // ~1000 slices of a LeNet-size layer are summed in two load rounds instead of a 200-deep dependent chain.
-__global__ void __launch_bounds__(256) k_conv_df_fold(const float *__restrict__ part, float *DF, float *DB,
-                                                      int nslice, int ndf, int ntot) {
+__device__ __forceinline__ void conv_df_fold_body(const float *__restrict__ part, float *DF, float *DB, int nslice, int ndf, int ntot, int bx) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + w;
+    const int i = bx * 4 + w;
     if (i >= ntot) return;
     float s = 0.f;
 #pragma unroll 4
     for (int k = lane; k < nslice; k += 64) s += part[(long)k * ntot + i];
     s = wave_sum_all(s);
     if (lane == 0) { if (i < ndf) DF[i] += s; else DB[i - ndf] += s; }
+}
+__global__ void __launch_bounds__(256) k_conv_df_fold(const float *__restrict__ part, float *DF, float *DB,
+                                                      int nslice, int ndf, int ntot) {
+    conv_df_fold_body(part, DF, DB, nslice, ndf, ntot, blockIdx.x);
+}
+// The dF fold and the layer's dX are independent once the dF partials exist, so they share a launch: the first nfold
+// workgroups fold, the rest run the dX implicit GEMM (hx x hy grid, linearised).  dX may now overwrite the layer input
+// (DX2 = I, the reference's `in = dx`): the dF kernel that read I finished with the previous launch.
+template <int K, int S, int P>
+__global__ void __launch_bounds__(256) k_conv_dx_and_fold(const float *__restrict__ part, float *DF, float *DB, int nslice, int ndf, int ntot, int nfold,
+                                                          const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2, const float *__restrict__ F,
+                                                          int N, int H1, int W1, int C1, int H0, int W0, int C0, int hx, int ppc) {
+    const int b = blockIdx.x;
+    if (b < nfold) conv_df_fold_body(part, DF, DB, nslice, ndf, ntot, b);
+    else { const int b2 = b - nfold; conv_gemm_body<K, S, P, true>(DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, ppc, b2 % hx, b2 / hx); }
 }
 
 // ------------------------------------------------------------------ generic column sums (dlinear_db)
@@ -439,14 +465,14 @@ void launch_conv_few(int K, hipStream_t hs, const float *X, float *Y, float *Y2,
 // CO accumulators, reads the C0 contiguous gradients of each tap's output pixel (adjacent lanes = adjacent pixels, so a
 // wave streams a contiguous span of dO) and takes the flipped filter (nmath.tcu:304-324) from LDS at a wave-uniform address.
 template <int K, int S, int P, int CO>
-__global__ void __launch_bounds__(256) k_conv_dx_few(const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2,
-                                                     const float *__restrict__ F, int N, int H0, int W0, int C0, int H1, int W1) {
+__device__ __forceinline__ void conv_dx_few_body(const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2,
+                                                 const float *__restrict__ F, int N, int H0, int W0, int C0, int H1, int W1, int bx, int gx) {
     __shared__ float Fl[LDS_FILTER_FLOATS];
     const int nF = CO * K * K * C0;
     for (int e = threadIdx.x; e < nF; e += 256) Fl[e] = F[e];
     __syncthreads();
     const long npix = (long)N * H1 * W1;
-    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
+    for (long pix = (long)bx * 256 + threadIdx.x; pix < npix; pix += (long)gx * 256) {
         const int x = (int)(pix % W1); long t = pix / W1; const int y = (int)(t % H1); const int n = (int)(t / H1);
         float acc[CO];
 #pragma unroll
@@ -485,17 +511,26 @@ __global__ void __launch_bounds__(256) k_conv_dx_few(const float *__restrict__ D
         for (int c = 0; c < CO; c++) { DX[pix * CO + c] = acc[c]; if (DX2) DX2[pix * CO + c] = acc[c]; }
     }
 }
+// optional fold of the same layer's dF partials in the first `nfold` workgroups (see k_conv_dx_and_fold)
+struct FoldArgs { const float *part; float *DF, *DB; int nslice, ndf, ntot, nfold; };
+template <int K, int S, int P, int CO>
+__global__ void __launch_bounds__(256) k_conv_dx_few(const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2,
+                                                     const float *__restrict__ F, int N, int H0, int W0, int C0, int H1, int W1, FoldArgs fa) {
+    const int b = blockIdx.x;
+    if (b < fa.nfold) conv_df_fold_body(fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot, b);
+    else conv_dx_few_body<K, S, P, CO>(DO, DX, DX2, F, N, H0, W0, C0, H1, W1, b - fa.nfold, (int)gridDim.x - fa.nfold);
+}
 template <int CO>
 void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, float *DX, float *DX2, const float *F,
-                        int N, int H0, int W0, int C0, int H1, int W1) {
+                        int N, int H0, int W0, int C0, int H1, int W1, FoldArgs fa) {
     const long npix = (long)N * H1 * W1;
     long gx = (npix + 255) / 256; if (gx > 8192) gx = 8192;
-    const dim3 g((unsigned)gx), b(256);
+    const dim3 g((unsigned)gx + fa.nfold), b(256);
     switch ((K << 8) | (S << 4) | P) {
-    case 0x110: hipLaunchKernelGGL((k_conv_dx_few<1, 1, 0, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
-    case 0x311: hipLaunchKernelGGL((k_conv_dx_few<3, 1, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
-    case 0x421: hipLaunchKernelGGL((k_conv_dx_few<4, 2, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
-    case 0x512: hipLaunchKernelGGL((k_conv_dx_few<5, 1, 2, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+    case 0x110: hipLaunchKernelGGL((k_conv_dx_few<1, 1, 0, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+    case 0x311: hipLaunchKernelGGL((k_conv_dx_few<3, 1, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+    case 0x421: hipLaunchKernelGGL((k_conv_dx_few<4, 2, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+    case 0x512: hipLaunchKernelGGL((k_conv_dx_few<5, 1, 2, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
     }
 }
 
@@ -582,6 +617,7 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
     if (!I || !DO || !F || N <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: bad argument");
     if ((DF == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_conv2d_bwd: DF and DB go together");
     hipStream_t hs = t4k::S(s);
+    FoldArgs fa = { nullptr, nullptr, nullptr, 0, 0, 0, 0 };
     if (train && DF) {                                  // DF == NULL: dX only (the caller runs dF|dB on another stream)
         // dF | dB first: they read I, which the host layer may let DX overwrite
         const int ntaps = C1 * K * K, nrow1 = ntaps + 1;
@@ -604,23 +640,40 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         case 0x512: hipLaunchKernelGGL((k_conv_df_mfma<5, 1, 2>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
         }
         const int ntot = nrow1 * C0;
-        hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, part, DF, DB, nslice, ntaps * C0, ntot);
+        fa.part = part; fa.DF = DF; fa.DB = DB; fa.nslice = nslice; fa.ndf = ntaps * C0; fa.ntot = ntot; fa.nfold = (ntot + 3) / 4;
         }
     }
-    if (DX && C1 <= 4 && C1 * K * K * C0 <= LDS_FILTER_FLOATS) {   // image-input layer: direct kernel, one thread per input pixel
+    int fG = 0, fNG = 0;
+    const bool dx_few = DX && C1 <= 4 && C1 * K * K * C0 <= LDS_FILTER_FLOATS;
+    const bool dx_fewch = DX && !dx_few && conv_few_on() && conv_few_ok(K, C0, C1, &fG, &fNG);
+    if (fa.nfold && (!DX || dx_fewch)) {                 // no dX kernel to share a launch with: fold on its own
+        hipLaunchKernelGGL(k_conv_df_fold, dim3(fa.nfold), dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot);
+        fa.nfold = 0;
+    }
+    if (dx_few) {                                       // image-input layer: direct kernel, one thread per input pixel (+ the fold)
         switch (C1) {
-        case 1: launch_conv_dx_few<1>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
-        case 2: launch_conv_dx_few<2>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
-        case 3: launch_conv_dx_few<3>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
-        default: launch_conv_dx_few<4>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1); break;
+        case 1: launch_conv_dx_few<1>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+        case 2: launch_conv_dx_few<2>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+        case 3: launch_conv_dx_few<3>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+        default: launch_conv_dx_few<4>(K, S, P, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
         }
-    } else if (int fG = 0, fNG = 0; DX && conv_few_on() && conv_few_ok(K, C0, C1, &fG, &fNG)) {
+    } else if (dx_fewch) {
         launch_conv_few<true>(K, hs, DO, DX, DX2, nullptr, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, fG, fNG);
     } else if (DX) {                                    // DX == NULL: dF|dB only; DX2 = optional second copy from the same launch
         const long npix1 = (long)N * H1 * W1;
-        dim3 g((unsigned)((npix1 + 127) / 128), (unsigned)((C1 + 31) / 32));
-        // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1)
-        launch_conv_gemm<true>(K, S, P, g, hs, DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0);
+        const int hx = (int)((npix1 + 127) / 128), hy = (C1 + 31) / 32;
+        // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1); the dF fold rides along
+        const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);
+        const dim3 g((unsigned)(fa.nfold + hx * hy));
+#define DXF(k, s_, p_) hipLaunchKernelGGL((k_conv_dx_and_fold<k, s_, p_>), g, dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot, fa.nfold, \
+                                          DO, DX, DX2, F, N, H1, W1, C1, H0, W0, C0, hx, ppc)
+        switch ((K << 8) | (S << 4) | P) {
+        case 0x110: DXF(1, 1, 0); break;
+        case 0x311: DXF(3, 1, 1); break;
+        case 0x421: DXF(4, 2, 1); break;
+        case 0x512: DXF(5, 1, 2); break;
+        }
+#undef DXF
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;
