@@ -45,6 +45,9 @@ struct GemmP {
     float alpha, beta;
     int pair;                          // 1: two workgroups per tile (K halves) combine in the epilogue, no fold launch
     int *sync;                         // [0,2048) tickets, [2048,4096) flags (self-cleaning)
+    // optional rider (generic 64x64 kernel only): workgroups beyond the tile grid add the column sums of a [rows, E] matrix
+    // into cs_out - the bias gradient of a linear layer shares the launch of its weight-gradient GEMM
+    const float *cs_X; float *cs_out; int cs_rows, cs_E;
 };
 
 // FULL: every tile is interior (M%BM == N%BN == K-slice%BK == 0, VEC): no predicates, no branches in
@@ -66,6 +69,18 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 
     // ---- XCD-aware, L2-friendly tile order ----
     const int T = p.tiles_m * p.tiles_n;
+    if ((int)blockIdx.x >= T) {                    // rider workgroups: cs_out[e] += sum_r cs_X[r, e] (k_dlinear_db nmath.cu:274-280)
+        const int ex = tid & 63, ry = tid >> 6, e = ((int)blockIdx.x - T) * 64 + ex;
+        float a = 0.f;
+        if (e < p.cs_E) {
+#pragma unroll 8
+            for (int r = ry; r < p.cs_rows; r += 4) a += p.cs_X[(long)r * p.cs_E + e];
+        }
+        lds[ry * 64 + ex] = a;
+        __syncthreads();
+        if (ry == 0 && e < p.cs_E) p.cs_out[e] += (lds[ex] + lds[64 + ex]) + (lds[128 + ex] + lds[192 + ex]);
+        return;
+    }
     int L;
     {
         const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
@@ -767,8 +782,10 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
     return v;
 }
 
+struct ColSum { const float *X; float *out; int rows, E; bool done; };
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,
-                int tA, int tB, int M, int N, int K, int C, t4k_stream_t s, const ActEpi *epi = nullptr, bool *epi_done = nullptr) {
+                int tA, int tB, int M, int N, int K, int C, t4k_stream_t s, const ActEpi *epi = nullptr, bool *epi_done = nullptr,
+                ColSum *cs = nullptr) {
     if (epi_done) *epi_done = false;
     if (!A || !B || !O || M < 0 || N < 0 || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_gemm: bad argument");
     if (M == 0 || N == 0) return T4K_OK;
@@ -810,6 +827,15 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
 
     dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)C);
     hipStream_t hs = S(s);
+    p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+    {   // column-sum rider: only the generic kernel carries it, and only when one workgroup per tile writes the output
+        const bool full64 = !big && vec && M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
+        const bool generic = big || !vec || !(full64 && (var & 4));
+        if (cs && generic && nsplit == 1 && C == 1 && cs->rows > 0 && cs->rows <= 4096 && cs->E > 0) {
+            p.cs_X = cs->X; p.cs_out = cs->out; p.cs_rows = cs->rows; p.cs_E = cs->E; cs->done = true;
+            grid.x += (unsigned)((cs->E + 63) / 64);
+        }
+    }
     if (big) {
         const bool full = vec && M % 128 == 0 && N % 128 == 0 && kchunk % 32 == 0 && K % kchunk == 0;
         if (full)     launch_variant<128, 128, 32, true, true, true>(p, grid, tA, tB, hs);
@@ -905,9 +931,10 @@ int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, f
     if ((DW == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_linear_bwd: DW and DB go together");
     if (N > 0 && linear_small_ok(E0, E1) && linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, S(s))) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (train && DW) {                                  // DW == NULL: dX only (the caller forks dW|dB to another stream)
-        int rc = colsum_add(DY, DB, N, E0, S(s)); if (rc) return rc;              // dB += sum_n dY
-        rc = gemm_launch(DY, X, DW, nullptr, 1.0f, 1.0f, 1, 0, E0, E1, N, 1, s);  // dW += dY^T @ X
+        ColSum cs = { DY, DB, N, E0, false };           // dB += sum_n dY rides in the dW launch when the generic kernel runs it
+        int rc = gemm_launch(DY, X, DW, nullptr, 1.0f, 1.0f, 1, 0, E0, E1, N, 1, s, nullptr, nullptr, &cs);   // dW += dY^T @ X
         if (rc) return rc;
+        if (!cs.done) { rc = colsum_add(DY, DB, N, E0, S(s)); if (rc) return rc; }
     }
     if (!DX) return T4K_OK;                             // DX == NULL: dW|dB only
     return gemm_launch(DY, W, DX, nullptr, 1.0f, 0.0f, 0, 0, N, E1, E0, 1, s);   // dX = dY @ W (may overwrite X)
