@@ -274,6 +274,10 @@ int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float
  * DX == NULL computes dW|dB only, DW == DB == NULL computes dX only. */
 int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX,
                    float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
+/* same, plus the backward of a mask-multiply layer (dropout, relu, ...) that sits in front of this linear layer:
+ * DXM = DX (*) MASK (`in = out * mask`, _bactivate backprop.cu:256-263); MASK == DXM == NULL behaves as t4k_linear_bwd */
+int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, const float *MASK, float *DXM,
+                    float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
 /* multi-tensor optimizer step over a parameter table (one launch for all layers).
  * tab_dev: array of n_tensors records {G, DG, M, V, n, Nw} on the device. */
 typedef struct { float *G, *DG, *M, *V; long n; int Nw; int pad; } t4k_param_rec;

@@ -141,6 +141,11 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
     if (layer == T4K_L_DROPOUT) t4o_rand(F, (long)N * E0, T4K_UNIFORM, 0.0f, 1.0f);
     return rc(t4o_activate(layer, Y, A, F, alpha, (long)N * E0), "k_activate");
 }
+int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, const float *MASK, float *DXM, float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t st) {
+    int r = t4k_linear_bwd(X, W, DY, DX, DW, DB, N, E0, E1, tr, st); if (r) return r;
+    if (DXM) return rc(t4o_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1), "k_tt_op");
+    return T4K_OK;
+}
 int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, t4k_stream_t st) {
     int r = t4k_linear_fwd(X, W, B, Y, N, E0, E1, st); if (r) return r;
     return t4o_softmax(Y, P, N, E0);

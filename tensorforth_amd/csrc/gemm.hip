@@ -874,7 +874,8 @@ int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
 // linear_small.hip: classifier-head sized layers on the vector ALUs, one launch each way
 bool linear_small_ok(int E0, int E1);
 int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs);
-bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, bool train, hipStream_t hs);
+bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, bool train, hipStream_t hs,
+                      const float *MASK = nullptr, float *DXM = nullptr);
 }
 
 extern "C" {
@@ -927,9 +928,21 @@ int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float
 // Model::_blinear src/nn/backprop.cu:193-254
 int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
                    int N, int E0, int E1, int train, t4k_stream_t s) {
+    return t4k_linear_bwd2(X, W, DY, DX, nullptr, nullptr, DW, DB, N, E0, E1, train, s);
+}
+// same, plus the mask-multiply backward of the element-wise layer in front of this linear layer (dropout, relu, ...):
+// DXM = DX (*) MASK (`in = out * mask`, _bactivate backprop.cu:256-263) from the same launch when the head is small
+int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, const float *MASK, float *DXM, float *DW, float *DB,
+                    int N, int E0, int E1, int train, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
+    if ((MASK == nullptr) != (DXM == nullptr) || (DXM && !DX)) return fail(T4K_ERR_ARG, "t4k_linear_bwd2: MASK and DXM go together (with DX)");
+    if (DXM && !(N > 0 && linear_small_ok(E0, E1))) {    // large layer: the GEMM path, then the mask multiply on its own
+        int rc = t4k_linear_bwd2(X, W, DY, DX, nullptr, nullptr, DW, DB, N, E0, E1, train, s); if (rc) return rc;
+        return t4k_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1, s);
+    }
     if ((DW == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_linear_bwd: DW and DB go together");
-    if (N > 0 && linear_small_ok(E0, E1) && linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, S(s))) { T4K_LAUNCH_CHECK(); return T4K_OK; }
+    if (N > 0 && linear_small_ok(E0, E1) && linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, S(s), MASK, DXM)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
+    if (DXM) { int rc = t4k_linear_bwd2(X, W, DY, DX, nullptr, nullptr, DW, DB, N, E0, E1, train, s); if (rc) return rc; return t4k_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1, s); }
     if (train && DW) {                                  // DW == NULL: dX only (the caller forks dW|dB to another stream)
         ColSum cs = { DY, DB, N, E0, false };           // dB += sum_n dY rides in the dW launch when the generic kernel runs it
         int rc = gemm_launch(DY, X, DW, nullptr, 1.0f, 1.0f, 1, 0, E0, E1, N, 1, s, nullptr, nullptr, &cs);   // dW += dY^T @ X

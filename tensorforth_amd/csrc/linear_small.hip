@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(256) k_linsmall_fwd(const float *__restrict__ 
 // blocks [0, nB): dW | dB for output row e0 = blockIdx.x; blocks [nB, nB+nA): dX for RA rows each
 __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const float *__restrict__ W, const float *__restrict__ DY,
                                                       float *DX, float *DW, float *DB, int N, int E0, int E1,
-                                                      int nB, int nA, int RA, int *sync, int alias) {
+                                                      int nB, int nA, int RA, int *sync, int alias,
+                                                      const float *__restrict__ MASK, float *__restrict__ DXM) {
     extern __shared__ float sm[];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < nB) {
@@ -140,7 +141,14 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int z = tid + q * 256;
-        if (z < total) { const int r = z / E1, n = row0 + r; if (n < N) DX[(long)n * E1 + (z - r * E1)] = out[q]; }
+        if (z < total) {
+            const int r = z / E1, n = row0 + r;
+            if (n < N) {
+                const long o = (long)n * E1 + (z - r * E1);
+                DX[o] = out[q];
+                if (DXM) DXM[o] = out[q] * MASK[o];             // the mask-multiply backward of the layer in front (dropout / relu ...)
+            }
+        }
     }
     if (alias) {                                                 // last dX workgroup re-arms the counters for the next launch
         __syncthreads();
@@ -183,7 +191,7 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
 
 // returns false when the shape does not qualify (caller falls back to the GEMM path)
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
-                      int N, int E0, int E1, bool train, hipStream_t hs) {
+                      int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM) {
     const int nB = (train && DW) ? E0 : 0;
     int RA = 1024 / E1; if (RA > 64) RA = 64; if (RA < 1) RA = 1;        // rows of dX per workgroup (<= 1024 outputs, <= 64 rows of dY in LDS)
     const int nA = DX ? (N + RA - 1) / RA : 0;
@@ -196,7 +204,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, g.d_sync + 4090, alias ? 1 : 0);
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, g.d_sync + 4090, alias ? 1 : 0, MASK, DXM);
     return true;
 }
 

@@ -432,6 +432,16 @@ void Model::run_backward(Tensor &tgt) {
             }
         }
         dy = bstep(i, in, o, dy, j == 0);
+        if (skip_next_) {                               // bstep also ran the backward of op i-1 (a lone mask-multiply layer)
+            skip_next_ = false;
+            if (grad_hook && train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns) {
+                const long off = (long)(in.grad[2]->data - gslab->data);
+                const long end = (long)(in.grad[3]->data - gslab->data) + (long)((in.grad[3]->numel + 63) & ~(uint64_t)63);
+                grad_hook(i, off, end - off, grad_hook_user);
+            }
+            dy = at(i - 1).data; i--; j++;
+            continue;
+        }
         if (grad_hook && train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns) {
             const long off = (long)(in.grad[2]->data - gslab->data);
             const long end = (long)(in.grad[3]->data - gslab->data) + (long)((in.grad[3]->numel + 63) & ~(uint64_t)63);
@@ -468,6 +478,16 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
         const int N = in.N(), E0 = (int)out.HWC(), E1 = (int)in.HWC();
         Tensor *gx = concurrent() ? gx_[i] : nullptr;
         if (!gx) {                                      // single stream: reference order (dW reads X, then dX overwrites it)
+            // a lone mask-multiply layer (dropout, relu, ...) right in front of this linear layer: its backward rides along
+            const bool fused = use_fusion && !(trace && *trace);
+            if (fused && i > 0 && run_of_[i - 1] >= 0 && runs_[run_of_[i - 1]].count == 1 && !runs_[run_of_[i - 1]].blk.pool_layer &&
+                runs_[run_of_[i - 1]].blk.pre_layer) {
+                Tensor &prev = at(i - 1);
+                chk(t4k_linear_bwd2(in.data, in.grad[0]->data, dy, in.data, prev.grad[4]->data, prev.data, train ? in.grad[2]->data : nullptr,
+                                    train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#blinear+act");
+                skip_next_ = true;
+                return in.data;
+            }
             chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, in.data, in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#blinear");
             return in.data;
         }
