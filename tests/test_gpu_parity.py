@@ -532,3 +532,24 @@ def test_small_linear_head_is_bit_identical_to_oracle(t4k, dev, oracle, N, E0, E
     dXc = dev.up(X)
     t4k.call("t4k_linear_bwd", p(dXc), p(dW), p(dG), p(dXc), p(dDW2), p(dDB2), N, E0, E1, 1, None)   # aliasing again
     assert np.array_equal(dev.down(dXc), DX)
+
+
+# ----------------------------------------------------------------------------- error behaviour (reference: print-and-continue, never abort)
+def test_error_paths_return_status_and_reference_messages(t4k, dev):
+    """Unsupported geometry / bad arguments come back as negative status codes with the reference's own message text
+    (forward.cu:149-151, backprop.cu:181-183, model.cpp:262) in t4k_last_error(); nothing throws or aborts."""
+    lib = t4k.lib
+    ARG, UNSUP = -1, -4                                  # T4K_ERR_ARG, T4K_ERR_UNSUPPORTED (include/t4k.h)
+    x = dev.zeros((2, 8, 8, 3)); y = dev.zeros((2, 8, 8, 4)); f = dev.zeros((3, 2, 2, 4)); b = dev.zeros(4)
+    rc = lib.t4k_conv2d_fwd(p(x), p(y), p(f), p(b), 2, 8, 8, 3, 8, 8, 4, 2, 1, 0, None)
+    assert rc == UNSUP and b"nn#fconv kernel_size=2 stride=1 padding=0 not supported" in lib.t4k_last_error()
+    rc = lib.t4k_conv2d_bwd(p(x), p(y), p(x), p(f), p(f), p(b), 2, 8, 8, 3, 8, 8, 4, 3, 2, 1, 1, None)
+    assert rc == UNSUP and b"nn#bconv kernel_size=3 stride=2 padding=1 not supported" in lib.t4k_last_error()
+    assert lib.t4k_pool(14, p(x), p(y), 2, 8, 8, 2, 2, 3, 4, None) == UNSUP and b"kernel_size=4" in lib.t4k_last_error()
+    assert lib.t4k_gemm(None, p(x), p(y), 1.0, 0.0, 0, 0, 4, 4, 4, 1, None) == ARG             # T4K_ERR_ARG
+    assert lib.t4k_math(99, p(x), 0.0, 10, None) == UNSUP                                         # unknown math_op
+    assert lib.t4k_linear_bwd(p(x), p(f), p(y), p(x), p(f), None, 2, 4, 3, 1, None) == ARG     # dW without dB
+    assert lib.t4k_allreduce_sum(p(x), 16, None) == UNSUP or lib.t4k_comm_world() > 0            # no communicator attached
+    # the library is still healthy afterwards
+    t4k.call("t4k_math", 12, p(x), 2.0, x.numel(), None)                                       # FILL
+    assert float(dev.down(x).sum()) == 2.0 * x.numel()
