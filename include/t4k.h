@@ -167,8 +167,9 @@ int t4k_logdet(const float *LU, int K, float *logdet_dev, int *sign_dev, t4k_str
 /* ------------------------------------------------------- RNG (util.cu:28-70) */
 /* Counter-based Philox4x32-10 replaces the reference's 1024 cuRAND XORWOW states
  * (distribution parity only; the reference seeds from time(), sys.cpp:37). */
-/* The stream state (seed, counter) is DEVICE resident: a t4k_rand captured in a graph draws a fresh
- * slice on every replay; t4k_rand_offset()/set_offset() synchronise and read/write that state. */
+/* The host keeps the stream position (seed, counter): an eager draw gets its slice as kernel arguments.  Draws recorded
+ * between t4k_graph_begin/end read a device copy instead and advance it themselves, so every replay gets a fresh slice;
+ * t4k_graph_launch keeps host and device positions in step.  t4k_rand_offset()/set_offset() are host-only and cheap. */
 int t4k_rand_init(uint64_t seed);
 /* d[i] = scale * (bias + u_i), u uniform (0,1] or N(0,1) (util.cu:58-70) */
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s);

@@ -19,7 +19,7 @@ struct PB {                                   // device copy of t4k_poolblock + 
     const float *X; float *P, *Q, *R, *R2, *Fpre, *Fpost;
     int pre, pool, post; float a_pre, a_post;
     int N, H1, W1, H0, W0, C;
-    uint64_t *rng;
+    RngArg rng;
 };
 
 // VW channels per thread (1, 2 or 4; C % VW == 0 and 4*VW-byte aligned tensors): vector loads / stores, and one
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
     const long total = (long)p.N * p.H0 * p.W0 * CV;
     uint64_t base = 0, seed = 0;
     const bool draw = p.pre == T4K_L_DROPOUT;
-    if (draw) rng_state_read(p.rng, base, seed);
+    if (draw) rng_begin(p.rng, base, seed);
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
         const int c = (int)(z % CV) * VW; long t = z / CV;
         const int j0 = (int)(t % p.W0); t /= p.W0;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
         }
         if (p.R2) vstore<VW>(p.R2 + zo, acc);
     }
-    if (draw) rng_advance_last_block(p.rng, base, (uint64_t)(((long)p.N * p.H1 * p.W1 * p.C + 3) >> 2));
+    if (draw && p.rng.state) rng_advance_last_block(p.rng.state, base, (uint64_t)(((long)p.N * p.H1 * p.W1 * p.C + 3) >> 2));
 }
 
 // backward: DY = gradient w.r.t. the run's last tensor.  Writes (reference in-place convention: each layer's
@@ -205,12 +205,12 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
     int rc = check_block(b, "t4k_poolblock_fwd"); if (rc) return rc;
     if (!X) return fail(T4K_ERR_ARG, "t4k_poolblock_fwd: null input");
     const long total = (long)N * H0 * W0 * C; if (total <= 0) return T4K_OK;
-    State &g = st();
-    if (b->pre_layer == T4K_L_DROPOUT && !g.d_rng) { rc = t4k_rand_init(0); if (rc) return rc; }
     PB p;
     p.X = X; p.P = b->pre_out; p.Q = b->pool_out; p.R = b->post_out; p.R2 = b->copy_out; p.Fpre = b->pre_mask; p.Fpost = b->post_mask;
     p.pre = b->pre_layer; p.pool = b->pool_layer; p.post = b->post_layer; p.a_pre = b->pre_alpha; p.a_post = b->post_alpha;
-    p.N = N; p.H1 = H1; p.W1 = W1; p.H0 = H0; p.W0 = W0; p.C = C; p.rng = g.d_rng;
+    p.N = N; p.H1 = H1; p.W1 = W1; p.H0 = H0; p.W0 = W0; p.C = C;
+    p.rng = RngArg{0, 0, nullptr};
+    if (b->pre_layer == T4K_L_DROPOUT) p.rng = rng_draw(S(s), (uint64_t)(((long)N * H1 * W1 * C + 3) >> 2));
     const int VW = vec_width(C, X, b);
     const dim3 grid(grid_for(total / VW)), blk(BLK);
 #define PBF(KS_) do { if (VW == 4) hipLaunchKernelGGL((k_poolblock_fwd<KS_, 4>), grid, blk, 0, S(s), p); \

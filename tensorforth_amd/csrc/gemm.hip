@@ -726,12 +726,12 @@ void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
 // Optional activation epilogue (the layer that follows a linear layer: relu / tanh / ... / dropout): O keeps the linear
 // output, ACT_O / ACT_F receive the activation output and derivative mask (k_activate nmath.cu:37-70); dropout draws its
 // Philox slice here, exactly the values t4k_rand would have stored in the mask tensor.
-struct ActEpi { int layer; float alpha; float *F, *A; uint64_t *rng; };
+struct ActEpi { int layer; float alpha; float *F, *A; RngArg rng; };
 __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ part, float *O, long mn, int nsplit,
                                                      float alpha, float beta, const float *__restrict__ bias, int N, ActEpi ep) {
     uint64_t base = 0, seed = 0;
     const bool draw = ep.layer == T4K_L_DROPOUT;
-    if (draw) rng_state_read(ep.rng, base, seed);
+    if (draw) rng_begin(ep.rng, base, seed);
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < mn; z += (long)gridDim.x * BLK) {
         float s = 0.f;
 #pragma unroll 4
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ p
         O[z] = o;
         if (ep.layer) { float a, f; act_rt(ep.layer, o, draw ? philox_u01_at(base, seed, z) : 0.f, ep.alpha, a, f); ep.F[z] = f; ep.A[z] = a; }
     }
-    if (draw) rng_advance_last_block(ep.rng, base, (uint64_t)((mn + 3) >> 2));
+    if (draw && ep.rng.state) rng_advance_last_block(ep.rng.state, base, (uint64_t)((mn + 3) >> 2));
 }
 
 // words gemm1/gemm2 (k_gemm src/t4math.cu:370, k_gemm_claude :411): double accumulator
@@ -859,8 +859,11 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     }
     if (nsplit > 1 && !p.pair) {
         const long mn = (long)M * N;
-        ActEpi ep = {0, 0.f, nullptr, nullptr, nullptr};
-        if (epi && epi->layer) { ep = *epi; if (epi_done) *epi_done = true; }
+        ActEpi ep = {0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
+        if (epi && epi->layer) {
+            ep = *epi; if (epi_done) *epi_done = true;
+            if (ep.layer == T4K_L_DROPOUT) ep.rng = rng_draw(hs, (uint64_t)((mn + 3) >> 2));
+        }
         hipLaunchKernelGGL(k_splitk_fold, dim3(grid_for(mn)), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N, ep);
     }
     T4K_LAUNCH_CHECK();
@@ -900,12 +903,11 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
     T4K_REQUIRE_INIT();
     if (!X || !W || !Y || !ACT_F || !ACT_O || N < 0) return fail(T4K_ERR_ARG, "t4k_linear_act_fwd: bad argument");
     if (N == 0) return T4K_OK;
-    State &g = st();
-    if (layer == T4K_L_DROPOUT && !g.d_rng) { int rc = t4k_rand_init(0); if (rc) return rc; }
     bool done = false;
     if (linear_small_ok(E0, E1)) linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s));
     else {
-        ActEpi ep = { layer, alpha, ACT_F, ACT_O, g.d_rng };
+        // the mask's Philox slice is reserved only if the fold launch will really apply the epilogue (decided inside gemm_launch)
+        ActEpi ep = { layer, alpha, ACT_F, ACT_O, RngArg{0, 0, nullptr} };
         int rc = gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s, &ep, &done); if (rc) return rc;
     }
     if (!done) {

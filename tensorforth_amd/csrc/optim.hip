@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(BLK) k_opt_multi(int kind, const t4k_param_rec
 // d[i] = scale * (bias + u_i): element i <- Philox(counter = (off+i)/4)[i%4].
 // The stream state (counter, seed) is read from device memory and advanced by the last workgroup to
 // finish, so the same launch captured in a hipGraph draws a fresh slice of the stream on every replay.
-__global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float bias, float scale, uint64_t *state) {
-    uint64_t base, seed; rng_state_read(state, base, seed);
+__global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float bias, float scale, RngArg ra) {
+    uint64_t base, seed; rng_begin(ra, base, seed);
     const long nq = (n + 3) >> 2;
     for (long q = (long)blockIdx.x * BLK + threadIdx.x; q < nq; q += (long)gridDim.x * BLK) {
         uint32_t r[4]; float v[4];
@@ -93,10 +93,33 @@ __global__ void __launch_bounds__(BLK) k_rand(float *d, long n, int opt, float b
 #pragma unroll
         for (int k = 0; k < 4; k++) { const long i = q * 4 + k; if (i < n) d[i] = scale * (bias + v[k]); }
     }
-    rng_advance_last_block(state, base, (uint64_t)nq);
+    if (ra.state) rng_advance_last_block(ra.state, base, (uint64_t)nq);
 }
 
 } // namespace
+
+namespace t4k {
+__global__ void k_rng_seed_dev(uint64_t *state, uint64_t ctr, uint64_t seed) { state[0] = ctr; state[1] = 0; state[2] = seed; }
+// Reserve nq counters for one launch.  Eager: by-value (base, seed), host counter advances.  While a graph is being
+// captured: the launch reads the device copy instead and advances it itself; the host only totals the draw.
+RngArg rng_draw(hipStream_t hs, uint64_t nq) {
+    State &g = st();
+    RngArg a = { g.rng_ctr, g.seed, nullptr };
+    if (g.capturing) {
+        if (!g.d_rng) (void)hipMalloc((void **)&g.d_rng, 4 * sizeof(uint64_t));   // allocated by t4k_graph_begin normally
+        a.state = g.d_rng; g.cap_adv += nq;
+    } else g.rng_ctr += nq;
+    (void)hs;
+    return a;
+}
+// bring the device copy up to date on stream `hs` if it is stale (before a graph that draws is launched)
+void rng_sync_device(hipStream_t hs) {
+    State &g = st();
+    if (!g.d_rng || g.d_rng_ctr == g.rng_ctr) return;
+    hipLaunchKernelGGL(k_rng_seed_dev, dim3(1), dim3(1), 0, hs, g.d_rng, g.rng_ctr, g.seed);
+    g.d_rng_ctr = g.rng_ctr;
+}
+}
 
 extern "C" {
 
@@ -128,30 +151,14 @@ int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long ma
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
-static int rng_state_write(uint64_t ctr, const uint64_t *seed) {
-    State &g = st();
-    if (!g.d_rng) { T4K_HIP(hipMalloc((void **)&g.d_rng, 4 * sizeof(uint64_t))); T4K_HIP(hipMemset(g.d_rng, 0, 4 * sizeof(uint64_t))); }
-    T4K_HIP(hipDeviceSynchronize());
-    const uint64_t z[2] = { ctr, 0 };
-    T4K_HIP(hipMemcpy(g.d_rng, z, sizeof(z), hipMemcpyHostToDevice));
-    if (seed) T4K_HIP(hipMemcpy(g.d_rng + 2, seed, sizeof(uint64_t), hipMemcpyHostToDevice));
-    return T4K_OK;
-}
-int t4k_rand_init(uint64_t seed) { T4K_REQUIRE_INIT(); return rng_state_write(0, &seed); }
-uint64_t t4k_rand_offset(void) {                        // synchronous read-back of the device-resident counter
-    State &g = st();
-    if (!g.ready || !g.d_rng) return 0;
-    (void)hipDeviceSynchronize();
-    uint64_t c = 0; (void)hipMemcpy(&c, g.d_rng, sizeof(c), hipMemcpyDeviceToHost);
-    return c * 4;
-}
-int t4k_rand_set_offset(uint64_t off) { T4K_REQUIRE_INIT(); (void)hipDeviceSynchronize(); return rng_state_write(off / 4, nullptr); }
+int t4k_rand_init(uint64_t seed) { T4K_REQUIRE_INIT(); State &g = st(); g.seed = seed; g.rng_ctr = 0; g.d_rng_ctr = ~0ull; return T4K_OK; }
+uint64_t t4k_rand_offset(void) { return st().rng_ctr * 4; }
+int t4k_rand_set_offset(uint64_t off) { T4K_REQUIRE_INIT(); State &g = st(); g.rng_ctr = off / 4; g.d_rng_ctr = ~0ull; return T4K_OK; }
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!d) return fail(T4K_ERR_ARG, "t4k_rand: null");
-    State &g = st();
-    if (!g.d_rng) { uint64_t z = 0; int rc = rng_state_write(0, &z); if (rc) return rc; }
-    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), d, n, opt, bias, scale, g.d_rng);
+    const RngArg ra = rng_draw(S(s), (uint64_t)((n + 3) / 4));
+    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), d, n, opt, bias, scale, ra);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

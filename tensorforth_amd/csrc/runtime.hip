@@ -25,6 +25,9 @@ int hip_fail(hipError_t e, const char *what) {
 
 using namespace t4k;
 
+namespace t4k { void rng_sync_device(hipStream_t hs); }   // optim.hip
+namespace { struct GraphRec { hipGraphExec_t exec; uint64_t rng_adv; }; }
+
 extern "C" {
 
 int t4k_device_count(void) {
@@ -150,21 +153,39 @@ int t4k_event_destroy(t4k_event_t e) { T4K_REQUIRE_INIT(); if (e) T4K_HIP(hipEve
 
 int t4k_graph_begin(t4k_stream_t s) {
     T4K_REQUIRE_INIT();
+    State &g = st();
+    if (!g.d_rng) { T4K_HIP(hipMalloc((void **)&g.d_rng, 4 * sizeof(uint64_t))); T4K_HIP(hipMemset(g.d_rng, 0, 4 * sizeof(uint64_t))); g.d_rng_ctr = ~0ull; }
     T4K_HIP(hipStreamBeginCapture(S(s), hipStreamCaptureModeThreadLocal));
+    g.capturing = true; g.cap_adv = 0;                  // draws recorded from here on read / advance the device copy of the stream
     return T4K_OK;
 }
-int t4k_graph_end(t4k_stream_t s, t4k_graph_t *g) {
+int t4k_graph_end(t4k_stream_t s, t4k_graph_t *out) {
     T4K_REQUIRE_INIT();
+    State &g = st();
+    g.capturing = false;
     hipGraph_t graph = nullptr;
     T4K_HIP(hipStreamEndCapture(S(s), &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     T4K_HIP(e);
-    *g = (t4k_graph_t)exec;
+    *out = (t4k_graph_t) new GraphRec{ exec, g.cap_adv };   // remember how far one replay moves the Philox stream
     return T4K_OK;
 }
-int t4k_graph_launch(t4k_graph_t g, t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipGraphLaunch((hipGraphExec_t)g, S(s))); return T4K_OK; }
-int t4k_graph_destroy(t4k_graph_t g) { T4K_REQUIRE_INIT(); if (g) T4K_HIP(hipGraphExecDestroy((hipGraphExec_t)g)); return T4K_OK; }
+int t4k_graph_launch(t4k_graph_t h, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!h) return fail(T4K_ERR_ARG, "t4k_graph_launch: null graph");
+    GraphRec *r = (GraphRec *)h;
+    State &g = st();
+    if (r->rng_adv) rng_sync_device(S(s));               // the replay draws from the device copy: make it current first
+    T4K_HIP(hipGraphLaunch(r->exec, S(s)));
+    if (r->rng_adv) { g.rng_ctr += r->rng_adv; g.d_rng_ctr = g.rng_ctr; }   // the graph's kernels advance the device copy by the same amount
+    return T4K_OK;
+}
+int t4k_graph_destroy(t4k_graph_t h) {
+    T4K_REQUIRE_INIT();
+    if (h) { GraphRec *r = (GraphRec *)h; T4K_HIP(hipGraphExecDestroy(r->exec)); delete r; }
+    return T4K_OK;
+}
 
 } // extern "C"

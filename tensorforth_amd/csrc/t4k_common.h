@@ -19,8 +19,15 @@ struct State {
     bool        own_stream = false;
     void       *ws      = nullptr;     // device workspace (replaces per-tensor _tmp)
     size_t      ws_bytes = 0;
-    uint64_t   *d_rng   = nullptr;     // device: [0] Philox counter (element offset / 4), [1] ticket, [2] seed.  The
-                                       //   RNG state lives in HBM so a captured graph draws fresh numbers on every replay.
+    // Philox stream.  The HOST counter is authoritative: an eager launch gets (seed, counter) as kernel arguments and the
+    // host advances - no device state read, no arrival ticket at the end of the kernel.  Only launches recorded into a
+    // hipGraph read / advance the device copy d_rng ([0] counter, [1] ticket, [2] seed), so a replay draws fresh numbers;
+    // the host adds the graph's total advance at every t4k_graph_launch and re-seeds the device copy when it is stale.
+    uint64_t    seed = 0, rng_ctr = 0; // counter = element offset / 4
+    uint64_t   *d_rng   = nullptr;
+    uint64_t    d_rng_ctr = ~0ull;     // what the device copy holds (after pending stream work); ~0 = unknown
+    uint64_t    cap_adv = 0;           // counters drawn by the capture in progress
+    bool        capturing = false;
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
     int        *d_sync  = nullptr;     // 8192 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags + linear_small, [4096,8192) skinny split-K tickets
@@ -28,6 +35,9 @@ struct State {
     char        err[256] = {0};
 };
 State &st();
+// what a drawing kernel receives: eager = (base, seed) by value and state == nullptr; inside a graph = the device copy
+struct RngArg { uint64_t base, seed; uint64_t *state; };
+RngArg rng_draw(hipStream_t hs, uint64_t nq);    // host: reserve nq counters (4 elements each) of the stream for one launch (optim.hip)
 
 int  fail(int code, const char *fmt, ...);
 int  hip_fail(hipError_t e, const char *what);
@@ -137,6 +147,12 @@ __device__ __forceinline__ void rng_advance_last_block(uint64_t *state, uint64_t
             __hip_atomic_store(&state[0], base + nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+__device__ __forceinline__ void rng_begin(const RngArg &a, uint64_t &base, uint64_t &seed) {
+    if (a.state) {
+        base = __hip_atomic_load(&a.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seed = __hip_atomic_load(&a.state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { base = a.base; seed = a.seed; }
 }
 __device__ __forceinline__ void rng_state_read(const uint64_t *state, uint64_t &base, uint64_t &seed) {
     base = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
