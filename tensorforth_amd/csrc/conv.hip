@@ -19,6 +19,16 @@
 
 using namespace t4k;
 
+namespace t4k {                                   // conv_big.hip: LDS-staged MFMA GEMM tiling for many channels
+bool conv_big_ok(int Cin, int Cout);
+template <bool BWD>
+void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
+                     int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f);
+int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, const float *DO, float *part, size_t part_floats,
+                       int N, int H1, int W1, int C1, int H0, int W0, int C0);
+int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
+}
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -534,6 +544,7 @@ void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, fl
     }
 }
 
+bool conv_big_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_BIG"); v = e ? atoi(e) : 1; } return v != 0; }
 bool conv_few_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_FEW"); v = e ? atoi(e) : 1; } return v != 0; }
 bool conv_supported(int K, int S, int P) {
     return (K == 1 && S == 1 && P == 0) || (K == 3 && S == 1 && P == 1) ||
@@ -595,6 +606,11 @@ int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, cons
         return T4K_OK;
     }
     if (ICOPY) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, t4k::S(s)));
+    if (conv_big_on() && conv_big_ok(C1, C0) && aligned16(I) && aligned16(F)) {       // many channels: LDS-staged GEMM tiling
+        launch_conv_big<false>(K, S, P, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
+        T4K_LAUNCH_CHECK();
+        return T4K_OK;
+    }
     const long npix = (long)N * H0 * W0;
     dim3 g((unsigned)((npix + 127) / 128), (unsigned)((C0 + 31) / 32));
     launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
@@ -621,7 +637,16 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
     if (train && DF) {                                  // DF == NULL: dX only (the caller runs dF|dB on another stream)
         // dF | dB first: they read I, which the host layer may let DX overwrite
         const int ntaps = C1 * K * K, nrow1 = ntaps + 1;
-        {
+        int nbig = 0;
+        if (conv_big_on() && conv_big_ok(C1, C0) && aligned16(I) && aligned16(DO)) {     // many channels: split-K GEMM over pixel slices
+            nbig = launch_conv_big_df(K, S, P, hs, I, DO, ws_for(s), st().ws_bytes / 8, N, H1, W1, C1, H0, W0, C0);
+            if (nbig > 0) {
+                const int ntot = ntaps * C0;                      // no bias row in these slabs: dB is a plain column sum of dO
+                hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, ws_for(s), DF, DB, nbig, ntot, ntot);
+                int rc = colsum_add(DO, DB, (long)N * H0 * W0, C0, hs); if (rc) return rc;
+            }
+        }
+        if (nbig == 0) {
         const int rows = N * H0;
         // enough slices that ~2000 waves are in flight (each wave then issues only a few batches of loads) without
         // inflating the partial slab the fold has to read: 512 workgroups in total across the (tap, c0) tiles
@@ -644,6 +669,12 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         }
     }
     int fG = 0, fNG = 0;
+    if (DX && conv_big_on() && conv_big_ok(C0, C1) && aligned16(DO) && aligned16(F)) {  // many channels: LDS-staged GEMM tiling
+        if (fa.nfold) { hipLaunchKernelGGL(k_conv_df_fold, dim3(fa.nfold), dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot); fa.nfold = 0; }
+        launch_conv_big<true>(K, S, P, hs, DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0);
+        T4K_LAUNCH_CHECK();
+        return T4K_OK;
+    }
     const bool dx_few = DX && C1 <= 4 && C1 * K * K * C0 <= LDS_FILTER_FLOATS;
     const bool dx_fewch = DX && !dx_few && conv_few_on() && conv_few_ok(K, C0, C1, &fG, &fNG);
     if (fa.nfold && (!DX || dx_fewch)) {                 // no dX kernel to share a launch with: fold on its own

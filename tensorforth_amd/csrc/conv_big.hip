@@ -1,0 +1,303 @@
+// conv_big.hip - conv2d forward / dX / dF for MANY channels (Cin % 32 == 0, Cout % 4 == 0) as LDS-staged MFMA GEMMs.
+//
+// The gather kernels in conv.hip feed every MFMA with one predicated global float per lane; that is fine for the
+// 1..20-channel LeNet layers (latency bound anyway) but reaches only ~22 % of the fp32 MFMA peak at 64-128 channels.
+// Here the implicit GEMM is tiled exactly like the dense GEMM in gemm.hip (same LDS layouts, XOR swizzle, k-permuted
+// ds_read_b128, 2x2 waves of 32x32 MFMA blocks, double-buffered stages):
+//   forward  Y[pix, co]  = sum_{tap,ci} X[pix (+) tap, ci] * F[ci, tap, co]            A k-contiguous, B n-contiguous
+//   dX       dX[pix, c1] = sum_{tap,c0} dO[pix (-) tap, c0] * F[c1, K*K-1-tap, c0]     A k-contiguous, B k-contiguous
+//   dF       dF[ci, tap, co] += sum_pix X[pix (+) tap, ci] * dO[pix, co]               A m-contiguous, B n-contiguous,
+//            split over pixel slices, partial slabs folded in fixed order (k_conv_df_fold) - no fp32 atomics
+// One stage = 32 channels of ONE tap (Cin % 32 == 0), so the tap shift is uniform per stage and a thread's pixel rows
+// are decomposed into (n, y, x) once.  NHWC makes every operand row a contiguous 128-byte run: all global loads are
+// coalesced 16-byte loads, out-of-image taps load nothing and stage zeros.
+// Arithmetic restates k_conv2d / k_dconv2d (src/nn/nmath.tcu:34-104, 211-338) incl. the flipped-filter dX.
+#include "t4k_common.h"
+
+using namespace t4k;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32, CH = BK / 4, SW = 64 / BK, NC = BK / 8;
+
+struct CbP {
+    const float *X, *F, *B;            // X: forward input / dX: dO;  F: filter [C1][K][K][C0];  B: bias (forward only)
+    float *Y, *Y2;                     // output (+ optional second copy)
+    int N, Hx, Wx, Cin, Hy, Wy, Cout;  // gather grid (Hx, Wx, Cin) -> output grid (Hy, Wy, Cout)
+    int C0f;                           // filter inner dimension (reference C0)
+    int tiles_n;
+};
+
+// ------------------------------------------------------------------ forward / dX
+template <int K, int S, int P, bool BWD, int BN>
+__global__ void __launch_bounds__(256) k_convbig(CbP p) {
+    constexpr int BM = 128, MT = BM / 64, NT = BN / 64, KK = K * K;
+    constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sA = lds, *sB = lds + 2 * BM * BK;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int Cin = p.Cin, Cout = p.Cout;
+    const long npix = (long)p.N * p.Hy * p.Wy;
+    const int nst = KK * (Cin / BK);
+
+    // this thread's A rows (pixels) and 16-byte chunk within the stage's 32 channels
+    int py[PA], px[PA]; long pbase[PA]; bool pok[PA];
+    const int aq = tid % CH;
+#pragma unroll
+    for (int pp = 0; pp < PA; pp++) {
+        const long m = m0 + pp * (256 / CH) + tid / CH;
+        pok[pp] = m < npix;
+        const long mc = pok[pp] ? m : 0;
+        px[pp] = (int)(mc % p.Wy); const long t = mc / p.Wy; py[pp] = (int)(t % p.Hy);
+        pbase[pp] = (t / p.Hy) * (long)p.Hx * p.Wx;              // image base (pixels)
+    }
+    v4f ra[PA], rb[PB];
+    auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+        const int tap = kt / (Cin / BK), c0 = (kt - tap * (Cin / BK)) * BK;
+        const int ky = tap / K, kx = tap - ky * K;
+#pragma unroll
+        for (int pp = 0; pp < PA; pp++) {
+            int gi, gj; bool ok;
+            if (!BWD) { gi = py[pp] * S + ky - P; gj = px[pp] * S + kx - P; ok = gi >= 0 && gi < p.Hx && gj >= 0 && gj < p.Wx; }
+            else { const int ti = py[pp] + P - ky, tj = px[pp] + P - kx; gi = ti / S; gj = tj / S;
+                   ok = ti >= 0 && tj >= 0 && (ti % S) == 0 && (tj % S) == 0 && gi < p.Hx && gj < p.Wx; }
+            ok = ok && pok[pp];
+            const v4f z = {0.f, 0.f, 0.f, 0.f};
+            ra[pp] = ok ? *reinterpret_cast<const v4f *>(p.X + (pbase[pp] + (long)gi * p.Wx + gj) * Cin + c0 + aq * 4) : z;
+        }
+#pragma unroll
+        for (int pp = 0; pp < PB; pp++) {
+            const int id = pp * 256 + tid;
+            const v4f z = {0.f, 0.f, 0.f, 0.f};
+            if (!BWD) {                                          // B[k = ci][n = co] = F[ci][tap][co]: n-contiguous
+                const int kk = id / (BN / 4), rq = id % (BN / 4), n = n0 + rq * 4;
+                rb[pp] = (n < Cout) ? *reinterpret_cast<const v4f *>(p.F + ((long)(c0 + kk) * KK + tap) * p.C0f + n) : z;
+            } else {                                             // B[n = c1][k = c0] = F[c1][KK-1-tap][c0]: k-contiguous
+                const int r = id / CH, q = id % CH, n = n0 + r;
+                rb[pp] = (n < Cout) ? *reinterpret_cast<const v4f *>(p.F + ((long)n * KK + (KK - 1 - tap)) * p.C0f + c0 + q * 4) : z;
+            }
+        }
+    };
+    int soa[PA], sob[PB];
+#pragma unroll
+    for (int pp = 0; pp < PA; pp++) { const int id = pp * 256 + tid, r = id / CH, q = id % CH; soa[pp] = r * BK + ((q ^ ((r / SW) & (CH - 1))) << 2); }
+#pragma unroll
+    for (int pp = 0; pp < PB; pp++) {
+        const int id = pp * 256 + tid;
+        if (BWD) { const int r = id / CH, q = id % CH; sob[pp] = r * BK + ((q ^ ((r / SW) & (CH - 1))) << 2); }
+        else     sob[pp] = (id / (BN / 4)) * BN + (id % (BN / 4)) * 4;
+    }
+    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+        float *a = sA + buf * BM * BK, *b = sB + buf * BN * BK;
+#pragma unroll
+        for (int pp = 0; pp < PA; pp++) *reinterpret_cast<v4f *>(a + soa[pp]) = ra[pp];
+#pragma unroll
+        for (int pp = 0; pp < PB; pp++) *reinterpret_cast<v4f *>(b + sob[pp]) = rb[pp];
+    };
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    load_tiles(0); store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nst; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nst) load_tiles(kt + 1);                     // in flight during the MFMAs below
+        const float *a = sA + buf * BM * BK, *b = sB + buf * BN * BK;
+#pragma unroll
+        for (int ci = 0; ci < NC; ci++) {                         // lane half h holds k = 8*ci + 4*h + {0..3}
+            float av[MT][4], bv[NT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const int r = wm * (BM / 2) + mt * 32 + l31;
+                const v4f t = *reinterpret_cast<const v4f *>(a + r * BK + (((ci * 2 + h) ^ ((r / SW) & (CH - 1))) << 2));
+                av[mt][0] = t[0]; av[mt][1] = t[1]; av[mt][2] = t[2]; av[mt][3] = t[3];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                const int r = wn * (BN / 2) + nt * 32 + l31;
+                if (BWD) { const v4f t = *reinterpret_cast<const v4f *>(b + r * BK + (((ci * 2 + h) ^ ((r / SW) & (CH - 1))) << 2));
+                           bv[nt][0] = t[0]; bv[nt][1] = t[1]; bv[nt][2] = t[2]; bv[nt][3] = t[3]; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) bv[nt][j] = b[(ci * 8 + 4 * h + j) * BN + r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+        if (kt + 1 < nst) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int gn = n0 + wn * (BN / 2) + nt * 32 + l31;
+            if (gn >= Cout) continue;
+            const float bias = (!BWD && p.B) ? p.B[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long gm = m0 + wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gm < npix) { const float v = acc[mt][nt][r] + bias; p.Y[gm * Cout + gn] = v; if (p.Y2) p.Y2[gm * Cout + gn] = v; }
+            }
+        }
+}
+
+// ------------------------------------------------------------------ dF partials
+// grid = (slices, taps * ci_tiles, co_tiles); tile 64 (ci) x 64 (co); K = the slice's pixels, 32 per stage
+struct CdP { const float *I, *DO; float *part; int N, H1, W1, C1, H0, W0, C0; int pix_per_slice, ci_tiles; };
+
+template <int K, int S, int P>
+__global__ void __launch_bounds__(256) k_convbig_df(CdP p) {
+    constexpr int BM = 64, BN = 64, KK = K * K;
+    constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;     // 2, 2
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+    float *sA = lds, *sB = lds + 2 * BM * BK;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1, h = lane >> 5, l31 = lane & 31;
+    const int tap = blockIdx.y / p.ci_tiles, cit = blockIdx.y - tap * p.ci_tiles;
+    const int ky = tap / K, kx = tap - ky * K;
+    const int m0 = cit * BM, n0 = blockIdx.z * BN;               // ci0, co0
+    const long npix = (long)p.N * p.H0 * p.W0;
+    const long k_beg = (long)blockIdx.x * p.pix_per_slice, k_end = min(npix, k_beg + p.pix_per_slice);
+    const int nst = (int)((k_end - k_beg + BK - 1) / BK);
+    v4f ra[PA], rb[PB];
+    auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+        const long k0 = k_beg + (long)kt * BK;
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < PA; pp++) {                         // A[k = pixel][m = ci] = I[pixel (+) tap][ci]: m-contiguous
+            const int id = pp * 256 + tid, kk = id / (BM / 4), rq = id % (BM / 4);
+            const long pix = k0 + kk; const int m = m0 + rq * 4;
+            bool ok = pix < k_end && m < p.C1;
+            const long pc = ok ? pix : 0;
+            const int x = (int)(pc % p.W0); const long t = pc / p.W0; const int y = (int)(t % p.H0); const long n = t / p.H0;
+            const int gi = y * S + ky - P, gj = x * S + kx - P;
+            ok = ok && gi >= 0 && gi < p.H1 && gj >= 0 && gj < p.W1;
+            ra[pp] = ok ? *reinterpret_cast<const v4f *>(p.I + ((n * p.H1 + gi) * (long)p.W1 + gj) * p.C1 + m) : z;
+        }
+#pragma unroll
+        for (int pp = 0; pp < PB; pp++) {                         // B[k = pixel][n = co] = dO[pixel][co]: n-contiguous
+            const int id = pp * 256 + tid, kk = id / (BN / 4), rq = id % (BN / 4);
+            const long pix = k0 + kk; const int n = n0 + rq * 4;
+            rb[pp] = (pix < k_end && n < p.C0) ? *reinterpret_cast<const v4f *>(p.DO + pix * p.C0 + n) : z;
+        }
+    };
+    int soa[PA], sob[PB];
+#pragma unroll
+    for (int pp = 0; pp < PA; pp++) { const int id = pp * 256 + tid; soa[pp] = (id / (BM / 4)) * BM + (id % (BM / 4)) * 4; }
+#pragma unroll
+    for (int pp = 0; pp < PB; pp++) { const int id = pp * 256 + tid; sob[pp] = (id / (BN / 4)) * BN + (id % (BN / 4)) * 4; }
+    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+        float *a = sA + buf * BM * BK, *b = sB + buf * BN * BK;
+#pragma unroll
+        for (int pp = 0; pp < PA; pp++) *reinterpret_cast<v4f *>(a + soa[pp]) = ra[pp];
+#pragma unroll
+        for (int pp = 0; pp < PB; pp++) *reinterpret_cast<v4f *>(b + sob[pp]) = rb[pp];
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (nst > 0) { load_tiles(0); store_tiles(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nst; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nst) load_tiles(kt + 1);
+        const float *a = sA + buf * BM * BK, *b = sB + buf * BN * BK;
+        const int ra_ = wm * 32 + l31, rb_ = wn * 32 + l31;
+#pragma unroll
+        for (int ci = 0; ci < NC; ci++) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { av[j] = a[(ci * 8 + 4 * h + j) * BM + ra_]; bv[j] = b[(ci * 8 + 4 * h + j) * BN + rb_]; }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
+        }
+        if (kt + 1 < nst) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    // partial slab [slice][row = (ci*K+ky)*K+kx][co]  (the fold's layout, without a bias row)
+    const int co = n0 + wn * 32 + l31;
+    if (co < p.C0) {
+        const long nrow = (long)p.C1 * KK;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ci = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (ci < p.C1) p.part[((long)blockIdx.x * nrow + ((long)ci * KK + tap)) * p.C0 + co] = acc0[r] + acc1[r];
+        }
+    }
+}
+
+} // namespace
+
+namespace t4k {
+
+bool conv_big_ok(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && Cout >= 16 && (Cout % 4) == 0; }
+
+// forward (BWD = false) or dX (BWD = true); X/Cin are the gathered tensor, Y/Cout the produced one
+template <bool BWD>
+void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
+                     int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f) {
+    CbP p = { X, F, B, Y, Y2, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, 0 };
+    const long npix = (long)N * Hy * Wy;
+    const int tiles_m = (int)((npix + 127) / 128);
+    const bool wide = Cout > 64;
+    const int BN = wide ? 128 : 64;
+    p.tiles_n = (Cout + BN - 1) / BN;
+    const dim3 g((unsigned)(tiles_m * p.tiles_n)), b(256);
+    const size_t lds = sizeof(float) * 2 * (128 + BN) * BK;
+#define CB(k, s, pd) do { if (wide) { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig<k, s, pd, BWD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); a1 = true; } \
+                                       hipLaunchKernelGGL((k_convbig<k, s, pd, BWD, 128>), g, b, lds, hs, p); } \
+                          else hipLaunchKernelGGL((k_convbig<k, s, pd, BWD, 64>), g, b, lds, hs, p); } while (0)
+    switch ((K << 8) | (S << 4) | P) {
+    case 0x110: CB(1, 1, 0); break;
+    case 0x311: CB(3, 1, 1); break;
+    case 0x421: CB(4, 2, 1); break;
+    case 0x512: CB(5, 1, 2); break;
+    }
+#undef CB
+}
+template void launch_conv_big<false>(int, int, int, hipStream_t, const float *, float *, float *, const float *, const float *, int, int, int, int, int, int, int, int);
+template void launch_conv_big<true>(int, int, int, hipStream_t, const float *, float *, float *, const float *, const float *, int, int, int, int, int, int, int, int);
+
+// dF partial slabs; returns the number of slices written (0: workspace too small).  Layout [slice][C1*K*K][C0].
+int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, const float *DO, float *part, size_t part_floats,
+                       int N, int H1, int W1, int C1, int H0, int W0, int C0) {
+    const long npix = (long)N * H0 * W0;
+    const int ci_tiles = (C1 + 63) / 64, co_tiles = (C0 + 63) / 64, KK = K * K;
+    const int tiles = KK * ci_tiles * co_tiles;
+    long nslice = (2L * st().cu_count + tiles - 1) / tiles; if (nslice < 1) nslice = 1;      // ~2 workgroups per CU in total
+    long pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; if (pps < 8 * BK) pps = 8 * BK;
+    nslice = (npix + pps - 1) / pps;
+    if ((size_t)nslice * C1 * KK * C0 > part_floats) return 0;
+    CdP p = { I, DO, part, N, H1, W1, C1, H0, W0, C0, (int)pps, ci_tiles };
+    const dim3 g((unsigned)nslice, (unsigned)(KK * ci_tiles), (unsigned)co_tiles), b(256);
+    switch ((K << 8) | (S << 4) | P) {
+    case 0x110: hipLaunchKernelGGL((k_convbig_df<1, 1, 0>), g, b, 0, hs, p); break;
+    case 0x311: hipLaunchKernelGGL((k_convbig_df<3, 1, 1>), g, b, 0, hs, p); break;
+    case 0x421: hipLaunchKernelGGL((k_convbig_df<4, 2, 1>), g, b, 0, hs, p); break;
+    case 0x512: hipLaunchKernelGGL((k_convbig_df<5, 1, 2>), g, b, 0, hs, p); break;
+    }
+    return (int)nslice;
+}
+
+} // namespace t4k

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""conv2d fwd / bwd timing at CIFAR-class sizes (many channels => MFMA implicit-GEMM path) against the fp32 MFMA peak."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tensorforth_amd import lib as t4lib
+k = t4lib.load(); k.init(0)
+p = lambda t: t.data_ptr()
+
+
+def timeit(fn, iters=30):
+    e0 = ctypes.c_void_p(); e1 = ctypes.c_void_p()
+    k.call("t4k_event_create", ctypes.byref(e0)); k.call("t4k_event_create", ctypes.byref(e1))
+    for _ in range(3): fn()
+    k.call("t4k_event_record", e0, None)
+    for _ in range(iters): fn()
+    k.call("t4k_event_record", e1, None); k.call("t4k_event_sync", e1)
+    ms = ctypes.c_float(0); k.call("t4k_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+    return ms.value / iters * 1e3
+
+
+for (N, H, C1, C0) in [(256, 32, 64, 64), (256, 16, 64, 128), (256, 32, 3, 64), (128, 14, 10, 20)]:
+    x = torch.rand(N, H, H, C1, device="cuda"); f = torch.rand(C1, 3, 3, C0, device="cuda") - 0.5; b = torch.rand(C0, device="cuda")
+    y = torch.zeros(N, H, H, C0, device="cuda"); dx = torch.zeros_like(x); df = torch.zeros_like(f); db = torch.zeros_like(b)
+    flop = 2.0 * N * H * H * C1 * C0 * 9
+    tf = timeit(lambda: k.call("t4k_conv2d_fwd", p(x), p(y), p(f), p(b), N, H, H, C1, H, H, C0, 3, 1, 1, None))
+    tb = timeit(lambda: k.call("t4k_conv2d_bwd", p(x), p(y), p(dx), p(f), p(df), p(db), N, H, H, C1, H, H, C0, 3, 1, 1, 1, None))
+    print("N=%d %dx%d %d->%d: fwd %.1f us (%.1f TF, %.0f%% of peak)   bwd (dF+dX) %.1f us (%.1f TF)" %
+          (N, H, H, C1, C0, tf, flop / tf / 1e6, 100 * flop / tf / 1e6 / 157.3, tb, 2 * flop / tb / 1e6), flush=True)
