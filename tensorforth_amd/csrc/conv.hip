@@ -569,7 +569,10 @@ namespace t4k {
 // OUT[e] += sum_rows X[row][e], deterministic (used by t4k_linear_bwd / t4k_dlinear_db)
 int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs) {
     if (rows <= 0 || E <= 0) return T4K_OK;
-    long want = (rows + 1023) / 1024; if (want > 64) want = 64; if (want < 1) want = 1;
+    // ~256 rows per chunk (each of the 4 row groups then sums 64 rows), up to 2048 chunks: a 262144 x 64 matrix
+    // (the dO of a CIFAR-size conv layer) spreads over 1024 workgroups instead of 64
+    long want = (rows + 255) / 256; if (want > 2048) want = 2048; if (want < 1) want = 1;
+    if (rows <= 1024) want = 1;                       // small: single chunk accumulates in place (one launch)
     const int rpc = (int)((rows + want - 1) / want);
     const int nchunk = (int)((rows + rpc - 1) / rpc);
     float *part = ws_for(hs) + (8 << 20);            // second 32 MiB half of the workspace
@@ -579,7 +582,7 @@ int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs) {
         return T4K_OK;
     }
     hipLaunchKernelGGL(k_colsum_part, dim3(nchunk, (E + 63) / 64), dim3(BLK), 0, hs, X, part, rows, E, rpc, (float *)nullptr);
-    hipLaunchKernelGGL(k_fold_add, dim3((E + BLK - 1) / BLK), dim3(BLK), 0, hs, part, OUT, E, nchunk);
+    hipLaunchKernelGGL(k_conv_df_fold, dim3((E + 3) / 4), dim3(256), 0, hs, part, OUT, OUT, nchunk, E, E);   // one wave per output, fixed xor tree
     return T4K_OK;
 }
 }

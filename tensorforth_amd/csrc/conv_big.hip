@@ -179,19 +179,33 @@ __global__ void __launch_bounds__(256) k_convbig_df(CdP p) {
     const long k_beg = (long)blockIdx.x * p.pix_per_slice, k_end = min(npix, k_beg + p.pix_per_slice);
     const int nst = (int)((k_end - k_beg + BK - 1) / BK);
     v4f ra[PA], rb[PB];
+    // this thread's pixel rows of the CURRENT stage, kept as (n, y, x) and advanced by 32 pixels per stage - no 64-bit
+    // divisions in the loop (they cost more than the MFMAs they feed)
+    int cx[PA], cy[PA]; long cn[PA];
+#pragma unroll
+    for (int pp = 0; pp < PA; pp++) {
+        const long pix = k_beg + (pp * 256 + tid) / (BM / 4);
+        cx[pp] = (int)(pix % p.W0); const long t = pix / p.W0; cy[pp] = (int)(t % p.H0); cn[pp] = t / p.H0;
+    }
+    int kt_loaded = 0;                                            // stage the coordinates above belong to
     auto load_tiles = [&](int kt) __attribute__((always_inline)) {
         const long k0 = k_beg + (long)kt * BK;
         const v4f z = {0.f, 0.f, 0.f, 0.f};
+        while (kt_loaded < kt) {                                  // advance by one stage (32 pixels)
+#pragma unroll
+            for (int pp = 0; pp < PA; pp++) {
+                cx[pp] += BK;
+                while (cx[pp] >= p.W0) { cx[pp] -= p.W0; if (++cy[pp] == p.H0) { cy[pp] = 0; cn[pp]++; } }
+            }
+            kt_loaded++;
+        }
 #pragma unroll
         for (int pp = 0; pp < PA; pp++) {                         // A[k = pixel][m = ci] = I[pixel (+) tap][ci]: m-contiguous
             const int id = pp * 256 + tid, kk = id / (BM / 4), rq = id % (BM / 4);
             const long pix = k0 + kk; const int m = m0 + rq * 4;
-            bool ok = pix < k_end && m < p.C1;
-            const long pc = ok ? pix : 0;
-            const int x = (int)(pc % p.W0); const long t = pc / p.W0; const int y = (int)(t % p.H0); const long n = t / p.H0;
-            const int gi = y * S + ky - P, gj = x * S + kx - P;
-            ok = ok && gi >= 0 && gi < p.H1 && gj >= 0 && gj < p.W1;
-            ra[pp] = ok ? *reinterpret_cast<const v4f *>(p.I + ((n * p.H1 + gi) * (long)p.W1 + gj) * p.C1 + m) : z;
+            const int gi = cy[pp] * S + ky - P, gj = cx[pp] * S + kx - P;
+            const bool ok = pix < k_end && m < p.C1 && gi >= 0 && gi < p.H1 && gj >= 0 && gj < p.W1;
+            ra[pp] = ok ? *reinterpret_cast<const v4f *>(p.I + ((cn[pp] * p.H1 + gi) * (long)p.W1 + gj) * p.C1 + m) : z;
         }
 #pragma unroll
         for (int pp = 0; pp < PB; pp++) {                         // B[k = pixel][n = co] = dO[pixel][co]: n-contiguous

@@ -25,5 +25,7 @@ for (N, H, C1, C0) in [(256, 32, 64, 64), (256, 16, 64, 128), (256, 32, 3, 64), 
     flop = 2.0 * N * H * H * C1 * C0 * 9
     tf = timeit(lambda: k.call("t4k_conv2d_fwd", p(x), p(y), p(f), p(b), N, H, H, C1, H, H, C0, 3, 1, 1, None))
     tb = timeit(lambda: k.call("t4k_conv2d_bwd", p(x), p(y), p(dx), p(f), p(df), p(db), N, H, H, C1, H, H, C0, 3, 1, 1, 1, None))
-    print("N=%d %dx%d %d->%d: fwd %.1f us (%.1f TF, %.0f%% of peak)   bwd (dF+dX) %.1f us (%.1f TF)" %
-          (N, H, H, C1, C0, tf, flop / tf / 1e6, 100 * flop / tf / 1e6 / 157.3, tb, 2 * flop / tb / 1e6), flush=True)
+    tdf = timeit(lambda: k.call("t4k_conv2d_bwd", p(x), p(y), None, p(f), p(df), p(db), N, H, H, C1, H, H, C0, 3, 1, 1, 1, None))
+    tdx = timeit(lambda: k.call("t4k_conv2d_bwd", p(x), p(y), p(dx), p(f), None, None, N, H, H, C1, H, H, C0, 3, 1, 1, 0, None))
+    print("N=%d %dx%d %d->%d: fwd %.1f us (%.1f TF, %.0f%% of peak)   bwd (dF+dX) %.1f us (%.1f TF)   dF|dB %.1f us  dX %.1f us" %
+          (N, H, H, C1, C0, tf, flop / tf / 1e6, 100 * flop / tf / 1e6 / 157.3, tb, 2 * flop / tb / 1e6, tdf, tdx), flush=True)
