@@ -158,7 +158,56 @@ __global__ void __launch_bounds__(BLK) k_dlinear_db(const float *__restrict__ DY
     if (ny == 0 && e < E0) DB[e] += (sm[0][ex] + sm[1][ex]) + (sm[2][ex] + sm[3][ex]);
 }
 
-// batchnorm statistics: one block per channel, finalised in the same launch
+// batchnorm statistics = two column sums of the [N*H*W, C] matrix view (NHWC: a row is one pixel's channels).
+// Stage 1: grid (row chunks, C/64); a workgroup = 64 adjacent channels x 4 row groups, so every load instruction of a wave
+// is one contiguous 256-byte run (the reference - and the first version here - walked a single channel with stride C:
+// 1/64 of every cache line used).  Stage 2: one wave per channel folds the chunk partials with a fixed xor tree and
+// finalises.  Deterministic: no fp32 atomics.  MODE 0: sum x, sum x^2 (k_batchnorm_1/2 nmath.cu:177-242);
+// MODE 1: sum dy, sum dy*xhat (k_dbatchnorm_1 nmath.cu:295-381).
+template <int MODE>
+__global__ void __launch_bounds__(BLK) k_bn_part(const float *__restrict__ X, const float *__restrict__ Y, float *__restrict__ part,
+                                                 long rows, int C, int rows_per_chunk) {
+    __shared__ float sm[2][4][64];
+    const int ex = threadIdx.x & 63, ry = threadIdx.x >> 6, e = blockIdx.y * 64 + ex;
+    const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float a = 0.f, b = 0.f;
+    if (e < C) {
+#pragma unroll 4
+        for (long r = r0 + ry; r < r1; r += 4) {
+            const float v = X[r * C + e];
+            if (MODE == 0) { a += v; b = fmaf(v, v, b); }
+            else           { a += v; b = fmaf(v, Y[r * C + e], b); }
+        }
+    }
+    sm[0][ry][ex] = a; sm[1][ry][ex] = b;
+    __syncthreads();
+    if (ry == 0 && e < C) {
+        part[((long)blockIdx.x * 2 + 0) * C + e] = (sm[0][0][ex] + sm[0][1][ex]) + (sm[0][2][ex] + sm[0][3][ex]);
+        part[((long)blockIdx.x * 2 + 1) * C + e] = (sm[1][0][ex] + sm[1][1][ex]) + (sm[1][2][ex] + sm[1][3][ex]);
+    }
+}
+template <int MODE>
+__global__ void __launch_bounds__(BLK) k_bn_fin(const float *__restrict__ part, float *stat, float *DW, float *DB,
+                                                long NHW, int C, int nchunk, int train) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int k = lane; k < nchunk; k += 64) { a += part[((long)k * 2 + 0) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+    a = wave_sum_all(a); b = wave_sum_all(b);
+    if (lane == 0) {
+        if (MODE == 0) {
+            const float avg = a / (float)NHW;
+            const float var = b / (float)NHW - avg * avg;
+            stat[C + c] = avg;
+            stat[c]     = 1.0f / (sqrtf(fmaxf(var, 0.0f)) + DU_EPS);
+        } else {
+            const float s1 = a / (float)NHW, s2 = b / (float)NHW;
+            stat[C + c] = s1; stat[2 * C + c] = s2;
+            if (train) { DB[c] += s1; DW[c] += s2; }
+        }
+    }
+}
+// single-launch variant for small row counts: one block per channel, finalised in the same launch
 __global__ void __launch_bounds__(BLK) k_bn_stats(const float *__restrict__ I, float *stat, long NHW, int C) {
     __shared__ float sm[4];
     const int c = blockIdx.x;
@@ -256,7 +305,14 @@ int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const
                       float *stat, int N, int HW, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_fwd: shape");
     const long NHW = (long)N * HW, total = NHW * C;
-    hipLaunchKernelGGL(k_bn_stats, dim3(C), dim3(BLK), 0, S(s), I, stat, NHW, C);
+    if (NHW >= 2048) {                                   // image-sized: chunked coalesced column sums + per-channel fold
+        long nch = (NHW + 255) / 256; if (nch > 2048) nch = 2048;
+        const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
+        float *part = ws_for(s);
+        if ((size_t)nch * 2 * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
+        hipLaunchKernelGGL(k_bn_part<0>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), I, (const float *)nullptr, part, NHW, C, rpc);
+        hipLaunchKernelGGL(k_bn_fin<0>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, (float *)nullptr, (float *)nullptr, NHW, C, (int)nch, 0);
+    } else hipLaunchKernelGGL(k_bn_stats, dim3(C), dim3(BLK), 0, S(s), I, stat, NHW, C);
     hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), I, O, XH, W, B, stat, total, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
@@ -264,7 +320,14 @@ int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *D
                       float *DW, float *DB, float *stat, int N, int HW, int C, int train, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_bwd: shape");
     const long NHW = (long)N * HW, total = NHW * C;
-    hipLaunchKernelGGL(k_dbn_stats, dim3(C), dim3(BLK), 0, S(s), DY, XH, stat, DW, DB, NHW, C, train);
+    if (NHW >= 2048) {
+        long nch = (NHW + 255) / 256; if (nch > 2048) nch = 2048;
+        const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
+        float *part = ws_for(s);
+        if ((size_t)nch * 2 * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
+        hipLaunchKernelGGL(k_bn_part<1>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), DY, XH, part, NHW, C, rpc);
+        hipLaunchKernelGGL(k_bn_fin<1>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, DW, DB, NHW, C, (int)nch, train);
+    } else hipLaunchKernelGGL(k_dbn_stats, dim3(C), dim3(BLK), 0, S(s), DY, XH, stat, DW, DB, NHW, C, train);
     hipLaunchKernelGGL(k_dbn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), W, DY, XH, DX, stat, total, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }

@@ -283,10 +283,10 @@ def test_linear_fwd_bwd(t4k, dev, oracle, N, E0, E1):
     assert rel(dev.down(dDB), DBo) < RTOL
 
 
-def test_batchnorm(t4k, dev, oracle):
+@pytest.mark.parametrize("N,HW,C", [(8, 49, 6), (16, 256, 70), (4, 1024, 128)])   # single-launch stats / chunked column sums
+def test_batchnorm(t4k, dev, oracle, N, HW, C):
     o = oracle.lib(); P = oracle.P
     rng = np.random.default_rng(8)
-    N, HW, C = 8, 49, 6
     x = (rng.standard_normal((N, HW, C)) * 2 + 1).astype(np.float32)
     g = rng.standard_normal(C).astype(np.float32); b = rng.standard_normal(C).astype(np.float32)
     y = np.zeros_like(x); xh = np.zeros_like(x); stat = np.zeros(3 * C, np.float32)
