@@ -477,7 +477,7 @@ void launch_conv_few(int K, hipStream_t hs, const float *X, float *Y, float *Y2,
 template <int K, int S, int P, int CO>
 __device__ __forceinline__ void conv_dx_few_body(const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2,
                                                  const float *__restrict__ F, int N, int H0, int W0, int C0, int H1, int W1, int bx, int gx) {
-    __shared__ float Fl[LDS_FILTER_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Fl[LDS_FILTER_FLOATS];
     const int nF = CO * K * K * C0;
     for (int e = threadIdx.x; e < nF; e += 256) Fl[e] = F[e];
     __syncthreads();
@@ -499,7 +499,18 @@ __device__ __forceinline__ void conv_dx_few_body(const float *__restrict__ DO, f
                 const float *d = nD + (ok ? ((long)gi * W0 + gj) * C0 : 0);
                 const float *f = Fl + ((K - 1 - ky) * K + (K - 1 - kx)) * C0;     // F[c1][K-1-ky][K-1-kx][c0]
                 const float msk = ok ? 1.f : 0.f;                 // loads are unconditional (clamped pixel), masked by a multiply-free select
-                if ((C0 & 1) == 0) {                              // even channel count: 8 B loads (pixel rows are 8 B aligned)
+                if ((C0 & 3) == 0) {                              // 16 B loads of dO and of the weights (LDS rows are 16 B aligned: C0 % 4 == 0)
+#pragma unroll 4
+                    for (int c0 = 0; c0 < C0; c0 += 4) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(d + c0);
+                        const float v0 = ok ? v4.x : 0.f, v1 = ok ? v4.y : 0.f, v2 = ok ? v4.z : 0.f, v3 = ok ? v4.w : 0.f;
+#pragma unroll
+                        for (int c = 0; c < CO; c++) {
+                            const float4 w4 = *reinterpret_cast<const float4 *>(f + c * K * K * C0 + c0);
+                            acc[c] = fmaf(v0, w4.x, acc[c]); acc[c] = fmaf(v1, w4.y, acc[c]); acc[c] = fmaf(v2, w4.z, acc[c]); acc[c] = fmaf(v3, w4.w, acc[c]);
+                        }
+                    }
+                } else if ((C0 & 1) == 0) {                       // even channel count: 8 B loads (pixel rows are 8 B aligned)
 #pragma unroll 5
                     for (int c0 = 0; c0 < C0; c0 += 2) {
                         const float2 v2 = *reinterpret_cast<const float2 *>(d + c0);
