@@ -10,6 +10,7 @@
 // with bit-identical values: the arithmetic is k_activate (nmath.cu:37-70), k_pool / k_dpool
 // (nmath.tcu:122-186, 475-568) and, for dropout, the same Philox slice t4k_rand would have drawn.
 #include "t4k_common.h"
+#include <algorithm>
 
 using namespace t4k;
 
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
     uint64_t base = 0, seed = 0;
     const bool draw = p.pre == T4K_L_DROPOUT;
     if (draw) rng_begin(p.rng, base, seed);
-    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
+    for (long z = (long)blockIdx.x * blockDim.x + threadIdx.x; z < total; z += (long)gridDim.x * blockDim.x) {
         const int c = (int)(z % CV) * VW; long t = z / CV;
         const int j0 = (int)(t % p.W0); t /= p.W0;
         const int i0 = (int)(t % p.H0); const int n = (int)(t / p.H0);
@@ -105,7 +106,7 @@ template <int KS, int VW>
 __global__ void __launch_bounds__(BLK) k_poolblock_bwd(PBB p) {
     const int CV = p.C / VW;
     const long total = (long)p.N * p.H0 * p.W0 * CV;
-    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
+    for (long z = (long)blockIdx.x * blockDim.x + threadIdx.x; z < total; z += (long)gridDim.x * blockDim.x) {
         const int c = (int)(z % CV) * VW; long t = z / CV;
         const int j0 = (int)(t % p.W0); t /= p.W0;
         const int i0 = (int)(t % p.H0); const int n = (int)(t / p.H0);
@@ -212,7 +213,9 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
     p.rng = RngArg{0, 0, nullptr};
     if (b->pre_layer == T4K_L_DROPOUT) p.rng = rng_draw(S(s), (uint64_t)(((long)N * H1 * W1 * C + 3) >> 2));
     const int VW = vec_width(C, X, b);
-    const dim3 grid(grid_for(total / VW)), blk(BLK);
+    const long nthr = total / VW;
+    const int bs = (nthr < (long)BLK * 2 * st().cu_count) ? 64 : BLK;      // small runs: one-wave workgroups reach every CU
+    const dim3 grid((unsigned)std::min<long>((nthr + bs - 1) / bs, 8192)), blk(bs);
 #define PBF(KS_) do { if (VW == 4) hipLaunchKernelGGL((k_poolblock_fwd<KS_, 4>), grid, blk, 0, S(s), p); \
                       else if (VW == 2) hipLaunchKernelGGL((k_poolblock_fwd<KS_, 2>), grid, blk, 0, S(s), p); \
                       else hipLaunchKernelGGL((k_poolblock_fwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
@@ -234,7 +237,9 @@ int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *b, int N, 
     p.pre = b->pre_layer; p.pool = b->pool_layer; p.post = b->post_layer;
     p.N = N; p.H1 = H1; p.W1 = W1; p.H0 = H0; p.W0 = W0; p.C = C;
     int VW = vec_width(C, X, b); if (VW > 1 && (((uintptr_t)DY) & (4 * VW - 1))) VW = 1;
-    const dim3 grid(grid_for(total / VW)), blk(BLK);
+    const long nthr = total / VW;
+    const int bs = (nthr < (long)BLK * 2 * st().cu_count) ? 64 : BLK;
+    const dim3 grid((unsigned)std::min<long>((nthr + bs - 1) / bs, 8192)), blk(bs);
 #define PBB_(KS_) do { if (VW == 4) hipLaunchKernelGGL((k_poolblock_bwd<KS_, 4>), grid, blk, 0, S(s), p); \
                        else if (VW == 2) hipLaunchKernelGGL((k_poolblock_bwd<KS_, 2>), grid, blk, 0, S(s), p); \
                        else hipLaunchKernelGGL((k_poolblock_bwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
