@@ -332,9 +332,11 @@ void VM::init_core() {
     CODE(".",       [this] { dot(POP()); });
     CODE("u.",      [this] { char b[24]; snprintf(b, sizeof(b), "%u ", (uint32_t)(int)POP()); pstr(b); });
     CODE(".r",      [this] { fmt_w_ = POPi(); DU v = POP(); char b[48]; snprintf(b, sizeof(b), "%g", v); std::string s = b;
-                             if (fmt_w_ > (int)s.size()) s = std::string(fmt_w_ - s.size(), ' ') + s; fmt_w_ = 0; pstr(s); });
+                             if (fmt_w_ > (int)s.size()) { s = std::string(fmt_w_ - s.size(), ' ') + s; }
+                             fmt_w_ = 0; pstr(s); });
     CODE("u.r",     [this] { int w = POPi(); DU v = POP(); char b[48]; snprintf(b, sizeof(b), "%u", (uint32_t)v); std::string s = b;
-                             if (w > (int)s.size()) s = std::string(w - s.size(), ' ') + s; pstr(s); });
+                             if (w > (int)s.size()) { s = std::string(w - s.size(), ' ') + s; }
+                             pstr(s); });
     CODE("type",    [this] { POP(); pstr((const char *)&pmem_[(uint32_t)POPi()]); });
     IMMD("key",     [this] { if (compile_) add_p(P_KEY); else PUSH((DU)getchar()); });
     CODE("emit",    [this] { char c = (char)(int)POP(); out_.push_back(c); });
