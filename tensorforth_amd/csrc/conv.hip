@@ -41,11 +41,14 @@ template <int K, int S, int P, bool BWD>
 __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
                                                const float *__restrict__ F, const float *__restrict__ B,
                                                int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout,
-                                               int C0 /* filter inner dim */, int pairs_per_chunk, int bx, int by) {
+                                               int C0 /* filter inner dim */, int pairs_per_chunk, int bx, int by, int ksplit = 1) {
     __shared__ float Bl[LDS_FILTER_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const long npix = (long)N * Hy * Wy;
-    const long tile = (long)bx * 4 + w;
+    // ksplit == 2 (small layers that would leave SIMDs empty): two waves share one 32x32 tile, each takes alternate
+    // blocks of channel pairs, the halves meet in LDS - twice the waves, half the dependent loads / MFMAs per wave
+    const int kh = (ksplit == 2) ? (w & 1) : 0;
+    const long tile = (ksplit == 2) ? (long)bx * 2 + (w >> 1) : (long)bx * 4 + w;
     const long pix  = tile * 32 + l31;                       // this lane's A-row pixel
     const int  co0  = by * 32;                               // output-channel tile
     const bool pok  = pix < npix;
@@ -108,7 +111,7 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
         }
         __syncthreads();
         }
-        for (int cpb = 0; cpb < cpn; cpb += 2) {            // two channel pairs per trip: 2*K*K loads in flight
+        for (int cpb = kh * 2; cpb < cpn; cpb += 2 * ksplit) {   // two channel pairs per trip: 2*K*K loads in flight
             float a[2][K * K];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -140,6 +143,17 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
             }
         }
     }
+    if (ksplit == 2) {                                      // the two k-halves of a tile meet in LDS (the filter stage is free now)
+        __syncthreads();
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) Bl[((w >> 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] += Bl[((w >> 1) * 16 + r) * 64 + lane];
+    }
     // ---- epilogue: D[row = pixel][col = channel]; col = lane&31, row = (r&3)+8*(r>>2)+4*h
     const int co = co0 + l31;
     if (co < Cout) {
@@ -155,8 +169,8 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
 template <int K, int S, int P, bool BWD>
 __global__ void __launch_bounds__(256) k_conv_gemm(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
                                                    const float *__restrict__ F, const float *__restrict__ B,
-                                                   int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0, int pairs_per_chunk) {
-    conv_gemm_body<K, S, P, BWD>(X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, pairs_per_chunk, blockIdx.x, blockIdx.y);
+                                                   int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0, int pairs_per_chunk, int ksplit) {
+    conv_gemm_body<K, S, P, BWD>(X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, pairs_per_chunk, blockIdx.x, blockIdx.y, ksplit);
 }
 
 // ------------------------------------------------------------------ dF | dB
@@ -251,10 +265,10 @@ __global__ void __launch_bounds__(256) k_conv_df_fold(const float *__restrict__ 
 template <int K, int S, int P>
 __global__ void __launch_bounds__(256) k_conv_dx_and_fold(const float *__restrict__ part, float *DF, float *DB, int nslice, int ndf, int ntot, int nfold,
                                                           const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2, const float *__restrict__ F,
-                                                          int N, int H1, int W1, int C1, int H0, int W0, int C0, int hx, int ppc) {
+                                                          int N, int H1, int W1, int C1, int H0, int W0, int C0, int hx, int ppc, int ksplit) {
     const int b = blockIdx.x;
     if (b < nfold) conv_df_fold_body(part, DF, DB, nslice, ndf, ntot, b);
-    else { const int b2 = b - nfold; conv_gemm_body<K, S, P, true>(DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, ppc, b2 % hx, b2 / hx); }
+    else { const int b2 = b - nfold; conv_gemm_body<K, S, P, true>(DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, ppc, b2 % hx, b2 / hx, ksplit); }
 }
 
 // ------------------------------------------------------------------ generic column sums (dlinear_db)
@@ -557,6 +571,12 @@ void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, fl
 
 bool conv_big_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_BIG"); v = e ? atoi(e) : 1; } return v != 0; }
 bool conv_few_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_FEW"); v = e ? atoi(e) : 1; } return v != 0; }
+// two waves per tile when the layer is small enough to leave SIMDs empty and has enough k-work to split
+int conv_gemm_ksplit(long npix, int Cout, int Cin, int K) {
+    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_KSPLIT"); on = e ? atoi(e) : 1; }
+    const long waves = ((npix + 31) / 32) * ((Cout + 31) / 32);
+    return (on && waves < 1536 && ((Cin + 1) / 2) * K * K >= 18) ? 2 : 1;
+}
 bool conv_supported(int K, int S, int P) {
     return (K == 1 && S == 1 && P == 0) || (K == 3 && S == 1 && P == 1) ||
            (K == 4 && S == 2 && P == 1) || (K == 5 && S == 1 && P == 2);
@@ -566,11 +586,14 @@ template <bool BWD>
 void launch_conv_gemm(int K, int S, int P, dim3 g, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
                       int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0) {
     const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);            // channel pairs per LDS filter slice
+    const long npix = (long)N * Hy * Wy;
+    const int ksplit = conv_gemm_ksplit(npix, Cout, Cin, K);
+    g.x = (unsigned)((npix + (128 / ksplit) - 1) / (128 / ksplit));
     switch ((K << 8) | (S << 4) | P) {
-    case 0x110: hipLaunchKernelGGL((k_conv_gemm<1, 1, 0, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
-    case 0x311: hipLaunchKernelGGL((k_conv_gemm<3, 1, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
-    case 0x421: hipLaunchKernelGGL((k_conv_gemm<4, 2, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
-    case 0x512: hipLaunchKernelGGL((k_conv_gemm<5, 1, 2, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc); break;
+    case 0x110: hipLaunchKernelGGL((k_conv_gemm<1, 1, 0, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
+    case 0x311: hipLaunchKernelGGL((k_conv_gemm<3, 1, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
+    case 0x421: hipLaunchKernelGGL((k_conv_gemm<4, 2, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
+    case 0x512: hipLaunchKernelGGL((k_conv_gemm<5, 1, 2, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
     }
 }
 
@@ -706,12 +729,13 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         launch_conv_few<true>(K, hs, DO, DX, DX2, nullptr, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0, fG, fNG);
     } else if (DX) {                                    // DX == NULL: dF|dB only; DX2 = optional second copy from the same launch
         const long npix1 = (long)N * H1 * W1;
-        const int hx = (int)((npix1 + 127) / 128), hy = (C1 + 31) / 32;
+        const int ksplit = conv_gemm_ksplit(npix1, C1, C0, K);
+        const int hx = (int)((npix1 + (128 / ksplit) - 1) / (128 / ksplit)), hy = (C1 + 31) / 32;
         // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1); the dF fold rides along
         const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);
         const dim3 g((unsigned)(fa.nfold + hx * hy));
 #define DXF(k, s_, p_) hipLaunchKernelGGL((k_conv_dx_and_fold<k, s_, p_>), g, dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot, fa.nfold, \
-                                          DO, DX, DX2, F, N, H1, W1, C1, H0, W0, C0, hx, ppc)
+                                          DO, DX, DX2, F, N, H1, W1, C1, H0, W0, C0, hx, ppc, ksplit)
         switch ((K << 8) | (S << 4) | P) {
         case 0x110: DXF(1, 1, 0); break;
         case 0x311: DXF(3, 1, 1); break;
