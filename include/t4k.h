@@ -258,6 +258,11 @@ typedef struct t4k_poolblock {
     float *copy_out;
 } t4k_poolblock;
 int t4k_poolblock_fwd(const float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);
+/* convolution forward with such a run right behind it (conv -> [dropout|activation] -> 2x2 pool -> [activation] -> [flatten]):
+ * O and every tensor of the run are written exactly as t4k_conv2d_fwd2 + t4k_poolblock_fwd would; one launch when the
+ * layer takes the gather-MFMA kernel (the pool window is four consecutive accumulator registers of a lane) */
+int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
+                         int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t s);
 /* backward of the same run (_bactivate backprop.cu:256-263, _bpool, flatten `in = out`): DY is the gradient
  * w.r.t. the run's last tensor; each stage's input buffer receives its dX (X receives the run's dX). */
 int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);

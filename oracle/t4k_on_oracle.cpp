@@ -188,6 +188,11 @@ int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *b, int N, 
     if (b->pre_layer) t4o_tt_op(T4K_MUL, g, b->pre_mask, X, n1);
     return T4K_OK;
 }
+int t4k_conv2d_block_fwd(const float *I, float *IC, float *O, const float *F, const float *B, const t4k_poolblock *blk, int N, int H1, int W1, int C1,
+                         int H0, int W0, int C0, int K, int S, int P, t4k_stream_t st) {
+    int r = t4k_conv2d_fwd2(I, IC, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, st); if (r) return r;
+    return t4k_poolblock_fwd(O, blk, N, H0, W0, H0 / blk->KS, W0 / blk->KS, C0, st);
+}
 int t4k_opt_multi(int kind, const t4k_param_rec *tab, int nt, long, float lr, float b1, float b2, float wd, t4k_stream_t) {
     for (int i = 0; i < nt; i++) {
         const t4k_param_rec &r = tab[i];

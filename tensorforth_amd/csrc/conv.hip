@@ -35,13 +35,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LDS_FILTER_FLOATS = 8192;          // 32 KiB filter slice per workgroup
 
+// element-wise run that follows the convolution (dropout/activation -> 2x2 pool -> activation -> flatten copy, see fused.hip),
+// applied in the conv epilogue: with a window-major pixel order the four positions of a pool window are four consecutive
+// accumulator registers of one lane, so the whole run is register-local
+struct PoolEpi {
+    float *P, *Q, *R, *R2, *Fpre, *Fpost;
+    int pre, pool, post; float a_pre, a_post;
+    RngArg rng;
+};
+
 // ------------------------------------------------------------------ forward / dX gather-GEMM
 // BWD = false: forward (Cin = C1 of I, Cout = C0);  BWD = true: dX (Cin = C0 of dO, Cout = C1)
-template <int K, int S, int P, bool BWD>
+template <int K, int S, int P, bool BWD, bool POOL = false>
 __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Y2,
                                                const float *__restrict__ F, const float *__restrict__ B,
                                                int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout,
-                                               int C0 /* filter inner dim */, int pairs_per_chunk, int bx, int by, int ksplit = 1) {
+                                               int C0 /* filter inner dim */, int pairs_per_chunk, int bx, int by, int ksplit = 1,
+                                               const PoolEpi *pe = nullptr) {
     __shared__ float Bl[LDS_FILTER_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const long npix = (long)N * Hy * Wy;
@@ -53,7 +63,13 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
     const int  co0  = by * 32;                               // output-channel tile
     const bool pok  = pix < npix;
     int jy = 0, iy = 0, n = 0;
-    if (pok) { jy = (int)(pix % Wy); long t = pix / Wy; iy = (int)(t % Hy); n = (int)(t / Hy); }
+    if (pok) {
+        if (POOL) {                                          // window-major: row m = 4 * window + position (Hy, Wy even)
+            const long wdx = pix >> 2; const int pos = (int)(pix & 3), W2 = Wy >> 1, H2 = Hy >> 1;
+            const int j0 = (int)(wdx % W2); const long t = wdx / W2; const int i0 = (int)(t % H2); n = (int)(t / H2);
+            iy = 2 * i0 + (pos >> 1); jy = 2 * j0 + (pos & 1);
+        } else { jy = (int)(pix % Wy); long t = pix / Wy; iy = (int)(t % Hy); n = (int)(t / Hy); }
+    }
     const float *nX = X + (long)n * Hx * Wx * Cin;
 
     f32x16 acc;
@@ -156,6 +172,46 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
     }
     // ---- epilogue: D[row = pixel][col = channel]; col = lane&31, row = (r&3)+8*(r>>2)+4*h
     const int co = co0 + l31;
+    if (POOL) {
+        // rows 4q+{0..3} (+4h) of this lane are the four positions of pool window tile*8 + 2q + h
+        uint64_t rbase = 0, rseed = 0;
+        const bool draw = pe->pre == T4K_L_DROPOUT;
+        if (draw) rng_begin(pe->rng, rbase, rseed);
+        if (co < Cout) {
+            const float bias = B ? B[co] : 0.f;
+            const int W2 = Wy >> 1, H2 = Hy >> 1;
+            const long nwin = npix >> 2;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const long wdx = tile * 8 + 2 * q + h;
+                if (wdx >= nwin) continue;
+                const int j0 = (int)(wdx % W2); const long t = wdx / W2; const int i0 = (int)(t % H2); const long nn = t / H2;
+                float pv = 0.f; bool first = true;
+#pragma unroll
+                for (int pos = 0; pos < 4; pos++) {
+                    const long a = (((nn * Hy + 2 * i0 + (pos >> 1)) * Wy) + 2 * j0 + (pos & 1)) * Cout + co;
+                    float e = acc[4 * q + pos] + bias;
+                    Y[a] = e;
+                    if (pe->pre) {
+                        float o, f;
+                        act_rt(pe->pre, e, draw ? philox_u01_at(rbase, rseed, a) : 0.f, pe->a_pre, o, f);
+                        pe->Fpre[a] = f; pe->P[a] = o; e = o;
+                    }
+                    if (pe->pool == T4K_L_MAXPOOL)      pv = first ? e : fmaxf(e, pv);
+                    else if (pe->pool == T4K_L_MINPOOL) pv = first ? e : fminf(e, pv);
+                    else                                pv += e;
+                    first = false;
+                }
+                if (pe->pool == T4K_L_AVGPOOL) pv /= 4.0f;
+                const long z = wdx * Cout + co;
+                pe->Q[z] = pv;
+                if (pe->post) { float o, f; act_rt(pe->post, pv, 0.f, pe->a_post, o, f); pe->Fpost[z] = f; pe->R[z] = o; pv = o; }
+                if (pe->R2) pe->R2[z] = pv;
+            }
+        }
+        if (draw && pe->rng.state) rng_advance_n(pe->rng.state, rbase, (uint64_t)((npix * Cout + 3) >> 2), gridDim.x * gridDim.y);
+        return;
+    }
     if (co < Cout) {
         const float bias = (!BWD && B) ? B[co] : 0.f;
 #pragma unroll
@@ -164,6 +220,12 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
             if (p2 < npix) { const float v = acc[r] + bias; Y[p2 * Cout + co] = v; if (Y2) Y2[p2 * Cout + co] = v; }
         }
     }
+}
+// forward convolution with the element-wise run behind it (t4k_conv2d_block_fwd)
+template <int K, int S, int P>
+__global__ void __launch_bounds__(256) k_conv_gemm_pool(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ F, const float *__restrict__ B,
+                                                        int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0, int pairs_per_chunk, int ksplit, PoolEpi pe) {
+    conv_gemm_body<K, S, P, false, true>(X, Y, nullptr, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, pairs_per_chunk, blockIdx.x, blockIdx.y, ksplit, &pe);
 }
 
 template <int K, int S, int P, bool BWD>
@@ -569,6 +631,7 @@ void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, fl
     }
 }
 
+bool conv_block_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_BLOCK"); v = e ? atoi(e) : 1; } return v != 0; }
 bool conv_big_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_BIG"); v = e ? atoi(e) : 1; } return v != 0; }
 bool conv_few_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_FEW"); v = e ? atoi(e) : 1; } return v != 0; }
 // two waves per tile when the layer is small enough to leave SIMDs empty and has enough k-work to split
@@ -651,6 +714,38 @@ int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, cons
     const long npix = (long)N * H0 * W0;
     dim3 g((unsigned)((npix + 127) / 128), (unsigned)((C0 + 31) / 32));
     launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
+    T4K_LAUNCH_CHECK();
+    return T4K_OK;
+}
+
+// conv forward + the element-wise run behind it (dropout/activation -> 2x2 pool -> activation -> flatten copy) in ONE launch
+// when the layer takes the gather-MFMA kernel; otherwise the two launches t4k_conv2d_fwd2 + t4k_poolblock_fwd.
+int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
+                         int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!blk) return fail(T4K_ERR_ARG, "t4k_conv2d_block_fwd: null block");
+    int fG, fNG;
+    const bool fusable = blk->pool_layer && blk->KS == 2 && (H0 % 2) == 0 && (W0 % 2) == 0 && S == 1 && (K == 3 || K == 5) &&
+                         blk->pool_out && (!blk->pre_layer || (blk->pre_mask && blk->pre_out)) && (!blk->post_layer || (blk->post_mask && blk->post_out)) &&
+                         !(conv_few_on() && conv_few_ok(K, C1, C0, &fG, &fNG)) && !(conv_big_on() && conv_big_ok(C1, C0)) &&
+                         conv_supported(K, S, P) && I && O && F && B && conv_block_on();
+    if (!fusable) {
+        int rc = t4k_conv2d_fwd2(I, ICOPY, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, s); if (rc) return rc;
+        return t4k_poolblock_fwd(O, blk, N, H0, W0, H0 / blk->KS, W0 / blk->KS, C0, s);
+    }
+    hipStream_t hs = t4k::S(s);
+    if (ICOPY) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, hs));
+    PoolEpi pe;
+    pe.P = blk->pre_out; pe.Q = blk->pool_out; pe.R = blk->post_out; pe.R2 = blk->copy_out; pe.Fpre = blk->pre_mask; pe.Fpost = blk->post_mask;
+    pe.pre = blk->pre_layer; pe.pool = blk->pool_layer; pe.post = blk->post_layer; pe.a_pre = blk->pre_alpha; pe.a_post = blk->post_alpha;
+    const long npix = (long)N * H0 * W0;
+    pe.rng = RngArg{0, 0, nullptr};
+    if (pe.pre == T4K_L_DROPOUT) pe.rng = rng_draw(hs, (uint64_t)((npix * C0 + 3) >> 2));
+    const int ksplit = conv_gemm_ksplit(npix, C0, C1, K);
+    const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);
+    const dim3 g((unsigned)((npix + (128 / ksplit) - 1) / (128 / ksplit)), (unsigned)((C0 + 31) / 32));
+    if (K == 3) hipLaunchKernelGGL((k_conv_gemm_pool<3, 1, 1>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe);
+    else        hipLaunchKernelGGL((k_conv_gemm_pool<5, 1, 2>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }

@@ -154,6 +154,17 @@ __device__ __forceinline__ void rng_begin(const RngArg &a, uint64_t &base, uint6
         seed = __hip_atomic_load(&a.state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else { base = a.base; seed = a.seed; }
 }
+// same, when `participants` workgroups of the launch each call it once (every workgroup that drew from the stream)
+__device__ __forceinline__ void rng_advance_n(uint64_t *state, uint64_t base, uint64_t nq, unsigned participants) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add((unsigned *)&state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == participants - 1) {
+            __hip_atomic_store((unsigned *)&state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[0], base + nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 __device__ __forceinline__ void rng_state_read(const uint64_t *state, uint64_t &base, uint64_t &seed) {
     base = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     seed = __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -268,6 +268,14 @@ void Model::run_forward(Tensor &input) {
             x = prob.data; i++;
             continue;
         }
+        if (fused && in.grad_fn == T4K_L_CONV && i + 2 < L && run_of_[i + 1] >= 0 && runs_[run_of_[i + 1]].blk.pool_layer &&
+            runs_[run_of_[i + 1]].blk.KS == 2) {        // conv + the element-wise run behind it: the run rides in the conv epilogue
+            const Run &r = runs_[run_of_[i + 1]];
+            chk(t4k_conv2d_block_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, out.data, in.grad[0]->data, in.grad[1]->data, &r.blk,
+                                     out.N(), in.H(), in.W(), in.C(), out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], stream()), "nn#fconv+run");
+            x = at(i + 1 + r.count).data; i += r.count;
+            continue;
+        }
         if (i == 0 && copy_in_conv) {
             chk(t4k_conv2d_fwd2(x, n0.data, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
                                 out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], stream()), "nn#fconv");
