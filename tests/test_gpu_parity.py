@@ -554,3 +554,38 @@ def test_error_paths_return_status_and_reference_messages(t4k, dev):
     # the library is still healthy afterwards
     t4k.call("t4k_math", 12, p(x), 2.0, x.numel(), None)                                       # FILL
     assert float(dev.down(x).sum()) == 2.0 * x.numel()
+
+
+def test_conv2d_many_channels_full_size_spot_checks(t4k, dev):
+    """CIFAR-class layer (N=64, 32x32, 64 -> 128 channels: the LDS-staged MFMA kernels) checked against float64 numpy on
+    randomly chosen output elements of forward, dX (reference's flipped-filter scatter, nmath.tcu:304-324) and dF / dB -
+    the oracle's scalar loops would take minutes at this size."""
+    rng = np.random.default_rng(2024)
+    N, H, C1, C0, K, Pd = 64, 32, 64, 128, 3, 1
+    I = rng.standard_normal((N, H, H, C1)).astype(np.float32)
+    F = (rng.standard_normal((C1, K, K, C0)) * 0.05).astype(np.float32)
+    B = rng.standard_normal(C0).astype(np.float32)
+    G = rng.standard_normal((N, H, H, C0)).astype(np.float32)
+    dI, dF_, dB_, dG = dev.up(I), dev.up(F), dev.up(B), dev.up(G)
+    dO, dDX = dev.zeros((N, H, H, C0)), dev.zeros((N, H, H, C1))
+    dDF, dDB = dev.zeros((C1, K, K, C0)), dev.zeros(C0)
+    t4k.call("t4k_conv2d_fwd", p(dI), p(dO), p(dF_), p(dB_), N, H, H, C1, H, H, C0, K, 1, Pd, None)
+    t4k.call("t4k_conv2d_bwd", p(dI), p(dG), p(dDX), p(dF_), p(dDF), p(dDB), N, H, H, C1, H, H, C0, K, 1, Pd, 1, None)
+    O, DX, DF, DB = dev.down(dO), dev.down(dDX), dev.down(dDF), dev.down(dDB)
+    Ip = np.pad(I.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    Gp = np.pad(G.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    F64 = F.astype(np.float64)
+    for _ in range(48):
+        n, i, j = rng.integers(0, N), rng.integers(0, H), rng.integers(0, H)
+        co, ci = rng.integers(0, C0), rng.integers(0, C1)
+        # forward: O[n,i,j,co] = B[co] + sum I[n,i+ky-1,j+kx-1,:] . F[:,ky,kx,co]
+        want = B[co] + sum(Ip[n, i + ky, j + kx, :] @ F64[:, ky, kx, co] for ky in range(K) for kx in range(K))
+        assert abs(O[n, i, j, co] - want) <= 1e-4 * max(1.0, abs(want))
+        # dX[n,y,x,c1] = sum dO[n, y+1-ky, x+1-kx, :] . F[c1, 2-ky, 2-kx, :]   (padded index y+1-ky+1 = y+2-ky)
+        want = sum(Gp[n, i + 2 - ky, j + 2 - kx, :] @ F64[ci, K - 1 - ky, K - 1 - kx, :] for ky in range(K) for kx in range(K))
+        assert abs(DX[n, i, j, ci] - want) <= 1e-4 * max(1.0, abs(want))
+    for _ in range(12):
+        ci, co, ky, kx = rng.integers(0, C1), rng.integers(0, C0), rng.integers(0, K), rng.integers(0, K)
+        want = float(np.sum(Ip[:, ky:ky + H, kx:kx + H, ci] * G[:, :, :, co].astype(np.float64)))
+        assert abs(DF[ci, ky, kx, co] - want) <= 2e-4 * max(1.0, abs(want))            # 65536-term fp32 accumulation
+    np.testing.assert_allclose(DB, G.astype(np.float64).sum(axis=(0, 1, 2)), rtol=2e-4, atol=2e-3)
