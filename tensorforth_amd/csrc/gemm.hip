@@ -530,7 +530,8 @@ __global__ void __launch_bounds__(256) k_gemm_glds(GemmP p) {
 template <int BK, bool AKC, bool BKC, bool PRIO = false>   // PRIO: s_setprio around the MFMA burst - measured +1.2 us at 1024^3, kept off
 __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     constexpr int BM = 64, BN = 64;
-    constexpr int NC = BK / 8, CH = BK / 4, SW = 64 / BK;
+    constexpr int NC = BK / 8, CH = BK / 4, SW = (64 / BK) > 0 ? (64 / BK) : 1;
+    constexpr int NST = (BK >= 128) ? 2 : 3;         // stage buffers: a 128-deep stage is 64 KiB, two of them fit (half the barriers per K)
     constexpr int STAGE = (BM + BN) * BK;          // floats per stage buffer
     constexpr int NI = BK / 4;                     // 1-KiB DMA instructions per operand per stage
     constexpr int NJ = NI / 8;                     // ... per wave (8 waves)
@@ -624,8 +625,8 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     };
 
     if (nst > 0) issue(0, 0);
-    if (nst > 1) issue(1, 1);
-    wait_next(nst > 1);
+    if (NST == 3 && nst > 1) issue(1, 1);
+    wait_next(NST == 3 && nst > 1);
 
     // Software pipeline: the operands of chunk c+1 are read BEFORE the MFMAs of chunk c are issued,
     // and the MFMAs of a stage's last chunk are issued after the barrier, behind the first reads of
@@ -635,8 +636,9 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     int buf = 0;
     for (int kt = 0; kt < nst; kt++) {
         int nb = buf + 2; if (nb >= 3) nb -= 3;
-        int b1 = buf + 1; if (b1 >= 3) b1 = 0;
-        if (kt + 2 < nst) issue(kt + 2, nb);                // overwrites the buffer read in stage kt-1
+        int b1 = buf + 1; if (b1 >= NST) b1 = 0;
+        if (NST == 3) { if (kt + 2 < nst) issue(kt + 2, nb); }      // overwrites the buffer read in stage kt-1
+        else          { if (kt + 1 < nst) issue(kt + 1, b1); }      // two buffers: the other one was read in stage kt-1
         const float *a = lds + buf * STAGE, *b = a + BM * BK;
 #pragma unroll
         for (int ci = 0; ci + 1 < NCG; ci++) {
@@ -648,7 +650,7 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
 #pragma unroll
             for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
         }
-        wait_next(kt + 2 < nst);                            // all my reads of stage kt done; stage kt+1 visible
+        wait_next(NST == 3 && kt + 2 < nst);                // all my reads of stage kt done; stage kt+1 visible
         float na[4], nbv[4];
         if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, c0, na, nbv);
         __builtin_amdgcn_sched_barrier(0);
@@ -707,7 +709,7 @@ void launch_glds(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
 
 template <int BK>
 void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)3 * 128 * BK * sizeof(float);
+    constexpr size_t lds_bytes = (size_t)((BK >= 128) ? 2 : 3) * 128 * BK * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, true, false>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -776,9 +778,9 @@ void launch_variant(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
     else            launch_one<BM, BN, BK, false, true,  VEC, SKEW, FULL>(p, grid, s);
 }
 
-int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 = BK64, bit1 = SKEW, bit2 = LDS-DMA pipeline, bit3 = pair mode, bit4 = 8-wave workgroups (default 21)
+int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 = BK64, bit1 = SKEW, bit2 = LDS-DMA pipeline, bit3 = pair mode, bit4 = 8-wave workgroups, bit5 = 128-deep stages with 2 LDS buffers (default 53)
     static int v = -1;
-    if (v < 0) { const char *e = getenv("T4K_GEMM_VARIANT"); v = e ? atoi(e) : 21; }
+    if (v < 0) { const char *e = getenv("T4K_GEMM_VARIANT"); v = e ? atoi(e) : 53; }
     return v;
 }
 
@@ -846,7 +848,10 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     } else {
         const bool full = M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
         if (full && (var & 4)) {
-            if ((var & 16) && !p.pair) { if (var & 1) launch_glds8<64>(p, grid, tA, tB, hs); else launch_glds8<32>(p, grid, tA, tB, hs); }
+            if ((var & 16) && !p.pair) {
+                if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs);   // bit5: 128-deep stages, 2 buffers
+                else if (var & 1) launch_glds8<64>(p, grid, tA, tB, hs); else launch_glds8<32>(p, grid, tA, tB, hs);
+            }
             else if ((var & 1) && !p.pair) launch_glds<64>(p, grid, tA, tB, hs); else launch_glds<32>(p, grid, tA, tB, hs);   // pair: 2 x 48 KiB LDS per CU
         } else if (full) {
             switch (var & 3) {

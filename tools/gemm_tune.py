@@ -18,16 +18,16 @@ def one(shape=(1024, 1024, 1024), iters=200):
     e0 = ctypes.c_void_p(); e1 = ctypes.c_void_p()
     k.call("t4k_event_create", ctypes.byref(e0)); k.call("t4k_event_create", ctypes.byref(e1))
     for _ in range(20): k.call("t4k_gemm", *args)
-    best = 1e9
-    for _ in range(5):
+    best = 1e9; reps = []
+    for _ in range(8):
         k.call("t4k_event_record", e0, None)
         for _ in range(iters): k.call("t4k_gemm", *args)
         k.call("t4k_event_record", e1, None); k.call("t4k_event_sync", e1)
         ms = ctypes.c_float(); k.call("t4k_event_elapsed_ms", e0, e1, ctypes.byref(ms))
-        best = min(best, ms.value / iters)
+        best = min(best, ms.value / iters); reps.append(round(ms.value / iters * 1e3, 2))
     tf = 2.0 * M * N * K / (best * 1e-3) / 1e12
     print("variant=%s shape=%s  %.2f us  %.1f TFLOP/s (%.1f%% of 157.3)  relerr=%.2e" %
-          (os.environ.get("T4K_GEMM_VARIANT", "default"), shape, best * 1e3, tf, 100 * tf / 157.3, err), flush=True)
+          (os.environ.get("T4K_GEMM_VARIANT", "default"), shape, best * 1e3, tf, 100 * tf / 157.3, err), "reps_us", reps, flush=True)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
