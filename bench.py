@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 BASELINE_METRIC = 'CNN train images/sec + fp32 GEMM TFLOP/s (% MI355X MFMA peak), 1→8 GPUs'    # BASELINE.json "metric"
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
-GEMM_TRAFFIC_BYTES = 29465614    # fabric-side bytes per 1024^3 launch from the PMC pass (algorithmic minimum 12.6 MB)
+GEMM_TRAFFIC_BYTES = 29479911    # fabric-side bytes per 1024^3 launch from the PMC pass (algorithmic minimum 12.6 MB)
 # algorithmic bytes per image and parameter count (SURVEY.md 8d / BASELINE.md 3)
 NETS = {"nn_f": dict(bytes_per_img=494720, params=101030, flop_per_img=3134160),
         "nn_c": dict(bytes_per_img=294800, params=197210, flop_per_img=1605360)}
