@@ -207,6 +207,34 @@ __global__ void __launch_bounds__(BLK) k_bn_fin(const float *__restrict__ part, 
         }
     }
 }
+// Data-parallel (synchronised) batch norm: the batch is sharded over ranks, so the per-channel sums must cover every shard.
+// k_bn_sums folds the chunk partials into sums[0..2C) (all-reduced in place by the caller) and keeps the rank-local copy in
+// sums[2C..4C); k_bn_fin_sync finalises from the global sums over NHW_global = world x NHW.  dgamma/dbeta accumulate the LOCAL
+// sums over NHW_global, so the SUM all-reduce of the gradient slab that follows yields the same batch means one rank x the
+// whole batch would have produced.
+__global__ void __launch_bounds__(BLK) k_bn_sums(const float *__restrict__ part, float *__restrict__ sums, int C, int nchunk) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int k = lane; k < nchunk; k += 64) { a += part[((long)k * 2 + 0) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+    a = wave_sum_all(a); b = wave_sum_all(b);
+    if (lane == 0) { sums[c] = a; sums[C + c] = b; sums[2 * C + c] = a; sums[3 * C + c] = b; }
+}
+template <int MODE>
+__global__ void __launch_bounds__(BLK) k_bn_fin_sync(const float *__restrict__ sums, float *stat, float *DW, float *DB,
+                                                     float NHWg, int C, int train) {
+    const int c = blockIdx.x * BLK + threadIdx.x;
+    if (c >= C) return;
+    const float a = sums[c], b = sums[C + c];
+    if (MODE == 0) {
+        const float avg = a / NHWg, var = b / NHWg - avg * avg;
+        stat[C + c] = avg;
+        stat[c]     = 1.0f / (sqrtf(fmaxf(var, 0.0f)) + DU_EPS);
+    } else {
+        stat[C + c] = a / NHWg; stat[2 * C + c] = b / NHWg;
+        if (train) { DB[c] += sums[2 * C + c] / NHWg; DW[c] += sums[3 * C + c] / NHWg; }
+    }
+}
 // single-launch variant for small row counts: one block per channel, finalised in the same launch
 __global__ void __launch_bounds__(BLK) k_bn_stats(const float *__restrict__ I, float *stat, long NHW, int C) {
     __shared__ float sm[4];
@@ -250,6 +278,22 @@ __global__ void __launch_bounds__(BLK) k_dbn_apply(const float *__restrict__ W, 
         int c = (int)(z % C);
         DX[z] = (stat[c] * W[c]) * (DY[z] - stat[C + c] - XH[z] * stat[2 * C + c]);
     }
+}
+
+
+// synchronised statistics for data-parallel runs (a communicator exists): chunk partials -> sums -> all-reduce -> finalise
+template <int MODE>
+static int bn_stats_sync(const float *X, const float *Y, float *stat, float *DW, float *DB, long NHW, int C, int train, t4k_stream_t s) {
+    long nch = (NHW + 255) / 256; if (nch > 2048) nch = 2048;
+    const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
+    float *part = ws_for(s), *sums = part + (size_t)nch * 2 * C;
+    if (((size_t)nch * 2 + 4) * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
+    hipLaunchKernelGGL(k_bn_part<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), X, Y, part, NHW, C, rpc);
+    hipLaunchKernelGGL(k_bn_sums, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, sums, C, (int)nch);
+    int rc = t4k_allreduce_sum(sums, 2L * C, s); if (rc != T4K_OK) return rc;
+    hipLaunchKernelGGL(k_bn_fin_sync<MODE>, dim3((C + BLK - 1) / BLK), dim3(BLK), 0, S(s), sums, stat, DW, DB,
+                       (float)NHW * (float)t4k_comm_world(), C, train);
+    return T4K_OK;
 }
 
 } // namespace
@@ -305,7 +349,9 @@ int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const
                       float *stat, int N, int HW, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_fwd: shape");
     const long NHW = (long)N * HW, total = NHW * C;
-    if (NHW >= 2048) {                                   // image-sized: chunked coalesced column sums + per-channel fold
+    if (t4k_comm_world() > 0) {                          // data parallel: statistics over every rank's shard
+        int rc = bn_stats_sync<0>(I, nullptr, stat, nullptr, nullptr, NHW, C, 0, s); if (rc != T4K_OK) return rc;
+    } else if (NHW >= 2048) {                            // image-sized: chunked coalesced column sums + per-channel fold
         long nch = (NHW + 255) / 256; if (nch > 2048) nch = 2048;
         const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
         float *part = ws_for(s);
@@ -320,7 +366,9 @@ int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *D
                       float *DW, float *DB, float *stat, int N, int HW, int C, int train, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_bwd: shape");
     const long NHW = (long)N * HW, total = NHW * C;
-    if (NHW >= 2048) {
+    if (t4k_comm_world() > 0) {
+        int rc = bn_stats_sync<1>(DY, XH, stat, DW, DB, NHW, C, train, s); if (rc != T4K_OK) return rc;
+    } else if (NHW >= 2048) {
         long nch = (NHW + 255) / 256; if (nch > 2048) nch = 2048;
         const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
         float *part = ws_for(s);

@@ -101,3 +101,34 @@ def test_two_rank_gloo_equals_single_process_large_batch(tmp_path):
         assert np.array_equal(a, b), "replicas diverged"                            # same slab on both ranks => bit-identical updates
         np.testing.assert_allclose(a, p, rtol=2e-5, atol=2e-6)                       # == large-batch update up to summation order
     assert r0["tot"][1] == GLOBAL_N
+
+
+def test_sharded_batchnorm_sums_reproduce_whole_batch_oracle():
+    """The data-parallel batch norm of reduce.hip (k_bn_sums / k_bn_fin_sync): per-rank column sums, SUM over ranks,
+    finalise over world x NHW; dgamma/dbeta take the LOCAL sums over the GLOBAL count so that the slab all-reduce that
+    follows yields the whole-batch means.  Restated in numpy per shard and checked against the oracle on the whole batch."""
+    import t4oracle
+    o = t4oracle.lib(); P = t4oracle.P
+    rng = np.random.default_rng(3)
+    N, HW, C, world = 8, 36, 5, 2
+    x = (rng.standard_normal((N, HW, C)) * 2 + 1).astype(np.float32)
+    g = rng.standard_normal(C).astype(np.float32); b = rng.standard_normal(C).astype(np.float32)
+    gy = rng.standard_normal(x.shape).astype(np.float32)
+    y = np.zeros_like(x); xh = np.zeros_like(x); stat = np.zeros(3 * C, np.float32)
+    o.t4o_batchnorm_fwd(P(x), P(y), P(xh), P(g), P(b), P(stat), N, HW, C)
+    fstat = stat.copy()                                                       # backward reuses the stat rows
+    DX = np.zeros_like(x); DW = np.zeros(C, np.float32); DB = np.zeros(C, np.float32)
+    o.t4o_batchnorm_bwd(P(g), P(gy), P(xh), P(DX), P(DW), P(DB), P(stat), N, HW, C, 1)
+    from tensorforth_amd import dp
+    nhw_g = np.float32(N * HW)
+    shards = [slice(*dp.shard_rows(N, r, world)) for r in range(world)]
+    sums = sum(np.stack([x[s].reshape(-1, C).sum(0), (x[s].reshape(-1, C) ** 2).sum(0)]) for s in shards)   # the all-reduce
+    avg = sums[0] / nhw_g; istd = 1.0 / (np.sqrt(np.maximum(sums[1] / nhw_g - avg * avg, 0)) + np.float32(1e-6))
+    np.testing.assert_allclose(avg, fstat[C:2 * C], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(istd, fstat[:C], rtol=1e-4)
+    slab = np.zeros((2, C), np.float32)
+    for s in shards:                                                          # each rank's dbeta/dgamma, then the slab SUM
+        loc = np.stack([gy[s].reshape(-1, C).sum(0), (gy[s] * xh[s]).reshape(-1, C).sum(0)])
+        slab += loc / nhw_g
+    np.testing.assert_allclose(slab[0], DB, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(slab[1], DW, rtol=1e-4, atol=1e-6)

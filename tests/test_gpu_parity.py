@@ -285,6 +285,24 @@ def test_linear_fwd_bwd(t4k, dev, oracle, N, E0, E1):
 
 @pytest.mark.parametrize("N,HW,C", [(8, 49, 6), (16, 256, 70), (4, 1024, 128)])   # single-launch stats / chunked column sums
 def test_batchnorm(t4k, dev, oracle, N, HW, C):
+    _batchnorm_case(t4k, dev, oracle, N, HW, C)
+
+
+@pytest.mark.parametrize("N,HW,C", [(8, 49, 6), (16, 256, 70)])
+def test_batchnorm_synchronised_statistics_world_one(t4k, dev, oracle, N, HW, C):
+    """With a communicator attached the statistics go partials -> sums -> all-reduce -> finalise (data-parallel batch norm);
+    one rank must reproduce the plain path's (= the oracle's) result."""
+    import ctypes
+    lib = t4k.lib
+    raw = (ctypes.c_ubyte * 128)()
+    assert lib.t4k_comm_unique_id(raw) == 0 and lib.t4k_comm_init(raw, 0, 1) == 0, lib.t4k_last_error()
+    try:
+        _batchnorm_case(t4k, dev, oracle, N, HW, C)
+    finally:
+        lib.t4k_comm_destroy()
+
+
+def _batchnorm_case(t4k, dev, oracle, N, HW, C):
     o = oracle.lib(); P = oracle.P
     rng = np.random.default_rng(8)
     x = (rng.standard_normal((N, HW, C)) * 2 + 1).astype(np.float32)
