@@ -284,6 +284,12 @@ int t4k_linear_bwd(const float *X, const float *W, const float *DY, float *DX,
  * DXM = DX (*) MASK (`in = out * mask`, _bactivate backprop.cu:256-263); MASK == DXM == NULL behaves as t4k_linear_bwd */
 int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, const float *MASK, float *DXM,
                     float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
+/* loss-side start of backprop folded into the last linear layer's backward (Model::backprop prep `out -= target`,
+ * backprop.cu:60-75, + the pass-through `in = out` of a softmax / sigmoid / log-softmax output layer, :122-131, + _blinear):
+ * OUT -= TGT in place, OUT2 = OUT (may be NULL), then exactly t4k_linear_bwd2 with DY = OUT.  One launch when the head is
+ * small and DX aliases X; otherwise the separate launches. */
+int t4k_loss_linear_bwd(const float *X, const float *W, float *OUT, const float *TGT, float *OUT2, float *DX,
+                        const float *MASK, float *DXM, float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
 /* multi-tensor optimizer step over a parameter table (one launch for all layers).
  * tab_dev: array of n_tensors records {G, DG, M, V, n, Nw} on the device. */
 typedef struct { float *G, *DG, *M, *V; long n; int Nw; int pad; } t4k_param_rec;

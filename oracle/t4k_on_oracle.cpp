@@ -146,6 +146,11 @@ int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, 
     if (DXM) return rc(t4o_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1), "k_tt_op");
     return T4K_OK;
 }
+int t4k_loss_linear_bwd(const float *X, const float *W, float *OUT, const float *TGT, float *OUT2, float *DX, const float *MASK, float *DXM,
+                        float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t st) {
+    int r = t4k_tt_op2(T4K_SUB, OUT, TGT, OUT, OUT2, (long)N * E0, st); if (r) return r;
+    return t4k_linear_bwd2(X, W, OUT, DX, MASK, DXM, DW, DB, N, E0, E1, tr, st);
+}
 int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, t4k_stream_t st) {
     int r = t4k_linear_fwd(X, W, B, Y, N, E0, E1, st); if (r) return r;
     return t4o_softmax(Y, P, N, E0);

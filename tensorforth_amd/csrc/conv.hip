@@ -44,6 +44,16 @@ struct PoolEpi {
     RngArg rng;
 };
 
+// component j of the Philox block held by lane SRC of this lane's quad, as a uniform (0,1] draw
+template <int SRC>
+__device__ __forceinline__ float quad_pick(const uint32_t r[4], int j) {
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r[0], SRC * 0x55, 0xf, 0xf, true);
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r[1], SRC * 0x55, 0xf, 0xf, true);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r[2], SRC * 0x55, 0xf, 0xf, true);
+    const uint32_t t3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)r[3], SRC * 0x55, 0xf, 0xf, true);
+    return u01(j == 0 ? t0 : (j == 1 ? t1 : (j == 2 ? t2 : t3)));
+}
+
 // ------------------------------------------------------------------ forward / dX gather-GEMM
 // BWD = false: forward (Cin = C1 of I, Cout = C0);  BWD = true: dX (Cin = C0 of dO, Cout = C1)
 template <int K, int S, int P, bool BWD, bool POOL = false>
@@ -66,9 +76,9 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
     if (pok) {
         if (POOL) {                                          // window-major: row m = 4 * window + position (Hy, Wy even)
             const long wdx = pix >> 2; const int pos = (int)(pix & 3), W2 = Wy >> 1, H2 = Hy >> 1;
-            const int j0 = (int)(wdx % W2); const long t = wdx / W2; const int i0 = (int)(t % H2); n = (int)(t / H2);
+            int j0, i0; split3(wdx, W2, H2, j0, i0, n);
             iy = 2 * i0 + (pos >> 1); jy = 2 * j0 + (pos & 1);
-        } else { jy = (int)(pix % Wy); long t = pix / Wy; iy = (int)(t % Hy); n = (int)(t / Hy); }
+        } else split3(pix, Wy, Hy, jy, iy, n);
     }
     const float *nX = X + (long)n * Hx * Wx * Cin;
 
@@ -181,32 +191,49 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
             const float bias = B ? B[co] : 0.f;
             const int W2 = Wy >> 1, H2 = Hy >> 1;
             const long nwin = npix >> 2;
+            // window coordinates: one split for the lane's first window, the other three advance by two windows each
+            int j0, i0, nn0; split3(tile * 8 + h, W2, H2, j0, i0, nn0);
+            long nn = nn0;
+            // Cout % 4 == 0: the four lanes of a quad (channels 4g..4g+3) sit in ONE Philox counter block per pixel, so lane j
+            // generates only the block of window position j and the quad exchanges components (4 blocks per lane, not 16)
+            const bool quad = draw && (Cout & 3) == 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const long wdx = tile * 8 + 2 * q + h;
-                if (wdx >= nwin) continue;
-                const int j0 = (int)(wdx % W2); const long t = wdx / W2; const int i0 = (int)(t % H2); const long nn = t / H2;
-                float pv = 0.f; bool first = true;
-#pragma unroll
-                for (int pos = 0; pos < 4; pos++) {
-                    const long a = (((nn * Hy + 2 * i0 + (pos >> 1)) * Wy) + 2 * j0 + (pos & 1)) * Cout + co;
-                    float e = acc[4 * q + pos] + bias;
-                    Y[a] = e;
-                    if (pe->pre) {
-                        float o, f;
-                        act_rt(pe->pre, e, draw ? philox_u01_at(rbase, rseed, a) : 0.f, pe->a_pre, o, f);
-                        pe->Fpre[a] = f; pe->P[a] = o; e = o;
+                if (wdx < nwin) {
+                    const long a0 = (((nn * Hy + 2 * i0) * Wy) + 2 * j0) * Cout + co;    // window position 0; +Cout, +Wy*Cout, +both
+                    float uq[4] = { 0.f, 0.f, 0.f, 0.f };
+                    if (quad) {
+                        const int j = lane & 3;
+                        const long aj = a0 + (long)((j >> 1) * Wy + (j & 1)) * Cout;
+                        uint32_t r4[4];
+                        philox4x32_10(rbase + (uint64_t)(aj >> 2), rseed, r4);
+                        uq[0] = quad_pick<0>(r4, j); uq[1] = quad_pick<1>(r4, j); uq[2] = quad_pick<2>(r4, j); uq[3] = quad_pick<3>(r4, j);
                     }
-                    if (pe->pool == T4K_L_MAXPOOL)      pv = first ? e : fmaxf(e, pv);
-                    else if (pe->pool == T4K_L_MINPOOL) pv = first ? e : fminf(e, pv);
-                    else                                pv += e;
-                    first = false;
+                    float pv = 0.f; bool first = true;
+#pragma unroll
+                    for (int pos = 0; pos < 4; pos++) {
+                        const long a = a0 + (long)((pos >> 1) * Wy + (pos & 1)) * Cout;
+                        float e = acc[4 * q + pos] + bias;
+                        Y[a] = e;
+                        if (pe->pre) {
+                            float o, f;
+                            act_rt(pe->pre, e, quad ? uq[pos] : (draw ? philox_u01_at(rbase, rseed, a) : 0.f), pe->a_pre, o, f);
+                            pe->Fpre[a] = f; pe->P[a] = o; e = o;
+                        }
+                        if (pe->pool == T4K_L_MAXPOOL)      pv = first ? e : fmaxf(e, pv);
+                        else if (pe->pool == T4K_L_MINPOOL) pv = first ? e : fminf(e, pv);
+                        else                                pv += e;
+                        first = false;
+                    }
+                    if (pe->pool == T4K_L_AVGPOOL) pv /= 4.0f;
+                    const long z = wdx * Cout + co;
+                    pe->Q[z] = pv;
+                    if (pe->post) { float o, f; act_rt(pe->post, pv, 0.f, pe->a_post, o, f); pe->Fpost[z] = f; pe->R[z] = o; pv = o; }
+                    if (pe->R2) pe->R2[z] = pv;
                 }
-                if (pe->pool == T4K_L_AVGPOOL) pv /= 4.0f;
-                const long z = wdx * Cout + co;
-                pe->Q[z] = pv;
-                if (pe->post) { float o, f; act_rt(pe->post, pv, 0.f, pe->a_post, o, f); pe->Fpost[z] = f; pe->R[z] = o; pv = o; }
-                if (pe->R2) pe->R2[z] = pv;
+                j0 += 2;                                                          // next window of this lane: wdx + 2
+                while (j0 >= W2) { j0 -= W2; if (++i0 >= H2) { i0 = 0; nn++; } }
             }
         }
         if (draw && pe->rng.state) rng_advance_n(pe->rng.state, rbase, (uint64_t)((npix * Cout + 3) >> 2), gridDim.x * gridDim.y);
@@ -368,9 +395,7 @@ __global__ void __launch_bounds__(BLK) k_pool(int layer, const float *__restrict
                                               int N, int H1, int W1, int H0, int W0, int C) {
     const long total = (long)N * H0 * W0 * C;
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
-        const int c = (int)(z % C); long t = z / C;
-        const int j0 = (int)(t % W0); t /= W0;
-        const int i0 = (int)(t % H0); const int n = (int)(t / H0);
+        int c, j0, i0, n; long t; split2(z, C, c, t); split3(t, W0, H0, j0, i0, n);
         float v = 0.f; bool first = true;
 #pragma unroll
         for (int y = 0; y < KS; y++)
@@ -393,9 +418,7 @@ __global__ void __launch_bounds__(BLK) k_dpool(int layer, float *I, const float 
                                                int N, int H1, int W1, int H0, int W0, int C) {
     const long total = (long)N * H0 * W0 * C;
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
-        const int c = (int)(z % C); long t = z / C;
-        const int j0 = (int)(t % W0); t /= W0;
-        const int i0 = (int)(t % H0); const int n = (int)(t / H0);
+        int c, j0, i0, n; long t; split2(z, C, c, t); split3(t, W0, H0, j0, i0, n);
         const float dy = DY[z];
         float best = 0.f; long arg = -1;
 #pragma unroll
@@ -451,7 +474,7 @@ __global__ void __launch_bounds__(256) k_conv_few(const float *__restrict__ X, f
         const long pix = pix0 + threadIdx.x;
         const bool live = pix < npix;
         const long pc = live ? pix : 0;
-        const int x = (int)(pc % Wy); long tq = pc / Wy; const int y = (int)(tq % Hy); const int n = (int)(tq / Hy);
+        int x, y, n; split3(pc, Wy, Hy, x, y, n);
         float acc[G];
 #pragma unroll
         for (int u = 0; u < G; u++) acc[u] = 0.f;
@@ -559,7 +582,7 @@ __device__ __forceinline__ void conv_dx_few_body(const float *__restrict__ DO, f
     __syncthreads();
     const long npix = (long)N * H1 * W1;
     for (long pix = (long)bx * 256 + threadIdx.x; pix < npix; pix += (long)gx * 256) {
-        const int x = (int)(pix % W1); long t = pix / W1; const int y = (int)(t % H1); const int n = (int)(t / H1);
+        int x, y, n; split3(pix, W1, H1, x, y, n);
         float acc[CO];
 #pragma unroll
         for (int c = 0; c < CO; c++) acc[c] = 0.f;

@@ -47,9 +47,7 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
     const bool draw = p.pre == T4K_L_DROPOUT;
     if (draw) rng_begin(p.rng, base, seed);
     for (long z = (long)blockIdx.x * blockDim.x + threadIdx.x; z < total; z += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(z % CV) * VW; long t = z / CV;
-        const int j0 = (int)(t % p.W0); t /= p.W0;
-        const int i0 = (int)(t % p.H0); const int n = (int)(t / p.H0);
+        int c, j0, i0, n; long t; split2(z, CV, c, t); c *= VW; split3(t, p.W0, p.H0, j0, i0, n);
         Vec<VW> acc; bool first = true;
 #pragma unroll
         for (int q = 0; q < VW; q++) acc.v[q] = 0.f;
@@ -107,9 +105,7 @@ __global__ void __launch_bounds__(BLK) k_poolblock_bwd(PBB p) {
     const int CV = p.C / VW;
     const long total = (long)p.N * p.H0 * p.W0 * CV;
     for (long z = (long)blockIdx.x * blockDim.x + threadIdx.x; z < total; z += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(z % CV) * VW; long t = z / CV;
-        const int j0 = (int)(t % p.W0); t /= p.W0;
-        const int i0 = (int)(t % p.H0); const int n = (int)(t / p.H0);
+        int c, j0, i0, n; long t; split2(z, CV, c, t); c *= VW; split3(t, p.W0, p.H0, j0, i0, n);
         const long zo = (((long)n * p.H0 + i0) * p.W0 + j0) * p.C + c;
         Vec<VW> g = vload<VW>(p.DY + zo);
         if (p.Rb) vstore<VW>(p.Rb + zo, g);                       // flatten: in = out

@@ -883,7 +883,7 @@ int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
 bool linear_small_ok(int E0, int E1);
 int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs);
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, bool train, hipStream_t hs,
-                      const float *MASK = nullptr, float *DXM = nullptr);
+                      const float *MASK = nullptr, float *DXM = nullptr, const float *TGT = nullptr, float *DY2 = nullptr);
 }
 
 extern "C" {
@@ -958,6 +958,19 @@ int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, 
     }
     if (!DX) return T4K_OK;                             // DX == NULL: dW|dB only
     return gemm_launch(DY, W, DX, nullptr, 1.0f, 0.0f, 0, 0, N, E1, E0, 1, s);   // dX = dY @ W (may overwrite X)
+}
+
+// backprop's `out -= target` (+ the output layer's pass-through copy) folded into the last linear layer's backward
+int t4k_loss_linear_bwd(const float *X, const float *W, float *OUT, const float *TGT, float *OUT2, float *DX,
+                        const float *MASK, float *DXM, float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X || !W || !OUT || !TGT || N < 0 || E0 < 1 || E1 < 1) return fail(T4K_ERR_ARG, "t4k_loss_linear_bwd: bad argument");
+    if ((MASK == nullptr) != (DXM == nullptr) || (DXM && !DX)) return fail(T4K_ERR_ARG, "t4k_loss_linear_bwd: MASK and DXM go together (with DX)");
+    if ((DW == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_loss_linear_bwd: DW and DB go together");
+    if (N == 0) return T4K_OK;
+    if (linear_small_ok(E0, E1) && linear_small_bwd(X, W, OUT, DX, DW, DB, N, E0, E1, train != 0, S(s), MASK, DXM, TGT, OUT2)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
+    int rc = t4k_tt_op2(T4K_SUB, OUT, TGT, OUT, OUT2, (long)N * E0, s); if (rc) return rc;
+    return t4k_linear_bwd2(X, W, OUT, DX, MASK, DXM, DW, DB, N, E0, E1, train, s);
 }
 
 int t4k_gemm_f64acc(const float *A, const float *B, float *O, float alpha, float beta,

@@ -60,7 +60,10 @@ __global__ void __launch_bounds__(256) k_linsmall_fwd(const float *__restrict__ 
 __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const float *__restrict__ W, const float *__restrict__ DY,
                                                       float *DX, float *DW, float *DB, int N, int E0, int E1,
                                                       int nB, int nA, int RA, int *sync, int alias,
-                                                      const float *__restrict__ MASK, float *__restrict__ DXM) {
+                                                      const float *__restrict__ MASK, float *__restrict__ DXM,
+                                                      const float *__restrict__ TGT, float *DYW, float *DY2) {
+    // TGT != NULL (alias mode only): dY = DY - TGT is formed while staging (the `out -= target` start of backprop); the dX
+    // workgroups store it over DY (= DYW) and into DY2 once every workgroup has staged its share (counter sync[2])
     extern __shared__ float sm[];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < nB) {
@@ -70,8 +73,9 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
         int CL = 32; while (CL < E1 + 1 && CL < 256) CL <<= 1;
         const int NG = 256 / CL, c0 = tid % CL, ng = tid / CL;
         float *dys = sm;                                         // dY[:, e0] for the whole batch
-        for (int n = tid; n < N; n += 256) dys[n] = DY[(long)n * E0 + e0];
+        for (int n = tid; n < N; n += 256) dys[n] = DY[(long)n * E0 + e0] - (TGT ? TGT[(long)n * E0 + e0] : 0.f);
         __syncthreads();
+        if (TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // dY column staged
         float acc[3] = {0.f, 0.f, 0.f};                          // columns c0, c0 + 256, c0 + 512 when E1 + 1 > 256
 #pragma unroll 1
         for (int nb = ng; nb < N; nb += NG * 16) {
@@ -120,8 +124,12 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
     float *Ws = sm, *Ds = sm + E0 * E1;                          // W verbatim, then RA rows of dY
     for (int e = tid; e < E0 * E1; e += 256) Ws[e] = W[e];
     const int row0 = ((int)blockIdx.x - nB) * RA;
-    for (int e = tid; e < RA * E0; e += 256) { const int n = row0 + e / E0; Ds[e] = n < N ? DY[(long)n * E0 + e % E0] : 0.f; }
+    for (int e = tid; e < RA * E0; e += 256) {
+        const int n = row0 + e / E0; const long o = (long)n * E0 + e % E0;
+        Ds[e] = n < N ? DY[o] - (TGT ? TGT[o] : 0.f) : 0.f;
+    }
     __syncthreads();
+    if (TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // dY rows staged
     const int total = RA * E1;
     float out[4];                                                // RA * E1 <= 1024 outputs per block
 #pragma unroll
@@ -135,8 +143,16 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
         out[q] = acc;
     }
     if (alias) {                                                 // DX overwrites X: wait until every dW workgroup is done reading it
-        if (tid == 0) while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nB) __builtin_amdgcn_s_sleep(1);
+        if (tid == 0) {
+            while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nB) __builtin_amdgcn_s_sleep(1);
+            if (TGT) while (__hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nA + nB) __builtin_amdgcn_s_sleep(1);
+        }
         __syncthreads();
+        if (TGT)                                                 // every reader of DY has staged: out -= target lands in place
+            for (int e = tid; e < RA * E0; e += 256) {
+                const int n = row0 + e / E0;
+                if (n < N) { const long o = (long)n * E0 + e % E0; DYW[o] = Ds[e]; if (DY2) DY2[o] = Ds[e]; }
+            }
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -157,6 +173,7 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
             if (t == nA - 1) {
                 __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sync + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -191,12 +208,13 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
 
 // returns false when the shape does not qualify (caller falls back to the GEMM path)
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
-                      int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM) {
+                      int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM, const float *TGT, float *DY2) {
     const int nB = (train && DW) ? E0 : 0;
     int RA = 1024 / E1; if (RA > 64) RA = 64; if (RA < 1) RA = 1;        // rows of dX per workgroup (<= 1024 outputs, <= 64 rows of dY in LDS)
     const int nA = DX ? (N + RA - 1) / RA : 0;
     if (nA + nB == 0) return true;
     const bool alias = DX && nB > 0 && (const float *)DX == X;
+    if (TGT && !alias) return false;                                       // the in-place `out -= target` needs the arrival counters
     State &g = st();
     if (alias && (nA + nB > g.cu_count || !g.d_sync)) return false;       // the arrival counter needs every workgroup resident
     size_t lds = sizeof(float) * (size_t)(E0 * E1 + RA * E0);
@@ -204,7 +222,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, g.d_sync + 4090, alias ? 1 : 0, MASK, DXM);
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, g.d_sync + 4090, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2);
     return true;
 }
 

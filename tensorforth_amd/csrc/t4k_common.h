@@ -93,6 +93,22 @@ __device__ __forceinline__ float block_sum(float v, float *smem4) {
     return r;
 }
 
+// flat index -> (n, i, j) of an [N][H][W] grid.  Indices that fit 32 bits (every LeNet/CIFAR-size tensor) take the 32-bit
+// divide: a 64-bit one is ~10x the instructions, and the latency-bound conv / pool kernels do several per lane.
+__device__ __forceinline__ void split3(long p, int W, int H, int &j, int &i, int &n) {
+    if (p < 0x7fffffffL) {
+        const unsigned q = (unsigned)p, t = q / (unsigned)W, m = t / (unsigned)H;
+        j = (int)(q - t * (unsigned)W); i = (int)(t - m * (unsigned)H); n = (int)m;
+    } else {
+        const long t = p / W, m = t / H;
+        j = (int)(p - t * W); i = (int)(t - m * H); n = (int)m;
+    }
+}
+__device__ __forceinline__ void split2(long p, int C, int &c, long &rest) {
+    if (p < 0x7fffffffL) { const unsigned q = (unsigned)p, t = q / (unsigned)C; c = (int)(q - t * (unsigned)C); rest = (long)t; }
+    else { const long t = p / C; c = (int)(p - t * C); rest = t; }
+}
+
 // Philox4x32-10; counter = element_index/4, key = seed (same definition as the oracle)
 __device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, uint32_t out[4]) {
     uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;

@@ -413,6 +413,7 @@ void Model::run_backward(Tensor &tgt) {
     int skip = 0;                                       // layers already handled by the prep launch
     switch (at(-2).grad_fn) {
     case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
+        if (fused && layer.size() > 3 && at(-3).grad_fn == T4K_L_LINEAR) { prep_tgt_ = &tgt; skip = 1; break; }   // rides in the linear backward launch
         if (fused && layer.size() > 2) {                // out -= target, and the pass-through `in = out` of the last layer, in one launch
             chk(t4k_tt_op2(T4K_SUB, out.data, tgt.data, out.data, at(-2).data, (long)out.numel, s), "bprep"); skip = 1; break;
         }
@@ -486,17 +487,24 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
         const int N = in.N(), E0 = (int)out.HWC(), E1 = (int)in.HWC();
         Tensor *gx = concurrent() ? gx_[i] : nullptr;
         if (!gx) {                                      // single stream: reference order (dW reads X, then dX overwrites it)
+            const float *tg = prep_tgt_ ? prep_tgt_->data : nullptr;   // backprop's `out -= target` still pending (run_backward)
+            prep_tgt_ = nullptr;
             // a lone mask-multiply layer (dropout, relu, ...) right in front of this linear layer: its backward rides along
             const bool fused = use_fusion && !(trace && *trace);
             if (fused && i > 0 && run_of_[i - 1] >= 0 && runs_[run_of_[i - 1]].count == 1 && !runs_[run_of_[i - 1]].blk.pool_layer &&
                 runs_[run_of_[i - 1]].blk.pre_layer) {
                 Tensor &prev = at(i - 1);
+                if (tg) chk(t4k_loss_linear_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, in.data, prev.grad[4]->data, prev.data,
+                                            train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#bprep+blinear+act");
+                else
                 chk(t4k_linear_bwd2(in.data, in.grad[0]->data, dy, in.data, prev.grad[4]->data, prev.data, train ? in.grad[2]->data : nullptr,
                                     train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#blinear+act");
                 skip_next_ = true;
                 return in.data;
             }
-            chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, in.data, in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#blinear");
+            if (tg) chk(t4k_loss_linear_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, in.data, nullptr, nullptr,
+                                        in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#bprep+blinear");
+            else chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, in.data, in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#blinear");
             return in.data;
         }
         if (train) chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, nullptr, in.grad[2]->data, in.grad[3]->data, N, E0, E1, 1, fork()), "nn#blinear dW");

@@ -260,6 +260,7 @@ private:
     bool replay(GraphSlot &slot, const void *key, int flags, const float *p);
     void end_capture(GraphSlot &slot, bool capturing);
     bool capturing_ = false;
+    Tensor *prep_tgt_ = nullptr;               // `out -= target` pending: the last linear layer's backward launch performs it
     bool skip_next_ = false;                   // set by bstep when it also ran the backward of the op in front
 };
 

@@ -553,6 +553,33 @@ def test_small_linear_head_is_bit_identical_to_oracle(t4k, dev, oracle, N, E0, E
     assert np.array_equal(dev.down(dXc), DX)
 
 
+@pytest.mark.parametrize("N,E0,E1,mask,train", [(128, 10, 100, True, 1), (128, 10, 100, False, 1), (7, 3, 17, True, 1), (64, 40, 200, False, 1),
+                                                 (128, 10, 100, True, 0), (32, 100, 700, False, 1)])
+def test_loss_prep_folded_into_linear_backward(t4k, dev, oracle, N, E0, E1, mask, train):
+    """t4k_loss_linear_bwd == `out -= target` + pass-through copy + t4k_linear_bwd2 (backprop.cu:60-75, 122-131, 193-254), in one
+    launch when the head is small (in-place store gated by arrival counters), as separate launches otherwise: same values."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N + E0 + E1)
+    X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) * 0.2).astype(np.float32)
+    OUT = rng.random((N, E0)).astype(np.float32); TGT = (rng.random((N, E0)) > 0.9).astype(np.float32)
+    M = (rng.random((N, E1)) > 0.5).astype(np.float32)
+    DW = rng.standard_normal((E0, E1)).astype(np.float32); DB = rng.standard_normal(E0).astype(np.float32)
+    G = OUT - TGT
+    DX = np.zeros_like(X); DWr, DBr = DW.copy(), DB.copy()
+    o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DWr), P(DBr), N, E0, E1, train)
+    for rep_ in range(2):                                                        # twice: the counters must re-arm
+        dX, dW_, dOUT, dTGT, dOUT2, dM, dXM = dev.up(X), dev.up(W), dev.up(OUT), dev.up(TGT), dev.zeros((N, E0)), dev.up(M), dev.zeros((N, E1))
+        dDW, dDB = dev.up(DW), dev.up(DB)
+        t4k.call("t4k_loss_linear_bwd", p(dX), p(dW_), p(dOUT), p(dTGT), p(dOUT2), p(dX), p(dM) if mask else None, p(dXM) if mask else None,
+                 p(dDW) if train else None, p(dDB) if train else None, N, E0, E1, train, None)
+        assert np.array_equal(dev.down(dOUT), G) and np.array_equal(dev.down(dOUT2), G)
+        small = E0 <= 64 and E1 <= 512
+        if small: assert np.array_equal(dev.down(dX), DX)
+        else:     assert rel(dev.down(dX), DX) < RTOL
+        if mask: assert rel(dev.down(dXM), DX * M) < (1e-6 if small else RTOL)
+        if train: assert rel(dev.down(dDW), DWr) < RTOL and rel(dev.down(dDB), DBr) < RTOL
+
+
 # ----------------------------------------------------------------------------- error behaviour (reference: print-and-continue, never abort)
 def test_error_paths_return_status_and_reference_messages(t4k, dev):
     """Unsupported geometry / bad arguments come back as negative status codes with the reference's own message text
