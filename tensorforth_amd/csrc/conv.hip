@@ -61,7 +61,7 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
                                                const float *__restrict__ F, const float *__restrict__ B,
                                                int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout,
                                                int C0 /* filter inner dim */, int pairs_per_chunk, int bx, int by, int ksplit = 1,
-                                               const PoolEpi *pe = nullptr) {
+                                               const PoolEpi *pe = nullptr, float *__restrict__ XC = nullptr) {
     __shared__ float Bl[LDS_FILTER_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const long npix = (long)N * Hy * Wy;
@@ -81,6 +81,10 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
         } else split3(pix, Wy, Hy, jy, iy, n);
     }
     const float *nX = X + (long)n * Hx * Wx * Cin;
+    if (POOL && XC && pok && by == 0 && kh == 0 && h == 0) {     // layer 0 keeps a COPY of the batch (forward.cu:39); same-size conv: shared pixel grid
+        const long o = (((long)n * Hy + iy) * Wy + jy) * Cin;
+        for (int ci = 0; ci < Cin; ci++) XC[o + ci] = X[o + ci];
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -251,8 +255,8 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
 // forward convolution with the element-wise run behind it (t4k_conv2d_block_fwd)
 template <int K, int S, int P>
 __global__ void __launch_bounds__(256) k_conv_gemm_pool(const float *__restrict__ X, float *__restrict__ Y, const float *__restrict__ F, const float *__restrict__ B,
-                                                        int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0, int pairs_per_chunk, int ksplit, PoolEpi pe) {
-    conv_gemm_body<K, S, P, false, true>(X, Y, nullptr, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, pairs_per_chunk, blockIdx.x, blockIdx.y, ksplit, &pe);
+                                                        int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0, int pairs_per_chunk, int ksplit, PoolEpi pe, float *__restrict__ XC) {
+    conv_gemm_body<K, S, P, false, true>(X, Y, nullptr, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, pairs_per_chunk, blockIdx.x, blockIdx.y, ksplit, &pe, XC);
 }
 
 template <int K, int S, int P, bool BWD>
@@ -747,17 +751,18 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
                          int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!blk) return fail(T4K_ERR_ARG, "t4k_conv2d_block_fwd: null block");
-    int fG, fNG;
     const bool fusable = blk->pool_layer && blk->KS == 2 && (H0 % 2) == 0 && (W0 % 2) == 0 && S == 1 && (K == 3 || K == 5) &&
                          blk->pool_out && (!blk->pre_layer || (blk->pre_mask && blk->pre_out)) && (!blk->post_layer || (blk->post_mask && blk->post_out)) &&
-                         !(conv_few_on() && conv_few_ok(K, C1, C0, &fG, &fNG)) && !(conv_big_on() && conv_big_ok(C1, C0)) &&
+                         !(conv_big_on() && conv_big_ok(C1, C0)) &&
                          conv_supported(K, S, P) && I && O && F && B && conv_block_on();
     if (!fusable) {
         int rc = t4k_conv2d_fwd2(I, ICOPY, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, s); if (rc) return rc;
         return t4k_poolblock_fwd(O, blk, N, H0, W0, H0 / blk->KS, W0 / blk->KS, C0, s);
     }
     hipStream_t hs = t4k::S(s);
-    if (ICOPY) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, hs));
+    // layer-0 copy: written by the conv launch itself when input and output share the pixel grid and the channels are few
+    float *xc = (ICOPY && H1 == H0 && W1 == W0 && C1 <= 4) ? ICOPY : nullptr;
+    if (ICOPY && !xc) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, hs));
     PoolEpi pe;
     pe.P = blk->pre_out; pe.Q = blk->pool_out; pe.R = blk->post_out; pe.R2 = blk->copy_out; pe.Fpre = blk->pre_mask; pe.Fpost = blk->post_mask;
     pe.pre = blk->pre_layer; pe.pool = blk->pool_layer; pe.post = blk->post_layer; pe.a_pre = blk->pre_alpha; pe.a_post = blk->post_alpha;
@@ -767,8 +772,8 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
     const int ksplit = conv_gemm_ksplit(npix, C0, C1, K);
     const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);
     const dim3 g((unsigned)((npix + (128 / ksplit) - 1) / (128 / ksplit)), (unsigned)((C0 + 31) / 32));
-    if (K == 3) hipLaunchKernelGGL((k_conv_gemm_pool<3, 1, 1>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe);
-    else        hipLaunchKernelGGL((k_conv_gemm_pool<5, 1, 2>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe);
+    if (K == 3) hipLaunchKernelGGL((k_conv_gemm_pool<3, 1, 1>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe, xc);
+    else        hipLaunchKernelGGL((k_conv_gemm_pool<5, 1, 2>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe, xc);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }

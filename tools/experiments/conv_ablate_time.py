@@ -32,3 +32,9 @@ t2 = timeit(lambda: k.call("t4k_conv2d_fwd", p(r1), p(c2), p(f2), p(b2), N, 14, 
 dx1 = z(N, 14, 14, 10); df2 = torch.zeros_like(f2); db2 = torch.zeros_like(b2)
 t3 = timeit(lambda: k.call("t4k_conv2d_bwd", p(r1), p(c2), p(dx1), p(f2), p(df2), p(db2), N, 14, 14, 10, 14, 14, 20, 3, 1, 1, 1, None))
 print("%-10s conv2 block fwd %6.2f us   plain fwd %6.2f us   bwd(dF+dX+fold) %6.2f us" % (os.path.basename(os.environ.get("T4K_LIB", "product")), t, t2, t3), flush=True)
+# conv1 block (image-input layer 1 -> 10 channels, 2x2 maxpool + relu behind it, layer-0 copy)
+x0 = z(N, 28, 28, 1); xc = z(N, 28, 28, 1); f1 = z(1, 3, 3, 10) - 0.5; b1 = z(10); c1 = z(N, 28, 28, 10)
+p1 = z(N, 14, 14, 10); q1 = z(N, 14, 14, 10); m1 = z(N, 14, 14, 10)
+blk1 = PoolBlock(); blk1.KS = 2; blk1.pool_layer = 14; blk1.pool_out = p(p1); blk1.post_layer = 4; blk1.post_mask = p(m1); blk1.post_out = p(q1)
+t4 = timeit(lambda: k.call("t4k_conv2d_block_fwd", p(x0), p(xc), p(c1), p(f1), p(b1), ctypes.byref(blk1), N, 28, 28, 1, 28, 28, 10, 3, 1, 1, None))
+print("conv1 block fwd (copy + conv + pool + relu) %6.2f us  [T4K_CONV_FEW=%s]" % (t4, os.environ.get("T4K_CONV_FEW", "1")), flush=True)
