@@ -52,8 +52,11 @@ struct GemmP {
 
 // FULL: every tile is interior (M%BM == N%BN == K-slice%BK == 0, VEC): no predicates, no branches in
 // the K loop, so the compiler can sink the next stage's loads and address math under the MFMAs.
+// gate (dual launches, see k_gemm_dual): mode 1 = this GEMM READS a buffer the other one overwrites: signal once the K loop
+// has consumed every load; mode 2 = this GEMM is the writer: hold the epilogue stores until gate_n readers have signalled.
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool SKEW, bool FULL>
-__global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
+__device__ __forceinline__ void gemm_mfma_body(const GemmP &p, const int bx, const int by, const int bz,
+                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0) {
     constexpr int MT = BM / 64, NT = BN / 64;      // 32x32 fragments per wave (wave grid is 2x2)
     constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;   // 16-byte loads per thread per stage
     constexpr int NC = BK / 8;                     // 8-deep k chunks per stage
@@ -64,13 +67,13 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1, h = lane >> 5, l31 = lane & 31;
-    const int c = blockIdx.z, C = p.C;
+    const int c = bz, C = p.C;
     const int M = p.M, N = p.N, K = p.K;
 
     // ---- XCD-aware, L2-friendly tile order ----
     const int T = p.tiles_m * p.tiles_n;
-    if ((int)blockIdx.x >= T) {                    // rider workgroups: cs_out[e] += sum_r cs_X[r, e] (k_dlinear_db nmath.cu:274-280)
-        const int ex = tid & 63, ry = tid >> 6, e = ((int)blockIdx.x - T) * 64 + ex;
+    if (bx >= T) {                                 // rider workgroups: cs_out[e] += sum_r cs_X[r, e] (k_dlinear_db nmath.cu:274-280)
+        const int ex = tid & 63, ry = tid >> 6, e = (bx - T) * 64 + ex;
         float a = 0.f;
         if (e < p.cs_E) {
 #pragma unroll 8
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
     }
     int L;
     {
-        const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
+        const int b = bx, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
         L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i;
     }
     constexpr int GROUP_M = 4;
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
     const int tm = first_m + (L % per_group) % gsz, tn = (L % per_group) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int kbeg = blockIdx.y * p.kchunk;
+    const int kbeg = by * p.kchunk;
     const int kend = min(K, kbeg + p.kchunk);
     const int nst  = (kend - kbeg + BK - 1) / BK;
 
@@ -236,6 +239,18 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
                     acc[mt][nt][j % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j], bv[nt][j], acc[mt][nt][j % NACC], 0, 0, 0);
     };
 
+    // beta != 0 (dW += ...): the old output values are fetched up front instead of as dependent loads after the K loop
+    constexpr bool PRE = (MT * NT == 1);
+    float oprev[16];
+    if (PRE && p.beta != 0.f && p.nsplit == 1) {
+        const int gn = n0 + wn * (BN / 2) + l31;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int gm = m0 + wm * (BM / 2) + (r & 3) + 8 * (r >> 2) + 4 * h;
+            oprev[r] = (gm < M && gn < N) ? p.O[((long)gm * N + gn) * C + c] : 0.f;
+        }
+    }
+
     if (nst > 0) { load_tiles(0); store_tiles(0); }
     __syncthreads();
 
@@ -314,6 +329,13 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const float alpha = p.alpha, beta = p.beta;
+    if (gate_mode == 1) {                                   // every load of the shared buffer has been consumed
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (gate_mode == 2) {
+        if (tid == 0) while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_n) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -326,17 +348,39 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
                     float v = acc[mt][nt][0][r];
                     if (NACC == 2) v += acc[mt][nt][NACC - 1][r];
                     if (p.nsplit > 1) {
-                        p.part[((long)blockIdx.y * M + gm) * N + gn] = v;
+                        p.part[((long)by * M + gm) * N + gn] = v;
                     } else {
                         const long z = ((long)gm * N + gn) * C + c;
                         float o = v * alpha;
-                        if (beta != 0.f) o += p.O[z] * beta;
+                        if (beta != 0.f) o += (PRE ? oprev[r] : p.O[z]) * beta;
                         if (p.bias) o += p.bias[gn];
                         p.O[z] = o;
                     }
                 }
             }
         }
+    if (gate_mode == 2) {                                   // last writer re-arms the gate for the next launch
+        __syncthreads();
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(gate + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gate_m - 1) {
+                __hip_atomic_store(gate, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gate + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool SKEW, bool FULL>
+__global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
+    gemm_mfma_body<BM, BN, BK, AKC, BKC, VEC, SKEW, FULL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// Two independent 64x64-tiled GEMMs in ONE launch (a linear layer's dW += dY^T X and dX = dY W): workgroups [0, nb1) run the
+// first, the rest the second.  When the second overwrites an operand of the first (dX lands in X's buffer, backprop.cu:240)
+// its stores wait on an arrival counter; every workgroup is resident (grid <= CU count), so the wait cannot deadlock.
+template <bool A1, bool B1, bool A2, bool B2>
+__global__ void __launch_bounds__(256) k_gemm_dual(GemmP p1, GemmP p2, int nb1, int t1, int t2, int *gate) {
+    if ((int)blockIdx.x < nb1) gemm_mfma_body<64, 64, 64, A1, B1, true, true, false>(p1, blockIdx.x, 0, 0, gate, 1);
+    else                       gemm_mfma_body<64, 64, 64, A2, B2, true, true, false>(p2, (int)blockIdx.x - nb1, 0, 0, gate, 2, t1, t2);
 }
 
 
@@ -785,6 +829,37 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
 }
 
 struct ColSum { const float *X; float *out; int rows, E; bool done; };
+bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0; }
+// dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
+// shapes belong to the other kernels (interior tiles -> LDS-DMA kernels, deep K -> split-K, large -> 128x128 tiles)
+bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, hipStream_t hs) {
+    State &g = st();
+    if (!dual_on() || !g.d_sync || (E0 & 3) || (E1 & 3) || !aligned16(DY) || !aligned16(X) || !aligned16(W) || N < 1) return false;
+    const int cu = g.cu_count;
+    auto tiles = [](int m, int n) { return (long)((m + 63) / 64) * ((n + 63) / 64); };
+    auto big = [&](int m, int n) { return (long)((m + 127) / 128) * ((n + 127) / 128) >= (long)cu * 3 / 4; };
+    auto splits = [&](int m, int n, int k) { return tiles(m, n) * 2 <= cu && k >= 256; };
+    auto full = [](int m, int n, int k) { return m % 64 == 0 && n % 64 == 0 && k % 64 == 0; };
+    if (big(E0, E1) || big(N, E1) || splits(E0, E1, N) || splits(N, E1, E0)) return false;
+    if ((gemm_variant() & 4) && (full(E0, E1, N) || full(N, E1, E0))) return false;
+    const long t1 = tiles(E0, E1), t2 = tiles(N, E1), riders = (E0 + 63) / 64;
+    if (t1 + riders + t2 > cu || N > 4096) return false;
+    GemmP p1, p2;
+    auto fill = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
+        p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
+        p.tiles_m = (M + 63) / 64; p.tiles_n = (Nn + 63) / 64; p.kchunk = ((K + 63) / 64) * 64; p.nsplit = 1;
+        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+    };
+    fill(p1, DY, X, DW, E0, E1, N, 1.0f);                    // A = dY^T ([K][M]), B = X ([K][N])
+    p1.cs_X = DY; p1.cs_out = DB; p1.cs_rows = N; p1.cs_E = E0;
+    fill(p2, DY, W, DX, N, E1, E0, 0.0f);                    // A = dY ([M][K]), B = W ([K][N])
+    constexpr size_t lds_bytes = (size_t)2 * (64 + 64) * 64 * sizeof(float);
+    auto kern = k_gemm_dual<false, false, true, false>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(t1 + riders + t2)), dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, g.d_sync + 4096);
+    return true;
+}
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,
                 int tA, int tB, int M, int N, int K, int C, t4k_stream_t s, const ActEpi *epi = nullptr, bool *epi_done = nullptr,
                 ColSum *cs = nullptr) {
@@ -810,7 +885,8 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     int nsplit = 1, kchunk = ((K + KG - 1) / KG) * KG; if (kchunk == 0) kchunk = KG;
     if (!big && C == 1 && tiles * 2 <= st().cu_count && K >= 4 * KG) {
         int want = (int)((st().cu_count + tiles - 1) / tiles);
-        int maxs = K / (2 * KG); if (want > maxs) want = maxs; if (want > 64) want = 64;
+        static int sdiv = -1; if (sdiv < 0) { const char *e = getenv("T4K_GEMM_SPLIT_DIV"); sdiv = e ? atoi(e) : 1; if (sdiv < 1) sdiv = 1; }
+        int maxs = K / (sdiv * KG); if (want > maxs) want = maxs; if (want > 64) want = 64;
         if (want > 1) {
             kchunk = (((K + want - 1) / want) + KG - 1) / KG * KG;
             nsplit = (K + kchunk - 1) / kchunk;
@@ -950,6 +1026,7 @@ int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, 
     if ((DW == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_linear_bwd: DW and DB go together");
     if (N > 0 && linear_small_ok(E0, E1) && linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, S(s), MASK, DXM)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (DXM) { int rc = t4k_linear_bwd2(X, W, DY, DX, nullptr, nullptr, DW, DB, N, E0, E1, train, s); if (rc) return rc; return t4k_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1, s); }
+    if (train && DW && DX && N > 0 && linear_bwd_dual(X, W, DY, DX, DW, DB, N, E0, E1, S(s))) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (train && DW) {                                  // DW == NULL: dX only (the caller forks dW|dB to another stream)
         ColSum cs = { DY, DB, N, E0, false };           // dB += sum_n dY rides in the dW launch when the generic kernel runs it
         int rc = gemm_launch(DY, X, DW, nullptr, 1.0f, 1.0f, 1, 0, E0, E1, N, 1, s, nullptr, nullptr, &cs);   // dW += dY^T @ X
