@@ -857,7 +857,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     auto kern = k_gemm_dual<false, false, true, false>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(t1 + riders + t2)), dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, g.d_sync + 4096);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(t1 + riders + t2)), dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate_for(hs, 1));
     return true;
 }
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,

@@ -222,7 +222,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, g.d_sync + 4090, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2);
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate_for(hs, 0), alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2);
     return true;
 }
 

@@ -54,7 +54,7 @@ int t4k_init(int device) {
         T4K_HIP(hipMalloc(&g.ws, g.ws_bytes));
         T4K_HIP(hipMemsetAsync(g.ws, 0, g.ws_bytes, g.stream));
     }
-    if (!g.d_sync) { T4K_HIP(hipMalloc((void **)&g.d_sync, 8192 * sizeof(int))); T4K_HIP(hipMemset(g.d_sync, 0, 8192 * sizeof(int))); }
+    if (!g.d_sync) { T4K_HIP(hipMalloc((void **)&g.d_sync, 32768 * sizeof(int))); T4K_HIP(hipMemset(g.d_sync, 0, 32768 * sizeof(int))); }
     g.device = device;
     g.ready  = true;
     return T4K_OK;

@@ -30,7 +30,7 @@ struct State {
     bool        capturing = false;
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
-    int        *d_sync  = nullptr;     // 8192 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags + linear_small, [4096,8192) skinny split-K tickets
+    int        *d_sync  = nullptr;     // 32768 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags, [8192,32768) per-stream arrival gates (gate_for / flags_for)
     int         cu_count = 256;
     char        err[256] = {0};
 };
@@ -43,6 +43,16 @@ int  fail(int code, const char *fmt, ...);
 int  hip_fail(hipError_t e, const char *what);
 inline hipStream_t S(t4k_stream_t s) { return s ? (hipStream_t)s : st().stream; }
 // workspace of the stream a kernel is launched on: work forked to a side stream must not share partial slabs
+// arrival gates of the one-launch producer/consumer kernels (self re-arming ints, zero between launches): one block of 64
+// ints per stream (kernels on different streams may overlap), `slot` picks 4 ints inside it
+inline int *gate_for(const void *s, int slot) {
+    State &g = st();
+    int li = 0;
+    if (s) for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) { li = i + 1; break; }
+    return g.d_sync + 8192 + li * 2048 + slot * 4;
+}
+// 16 broadcast flags of the same stream, one per 64-byte line (hundreds of waiting workgroups poll these instead of the counter)
+inline int *flags_for(const void *s) { return gate_for(s, 0) + 1024; }
 inline float *ws_for(const void *s) {            // accepts a t4k_stream_t or an already resolved hipStream_t
     State &g = st();
     if (s) for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) return (float *)g.lane[i].ws;

@@ -261,7 +261,7 @@ def test_activations_softmax_bias(t4k, dev, oracle):
     assert np.array_equal(dev.down(dY), Y)
 
 
-@pytest.mark.parametrize("N,E0,E1", [(128, 100, 1960), (128, 10, 100), (3, 2, 2), (256, 512, 784)])
+@pytest.mark.parametrize("N,E0,E1", [(128, 100, 1960), (128, 10, 100), (3, 2, 2), (256, 512, 784), (128, 100, 980), (200, 72, 516), (31, 68, 12)])
 def test_linear_fwd_bwd(t4k, dev, oracle, N, E0, E1):
     o = oracle.lib(); P = oracle.P
     rng = np.random.default_rng(N + E0)
@@ -278,6 +278,11 @@ def test_linear_fwd_bwd(t4k, dev, oracle, N, E0, E1):
     o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)
     t4k.call("t4k_linear_bwd", p(dX), p(dW), p(dG), p(dX), p(dDW), p(dDB), N, E0, E1, 1, None)   # dX in place (as the host does)
     assert rel(dev.down(dX), DX) < RTOL and rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL
+    # again on fresh buffers (the one-launch dW|dX path re-arms its arrival gate), accumulating into the same dW / dB
+    o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)
+    dX2 = dev.up(X)
+    t4k.call("t4k_linear_bwd", p(dX2), p(dW), p(dG), p(dX2), p(dDW), p(dDB), N, E0, E1, 1, None)
+    assert rel(dev.down(dX2), DX) < RTOL and rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL
     DBo = DB.copy(); o.t4o_dlinear_db(P(G), P(DBo), N, E0)
     t4k.call("t4k_dlinear_db", p(dG), p(dDB), N, E0, None)
     assert rel(dev.down(dDB), DBo) < RTOL
