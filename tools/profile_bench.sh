@@ -1,0 +1,23 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ on a GPU box:  gpurun -- 'bash tools/profile_bench.sh r1e'
+# (four separate runs of bench.py: plain, kernel trace, and three --pmc passes; counters never together with sys/hip/hsa traces)
+set -u
+TAG=${1:-r1x}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+python "$R/bench.py" > "$O/bench.json" 2> "$O/bench.err"
+B="python $R/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d "$O/kt" -o bench -- $B > "$O/kt.log" 2>&1
+rocprofv3 --kernel-trace -f csv -d "$O/pmc_mfma" -o bench --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -- $B > "$O/pmc_mfma.log" 2>&1
+rocprofv3 --kernel-trace -f csv -d "$O/pmc_hbm" -o bench --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -- $B > "$O/pmc_hbm.log" 2>&1
+rocprofv3 --kernel-trace -f csv -d "$O/pmc_lds" -o bench --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -- $B > "$O/pmc_lds.log" 2>&1
+DB=$(find "$O/kt" -name '*.db' | head -1)
+python "$R/tools/rocpd_summary.py" "$DB" > "$O/kernel_trace.txt"
+for p in mfma hbm lds; do
+  C=$(find "$O/pmc_$p" -name '*counter_collection.csv' | head -1)
+  python "$R/tools/pmc_summary.py" "$C" > "$O/pmc_$p.txt"
+done
+tail -1 "$O/bench.json"
+head -25 "$O/kernel_trace.txt"
