@@ -802,7 +802,10 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
             nbig = launch_conv_big_df(K, S, P, hs, I, DO, ws_for(s), st().ws_bytes / 8, N, H1, W1, C1, H0, W0, C0);
             if (nbig > 0) {
                 const int ntot = ntaps * C0;                      // no bias row in these slabs: dB is a plain column sum of dO
-                hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, ws_for(s), DF, DB, nbig, ntot, ntot);
+                // few slices x many outputs: one thread per output walks the slices (coalesced); the wave-per-output fold is
+                // for the opposite shape (hundreds of slices, few outputs) and would run 8 of 64 lanes here
+                if (nbig <= 32) hipLaunchKernelGGL(k_fold_add, dim3((ntot + BLK - 1) / BLK), dim3(BLK), 0, hs, ws_for(s), DF, ntot, nbig);
+                else hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, ws_for(s), DF, DB, nbig, ntot, ntot);
                 int rc = colsum_add(DO, DB, (long)N * H0 * W0, C0, hs); if (rc) return rc;
             }
         }

@@ -299,9 +299,15 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
     const long npix = (long)N * H0 * W0;
     const int ci_tiles = (C1 + 63) / 64, co_tiles = (C0 + 63) / 64, KK = K * K;
     const int tiles = KK * ci_tiles * co_tiles;
-    long nslice = (2L * st().cu_count + tiles - 1) / tiles; if (nslice < 1) nslice = 1;      // ~2 workgroups per CU in total
+    static int wpc = -1; if (wpc < 0) { const char *e = getenv("T4K_DF_WGS_PER_CU"); wpc = e ? atoi(e) : 3; if (wpc < 1) wpc = 1; }
+    long nslice = ((long)wpc * st().cu_count + tiles - 1) / tiles; if (nslice < 1) nslice = 1;      // workgroups per CU in total
     long pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; if (pps < 8 * BK) pps = 8 * BK;
     nslice = (npix + pps - 1) / pps;
+    // Workgroups go to XCD (linear block id % 8) and the grid is slice-major: with a slice count that is a multiple of 8 every
+    // tap / channel tile of one pixel slice lands on the SAME XCD, so the K*K-fold re-read of I and dO is served by that XCD's
+    // L2 instead of crossing the fabric once per tap (a trailing slice may be empty: it writes a zero slab)
+    static int x8 = -1; if (x8 < 0) { const char *e = getenv("T4K_DF_XCD"); x8 = e ? atoi(e) : 1; }
+    if (x8 && nslice >= 8) { nslice = (nslice + 7) / 8 * 8; pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; }
     if ((size_t)nslice * C1 * KK * C0 > part_floats) return 0;
     CdP p = { I, DO, part, N, H1, W1, C1, H0, W0, C0, (int)pps, ci_tiles };
     const dim3 g((unsigned)nslice, (unsigned)(KK * ci_tiles), (unsigned)co_tiles), b(256);

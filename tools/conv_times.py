@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tensorforth_amd import lib as t4lib
-k = t4lib.load(); k.init(0)
+k = t4lib.load(os.environ.get("T4K_LIB")); k.init(0)
 p = lambda t: t.data_ptr()
 
 
