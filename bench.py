@@ -102,7 +102,7 @@ def main():
     slab = vm.grad_slab() if (dp and not native) else None
     vstream = vm.stream() if (dp and not native) else None
     reducer = None
-    if slab is not None and os.environ.get("T4_DP_OVERLAP", "0") == "1":   # torch path only: reduce the slab's tail under conv backprop
+    if slab is not None and os.environ.get("T4_DP_TORCH_OVERLAP", "0") == "1":   # torch path only: reduce the slab's tail under conv backprop
         from tensorforth_amd.dp import OverlappedSlabReducer
         reducer = OverlappedSlabReducer(slab, vstream)
         vm.set_grad_hook(reducer.on_layer)

@@ -136,6 +136,8 @@ void Model::finalize() {                                // gradient slab: SURVEY
         }
         if (gslab) Store::get().free(*gslab);
         gslab = slab;
+        if (dp_busy_) { t4k_sync(comm_s_); dp_busy_ = false; }
+        dp_done_lo_ = dp_pend_lo_ = -1; dp_mixed_ = false;     // offsets of the old slab are meaningless now
     }
     if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }                  // parameter table holds the old pointers
     if (use_side && !side_) chk(t4k_stream_create(&side_), "side stream");
@@ -406,7 +408,56 @@ Model &Model::backprop(Tensor &tgt) {
     NLOG("\n} Model::backprop\n");
     return *this;
 }
+// ---- data parallel overlap.  The slab fills tail-first (last layer's dW|dB first, tests/test_gpu_embed.py pins the order).
+// Ranges complete on the main stream are queued; once a bucket is full it is all-reduced on the communication stream behind
+// an event, concurrently with the backward of the earlier layers.  RCCL serialises the collectives of one communicator in
+// issue order whatever stream they are on, and every rank issues the same sequence (same model, same bucket size).
+int  Model::dp_overlap = getenv("T4_DP_OVERLAP") ? atoi(getenv("T4_DP_OVERLAP")) : 1;       // 0 off, 1 on for world > 1, 2 also for a one-rank communicator (tests)
+long Model::dp_bucket  = getenv("T4_DP_BUCKET") ? atol(getenv("T4_DP_BUCKET")) : 16384;          // floats per early all-reduce (64 KiB)
+void Model::grads_ready(int i, Tensor &in) {
+    if (!(train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns)) return;
+    const long off = (long)(in.grad[2]->data - gslab->data);
+    const long end = (long)(in.grad[3]->data - gslab->data) + (long)((in.grad[3]->numel + 63) & ~(uint64_t)63);
+    if (grad_hook) grad_hook(i, off, end - off, grad_hook_user);
+    if (!dp_overlap || dp_mixed_ || dp_pend_lo_ < 0 || t4k_comm_world() < (dp_overlap >= 2 ? 1 : 2) || concurrent() || use_graphs || capturing_) return;
+    if (end != dp_pend_lo_ || off < 0 || off >= end) { dp_mixed_ = true; return; }   // not the next range down: leave the rest to `gradient`
+    dp_pend_lo_ = off;
+    if (dp_done_lo_ - dp_pend_lo_ >= dp_bucket) dp_flush();
+}
+void Model::dp_flush() {
+    if (dp_done_lo_ <= dp_pend_lo_) return;
+    if (!comm_s_) { chk(t4k_stream_create(&comm_s_), "comm stream"); t4k_event_create(&dp_ev_[0]); t4k_event_create(&dp_ev_[1]); }
+    t4k_event_record(dp_ev_[0], stream()); t4k_stream_wait_event(comm_s_, dp_ev_[0]);            // the range is complete on the main stream
+    chk(t4k_allreduce_sum(gslab->data + dp_pend_lo_, dp_done_lo_ - dp_pend_lo_, comm_s_), "allreduce (overlapped)");
+    static const bool tr = getenv("T4_DP_TRACE") != nullptr;
+    if (tr) fprintf(stderr, "dp: early all-reduce of slab [%ld, %ld)\n", dp_pend_lo_, dp_done_lo_);
+    dp_done_lo_ = dp_pend_lo_; dp_busy_ = true;
+}
+void Model::dp_begin_backward() {
+    if (!gslab) return;
+    const long numel = (long)gslab->numel;
+    if (dp_done_lo_ >= 0 && dp_done_lo_ < numel) {
+        // a second backprop before the optimizer (gradient accumulation) finds ranges that already hold the SUM over ranks:
+        // turn them back into a local share (x 1/world, exact for power-of-two worlds) so the final all-reduce of the whole
+        // slab gives SUM(first) + SUM(second); no more early reductions in this accumulation window
+        if (dp_busy_) { t4k_event_record(dp_ev_[1], comm_s_); t4k_stream_wait_event(stream(), dp_ev_[1]); dp_busy_ = false; }
+        chk(t4k_math(T4K_SCALE, gslab->data + dp_done_lo_, 1.0f / (float)t4k_comm_world(), numel - dp_done_lo_, stream()), "dp rescale");
+        dp_mixed_ = true;
+    }
+    dp_done_lo_ = dp_pend_lo_ = numel;
+}
+void Model::dp_finish() {                                // before the update: reduce what is left, join the communication stream
+    if (!gslab || t4k_comm_world() <= 0) return;
+    const long numel = (long)gslab->numel;
+    const long rest = (dp_done_lo_ >= 0 && dp_done_lo_ <= numel) ? dp_done_lo_ : numel;
+    if (rest > 0) chk(t4k_allreduce_sum(gslab->data, rest, stream()), "allreduce");
+    static const bool tr = getenv("T4_DP_TRACE") != nullptr;
+    if (tr) fprintf(stderr, "dp: final all-reduce of slab [0, %ld) of %ld\n", rest, numel);
+    if (dp_busy_) { t4k_event_record(dp_ev_[1], comm_s_); t4k_stream_wait_event(stream(), dp_ev_[1]); dp_busy_ = false; }
+    dp_done_lo_ = dp_pend_lo_ = -1; dp_mixed_ = false;
+}
 void Model::run_backward(Tensor &tgt) {
+    dp_begin_backward();
     Tensor &out = at(-1);
     t4k_stream_t s = stream();
     const bool fused = use_fusion && !(trace && *trace) && !concurrent();
@@ -443,19 +494,11 @@ void Model::run_backward(Tensor &tgt) {
         dy = bstep(i, in, o, dy, j == 0);
         if (skip_next_) {                               // bstep also ran the backward of op i-1 (a lone mask-multiply layer)
             skip_next_ = false;
-            if (grad_hook && train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns) {
-                const long off = (long)(in.grad[2]->data - gslab->data);
-                const long end = (long)(in.grad[3]->data - gslab->data) + (long)((in.grad[3]->numel + 63) & ~(uint64_t)63);
-                grad_hook(i, off, end - off, grad_hook_user);
-            }
+            grads_ready(i, in);
             dy = at(i - 1).data; i--; j++;
             continue;
         }
-        if (grad_hook && train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns) {
-            const long off = (long)(in.grad[2]->data - gslab->data);
-            const long end = (long)(in.grad[3]->data - gslab->data) + (long)((in.grad[3]->numel + 63) & ~(uint64_t)63);
-            grad_hook(i, off, end - off, grad_hook_user);
-        }
+        grads_ready(i, in);
         if (trace && *trace && in.has_nan()) { printf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
     }
     join();
@@ -574,7 +617,7 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     const float p[4] = { lr, b1, b2, wd };
     // data parallel: every rank holds a shard of the batch; SUM the gradient slab (raw batch sums, quirk a-19) in-order
     // on the VM stream right before the update, so N ranks x batch B reproduce one rank x batch N*B
-    if (gslab && t4k_comm_world() > 0) chk(t4k_allreduce_sum(gslab->data, (long)gslab->numel, stream()), "allreduce");
+    dp_finish();
     if (!replay(g_opt_, tab_dev, (int)op, p)) {
         const bool cap = capturing_;
         chk(t4k_opt_multi(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_max, lr, b1, b2, wd, stream()), nm);
@@ -642,6 +685,7 @@ void Model::free_all() {
     if (current == this) current = nullptr;
     t4k_sync(stream());
     if (side_) { t4k_stream_destroy(side_); side_ = nullptr; }
+    if (comm_s_) { t4k_stream_destroy(comm_s_); comm_s_ = nullptr; for (auto &e : dp_ev_) if (e) { t4k_event_destroy(e); e = nullptr; } }
     for (auto e : ev_) if (e) t4k_event_destroy(e);
     ev_.clear();
     for (Tensor *t : gx_) if (t) Store::get().free(*t);

@@ -260,6 +260,16 @@ private:
     bool replay(GraphSlot &slot, const void *key, int flags, const float *p);
     void end_capture(GraphSlot &slot, bool capturing);
     bool capturing_ = false;
+    // ---- data parallel (library-owned communicator): slab ranges that are complete are SUM all-reduced on a communication
+    // stream while the earlier layers' backward still runs; `gradient` reduces the rest and joins before the update
+    static int dp_overlap; static long dp_bucket;
+    t4k_stream_t comm_s_ = nullptr; t4k_event_t dp_ev_[2] = { nullptr, nullptr };
+    long dp_done_lo_ = -1, dp_pend_lo_ = -1;   // [dp_done_lo_, numel) submitted; [dp_pend_lo_, dp_done_lo_) complete, not yet submitted
+    bool dp_busy_ = false, dp_mixed_ = false;
+    void grads_ready(int i, Tensor &in);
+    void dp_flush();
+    void dp_begin_backward();
+    void dp_finish();
     Tensor *prep_tgt_ = nullptr;               // `out -= target` pending: the last linear layer's backward launch performs it
     bool skip_next_ = false;                   // set by bstep when it also ran the backward of the op in front
 };

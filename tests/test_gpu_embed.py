@@ -83,3 +83,51 @@ def test_library_owned_communicator_world_size_one(vm, t4k):
     finally:
         lib.t4k_comm_destroy()
     assert lib.t4k_comm_world() == 0
+
+
+_DP_SCRIPT = r'''
+import ctypes, os, sys
+sys.path.insert(0, os.environ["T4_ROOT"])
+from tensorforth_amd.vm import VM
+from tensorforth_amd import lib as t4lib
+SRC = """0 trace
+16 12 12 1 nn.model 0.5 6 conv2d 2 maxpool relu 0.5 8 conv2d relu flatten 300 linear relu 10 linear softmax constant net
+16 12 12 1 tensor rand constant img
+: hot ( T -- T ) 16 0 do 1 i 10 * i 3 * 10 mod + t! loop ;
+160 vector zeros hot 16 1 10 1 reshape4 constant lbl
+: step ( N -- N ) img forward lbl backprop 0.05 0.0 nn.sgd ;
+: acc2 ( N -- N ) img forward lbl backprop img forward lbl backprop 0.05 0.0 nn.sgd ;
+net
+"""
+v = VM(device=0, seed=11)
+out = v.eval(SRC)                                        # (the first eval initialises the device library)
+assert "?" not in out.replace("-> ok", ""), out
+k = t4lib.load()
+if os.environ.get("WITH_COMM") == "1":
+    raw = (ctypes.c_ubyte * 128)()
+    assert k.lib.t4k_comm_unique_id(raw) == 0 and k.lib.t4k_comm_init(raw, 0, 1) == 0, k.lib.t4k_last_error()
+v.eval("step step step acc2 step")
+print(v.eval('." W6 " 6 nn.w sum . drop ." W8 " 8 nn.w sum . drop ." W0 " 0 nn.w sum . drop ." W3 " 3 nn.w sum . drop lbl loss.ce ." CE " .'))
+'''
+
+
+def test_overlapped_slab_reduction_equals_in_order_training(tmp_path):
+    """T4_DP_OVERLAP=2 forces the early-bucket path (event -> communication stream -> RCCL -> join) with a one-rank communicator:
+    three plain steps, a two-backprop accumulation step (the 1/world rescale path) and another step must leave exactly the weights
+    and loss of the same script without a communicator."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = tmp_path / "dp.py"; f.write_text(_DP_SCRIPT)
+    outs = []
+    for comm, ov, bucket in (("0", "1", "16384"), ("1", "2", "1024"), ("1", "2", "100000000"), ("1", "0", "16384")):
+        env = dict(os.environ, T4_ROOT=root, WITH_COMM=comm, T4_DP_OVERLAP=ov, T4_DP_BUCKET=bucket, T4_DP_TRACE="1")
+        r = subprocess.run([sys.executable, str(f)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        early = r.stderr.count("dp: early all-reduce"); final = r.stderr.count("dp: final all-reduce")
+        if comm == "0": assert early == 0 and final == 0
+        elif ov == "2" and bucket == "1024": assert early >= 8 and final == 5, r.stderr      # several buckets in each of the 4 one-backprop steps
+        else: assert early == 0 and final == 5, r.stderr                                     # bucket never fills / overlap off: one in-order reduction per step
+        line = [l for l in r.stdout.splitlines() if "W6" in l][-1]
+        outs.append(line[line.index("W6"):])
+    assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0], outs
+    assert all(np.isfinite(_num(outs[0], lab)) for lab in ("W6", "W8", "W0", "W3", "CE"))
