@@ -412,7 +412,10 @@ Model &Model::backprop(Tensor &tgt) {
 // Ranges complete on the main stream are queued; once a bucket is full it is all-reduced on the communication stream behind
 // an event, concurrently with the backward of the earlier layers.  RCCL serialises the collectives of one communicator in
 // issue order whatever stream they are on, and every rank issues the same sequence (same model, same bucket size).
-int  Model::dp_overlap = getenv("T4_DP_OVERLAP") ? atoi(getenv("T4_DP_OVERLAP")) : 1;       // 0 off, 1 on for world > 1, 2 also for a one-rank communicator (tests)
+// Off by default: with a one-rank communicator the two cross-stream edges on the main stream (RCCL's own ordering of the final
+// reduction behind the early one + the join) cost +16 us per step (0.129 -> 0.145 ms), about what hiding a 400 KB all-reduce
+// can win back on 8 GPUs - to be decided with measurements on an 8-GPU box.
+int  Model::dp_overlap = getenv("T4_DP_OVERLAP") ? atoi(getenv("T4_DP_OVERLAP")) : 0;       // 0 off, 1 on for world > 1, 2 also for a one-rank communicator (tests)
 long Model::dp_bucket  = getenv("T4_DP_BUCKET") ? atol(getenv("T4_DP_BUCKET")) : 16384;          // floats per early all-reduce (64 KiB)
 void Model::grads_ready(int i, Tensor &in) {
     if (!(train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns)) return;
