@@ -222,7 +222,7 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
                         Y[a] = e;
                         if (pe->pre) {
                             float o, f;
-                            act_rt(pe->pre, e, quad ? uq[pos] : (draw ? philox_u01_at(rbase, rseed, a) : 0.f), pe->a_pre, o, f);
+                            act_rt_lean(pe->pre, e, quad ? uq[pos] : (draw ? philox_u01_at(rbase, rseed, a) : 0.f), pe->a_pre, o, f);
                             pe->Fpre[a] = f; pe->P[a] = o; e = o;
                         }
                         if (pe->pool == T4K_L_MAXPOOL)      pv = first ? e : fmaxf(e, pv);
@@ -233,7 +233,7 @@ __device__ __forceinline__ void conv_gemm_body(const float *__restrict__ X, floa
                     if (pe->pool == T4K_L_AVGPOOL) pv /= 4.0f;
                     const long z = wdx * Cout + co;
                     pe->Q[z] = pv;
-                    if (pe->post) { float o, f; act_rt(pe->post, pv, 0.f, pe->a_post, o, f); pe->Fpost[z] = f; pe->R[z] = o; pv = o; }
+                    if (pe->post) { float o, f; act_rt_lean(pe->post, pv, 0.f, pe->a_post, o, f); pe->Fpost[z] = f; pe->R[z] = o; pv = o; }
                     if (pe->R2) pe->R2[z] = pv;
                 }
                 j0 += 2;                                                          // next window of this lane: wdx + 2

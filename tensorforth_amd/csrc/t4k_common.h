@@ -153,6 +153,15 @@ __device__ __forceinline__ void act_rt(int L, float i, float u, float alpha, flo
     default:            o = i; f = 1.0f; break;
     }
 }
+// same, for heavily unrolled epilogues: the cheap mask activations stay inline, the transcendental ones (libm-sized bodies,
+// 20 inlined copies made the conv+pool kernel 46 KB of code) go through one out-of-line copy
+__device__ __noinline__ static float2 act_rt_slow(int L, float i, float alpha) { float o, f; act_rt(L, i, 0.f, alpha, o, f); return make_float2(o, f); }
+__device__ __forceinline__ void act_rt_lean(int L, float i, float u, float alpha, float &o, float &f) {
+    if (L == T4K_L_RELU)         { if (i > 0.0f) { f = 1.0f; o = i; } else { f = 0.0f; o = 0.0f; } }
+    else if (L == T4K_L_DROPOUT) { if (u > alpha) { f = 1.0f; o = i; } else { f = 0.0f; o = 0.0f; } }
+    else if (L == T4K_L_LEAKYRL) { if (i > 0.0f) { f = 1.0f; o = i; } else { f = alpha; o = alpha * i; } }
+    else { const float2 r = act_rt_slow(L, i, alpha); o = r.x; f = r.y; }
+}
 // element `a` of a tensor whose Philox slice starts at counter `base` (units of 4 elements): the same value
 // t4k_rand(uniform, bias 0, scale 1) would have stored at index a
 __device__ __forceinline__ float philox_u01_at(uint64_t base, uint64_t seed, long a) {
