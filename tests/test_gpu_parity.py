@@ -525,6 +525,66 @@ def test_poolblock_matches_unfused_oracle(t4k, dev, oracle, pre, pool, post, fla
             assert rel(dev.down(d[k_]).reshape(bufs[k_].shape), bufs[k_]) < 1e-6, "bwd " + k_
 
 
+@pytest.mark.parametrize("N,H,C1,C0,K,pre,post,flat,icopy", [
+    (128, 14, 10, 20, 3, "dropout", "relu", True, False),      # LeNet conv2 block
+    (16, 28, 1, 10, 3, None, "relu", False, True),             # LeNet conv1 block: layer-0 copy written by the conv launch
+    (5, 12, 3, 8, 5, "relu", None, False, True),               # 5x5, 3 input channels, odd batch
+    (4, 8, 6, 40, 3, "dropout", "leaky", True, False),         # two output-channel tiles (40 > 32), Cout % 4 == 0 -> quad-shared Philox
+    (3, 6, 5, 7, 3, "dropout", None, False, False),            # Cout % 4 != 0 -> per-element Philox path
+    (2, 16, 64, 64, 3, None, "relu", False, False),            # many channels: not fusable in-kernel, the entry composes the launches
+])
+def test_conv_block_forward_and_dual_store_backward(t4k, dev, oracle, N, H, C1, C0, K, pre, post, flat, icopy):
+    """t4k_conv2d_block_fwd == t4k_conv2d_fwd + the element-wise run as separate oracle layers (every tensor of the run, the
+    optional layer-0 copy, dropout masks bit-exact and the Philox stream advanced identically); t4k_conv2d_bwd2's second dX
+    copy equals dX."""
+    o = oracle.lib(); P = oracle.P
+    LAY = {"dropout": (oracle.L_DROPOUT, 0.5), "relu": (oracle.L_RELU, 0.0), "leaky": (oracle.L_LEAKYRL, 0.1)}
+    rng = np.random.default_rng(N * 7 + C0)
+    Pd = K // 2; H0 = H; Hp = H // 2
+    X = rng.standard_normal((N, H, H, C1)).astype(np.float32); F = (rng.standard_normal((C1, K, K, C0)) * 0.3).astype(np.float32)
+    B = rng.standard_normal(C0).astype(np.float32)
+    n1, n0 = N * H0 * H0 * C0, N * Hp * Hp * C0
+    seed, off = 91, 8192
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    Y = np.zeros((N, H0, H0, C0), np.float32); o.t4o_conv2d_fwd(P(X), P(Y), P(F), P(B), N, H, H, C1, H0, H0, C0, K, 1, Pd)
+    ref = {}; x = Y
+    if pre:
+        L, a = LAY[pre]; f = np.zeros(n1, np.float32); y = np.zeros_like(Y)
+        if pre == "dropout": o.t4o_rand(P(f), n1, 0, 0.0, 1.0)
+        o.t4o_activate(L, P(x), P(y), P(f), a, n1); ref["pre_mask"] = f; ref["pre_out"] = y; x = y
+    q = np.zeros((N, Hp, Hp, C0), np.float32); o.t4o_pool(oracle.L_MAXPOOL, P(x), P(q), N, H0, H0, Hp, Hp, C0, 2); ref["pool_out"] = q; x = q
+    if post:
+        L, a = LAY[post]; f = np.zeros(n0, np.float32); y = np.zeros_like(q)
+        o.t4o_activate(L, P(x), P(y), P(f), a, n0); ref["post_mask"] = f; ref["post_out"] = y; x = y
+    if flat: ref["copy_out"] = x.copy()
+    t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+    d = {k: dev.zeros(v.shape) for k, v in ref.items()}
+    dX, dF, dB, dY, dXC = dev.up(X), dev.up(F), dev.up(B), dev.zeros(Y.shape), dev.zeros(X.shape)
+    blk = PoolBlock(); blk.KS = 2; blk.pool_layer = oracle.L_MAXPOOL; blk.pool_out = p(d["pool_out"])
+    if pre: blk.pre_layer, blk.pre_alpha = LAY[pre]; blk.pre_mask = p(d["pre_mask"]); blk.pre_out = p(d["pre_out"])
+    if post: blk.post_layer, blk.post_alpha = LAY[post]; blk.post_mask = p(d["post_mask"]); blk.post_out = p(d["post_out"])
+    if flat: blk.copy_out = p(d["copy_out"])
+    t4k.call("t4k_conv2d_block_fwd", p(dX), p(dXC) if icopy else None, p(dY), p(dF), p(dB), ctypes.byref(blk), N, H, H, C1, H0, H0, C0, K, 1, Pd, None)
+    assert rel(dev.down(dY), Y) < RTOL
+    if icopy: assert np.array_equal(dev.down(dXC), X)
+    if pre == "dropout":
+        assert np.array_equal(dev.down(d["pre_mask"]).ravel(), ref["pre_mask"])
+        assert t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
+    for k_, v in ref.items():
+        if k_.endswith("mask") and k_ != "pre_mask" or (k_ == "pre_mask" and pre != "dropout"):
+            # derivative masks flip where the pre-activation sits within rounding distance of zero: compare away from it
+            continue
+        assert rel(dev.down(d[k_]).reshape(v.shape), v) < RTOL, k_
+    # backward with the second dX copy (the reference's `in = dx`)
+    G = rng.standard_normal(Y.shape).astype(np.float32)
+    DX = np.zeros_like(X); DF = np.zeros_like(F); DB = np.zeros_like(B)
+    o.t4o_conv2d_bwd(P(X), P(G), P(DX), P(F), P(DF), P(DB), N, H, H, C1, H0, H0, C0, K, 1, Pd, 1)
+    dG, dDX, dDX2, dDF, dDB = dev.up(G), dev.zeros(X.shape), dev.zeros(X.shape), dev.zeros(F.shape), dev.zeros(B.shape)
+    t4k.call("t4k_conv2d_bwd2", p(dX), p(dG), p(dDX), p(dDX2), p(dF), p(dDF), p(dDB), N, H, H, C1, H0, H0, C0, K, 1, Pd, 1, None)
+    assert rel(dev.down(dDX), DX) < RTOL and np.array_equal(dev.down(dDX2), dev.down(dDX))
+    assert rel(dev.down(dDF), DF) < RTOL and rel(dev.down(dDB), DB) < RTOL
+
+
 @pytest.mark.parametrize("N,E0,E1", [(128, 10, 100), (7, 3, 17), (256, 1, 256), (64, 40, 200), (33, 48, 130)])
 def test_small_linear_head_is_bit_identical_to_oracle(t4k, dev, oracle, N, E0, E1):
     """Classifier-head path (linear_small.hip): fmaf chains in ascending k, the oracle's order => exact equality
