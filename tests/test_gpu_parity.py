@@ -645,6 +645,57 @@ def test_loss_prep_folded_into_linear_backward(t4k, dev, oracle, N, E0, E1, mask
         if train: assert rel(dev.down(dDW), DWr) < RTOL and rel(dev.down(dDB), DBr) < RTOL
 
 
+def test_plu_and_second_destination_entries(t4k, dev, oracle):
+    """t4k_plu (packed L\\U + pivots + permutation applied to I), t4k_tt_op2 (second destination) and t4k_conv2d_fwd2 (layer-0 copy)."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(4)
+    for K in (2, 5, 33):
+        a0 = (rng.standard_normal((K, K)) + np.eye(K) * 0.5).astype(np.float32)
+        a, I = a0.copy(), np.eye(K, dtype=np.float32); piv = np.zeros(K, np.int32); st = ctypes.c_int(0)
+        o.t4o_plu(P(a), P(I), P(piv), K, ctypes.byref(st))
+        dA, dI, dpiv, dst = dev.up(a0), dev.up(np.eye(K, dtype=np.float32)), dev.zeros(K, dev.torch.int32), dev.zeros(1, dev.torch.int32)
+        t4k.call("t4k_plu", p(dA), p(dI), p(dpiv), K, p(dst), None)
+        assert rel(dev.down(dA), a) < 1e-5 and np.array_equal(dev.down(dI), I)
+        assert np.array_equal(dev.down(dpiv), piv) and dev.down(dst)[0] == st.value == 0
+    A = rng.standard_normal(1000).astype(np.float32); B = rng.standard_normal(1000).astype(np.float32)
+    dO, dO2 = dev.zeros(1000), dev.zeros(1000)
+    t4k.call("t4k_tt_op2", oracle.SUB, p(dev.up(A)), p(dev.up(B)), p(dO), p(dO2), 1000, None)
+    assert np.array_equal(dev.down(dO), A - B) and np.array_equal(dev.down(dO2), A - B)
+    for (N, H, C1, C0) in ((4, 12, 1, 10), (2, 8, 16, 8)):                       # direct image-input kernel / gather-MFMA kernel (+ copy launch)
+        X = rng.standard_normal((N, H, H, C1)).astype(np.float32); F = rng.standard_normal((C1, 3, 3, C0)).astype(np.float32)
+        Bv = rng.standard_normal(C0).astype(np.float32); Y = np.zeros((N, H, H, C0), np.float32)
+        o.t4o_conv2d_fwd(P(X), P(Y), P(F), P(Bv), N, H, H, C1, H, H, C0, 3, 1, 1)
+        dXC, dY = dev.zeros(X.shape), dev.zeros(Y.shape)
+        t4k.call("t4k_conv2d_fwd2", p(dev.up(X)), p(dXC), p(dY), p(dev.up(F)), p(dev.up(Bv)), N, H, H, C1, H, H, C0, 3, 1, 1, None)
+        assert rel(dev.down(dY), Y) < RTOL and np.array_equal(dev.down(dXC), X)
+
+
+@pytest.mark.parametrize("N,E0,E1,layer", [(128, 100, 980, "dropout"), (128, 100, 980, "relu"), (64, 16, 40, "dropout"), (32, 256, 64, "tanh"),
+                                           (256, 128, 1024, "dropout")])
+def test_linear_with_activation_epilogue(t4k, dev, oracle, N, E0, E1, layer):
+    """t4k_linear_act_fwd == linear forward + the element-wise layer behind it (mask and output), whichever kernel takes the
+    shape (small head, split-K GEMM with the activation in the fold, plain GEMM + separate launch); dropout draws the slice
+    t4k_rand would have drawn."""
+    o = oracle.lib(); P = oracle.P
+    LAY = {"dropout": (oracle.L_DROPOUT, 0.5), "relu": (oracle.L_RELU, 0.0), "tanh": (oracle.L_TANH, 0.0)}
+    L, alpha = LAY[layer]
+    rng = np.random.default_rng(E0 + E1)
+    X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(E0).astype(np.float32)
+    Y = np.zeros((N, E0), np.float32); o.t4o_linear_fwd(P(X), P(W), P(b), P(Y), N, E0, E1)
+    seed, off = 5, 1 << 20
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    f = np.zeros(N * E0, np.float32); a = np.zeros((N, E0), np.float32)
+    if layer == "dropout": o.t4o_rand(P(f), N * E0, 0, 0.0, 1.0)
+    o.t4o_activate(L, P(Y), P(a), P(f), alpha, N * E0)
+    t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+    dY, dF, dA = dev.zeros((N, E0)), dev.zeros(N * E0), dev.zeros((N, E0))
+    t4k.call("t4k_linear_act_fwd", p(dev.up(X)), p(dev.up(W)), p(dev.up(b)), p(dY), L, alpha, p(dF), p(dA), N, E0, E1, None)
+    assert rel(dev.down(dY), Y) < RTOL and rel(dev.down(dA), a) < RTOL
+    if layer == "dropout":
+        assert np.array_equal(dev.down(dF), f) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
+
+
 # ----------------------------------------------------------------------------- error behaviour (reference: print-and-continue, never abort)
 def test_error_paths_return_status_and_reference_messages(t4k, dev):
     """Unsupported geometry / bad arguments come back as negative status codes with the reference's own message text
