@@ -8,10 +8,10 @@ k = t4lib.load(os.environ.get("T4K_LIB")); k.init(0)
 p = lambda t: t.data_ptr()
 
 
-def timeit(fn, iters=30):
+def timeit(fn, iters=60):
     e0 = ctypes.c_void_p(); e1 = ctypes.c_void_p()
     k.call("t4k_event_create", ctypes.byref(e0)); k.call("t4k_event_create", ctypes.byref(e1))
-    for _ in range(3): fn()
+    for _ in range(10): fn()                    # first touches of freshly allocated 67 MB tensors are slow (3 were not enough)
     k.call("t4k_event_record", e0, None)
     for _ in range(iters): fn()
     k.call("t4k_event_record", e1, None); k.call("t4k_event_sync", e1)
@@ -19,6 +19,9 @@ def timeit(fn, iters=30):
     return ms.value / iters * 1e3
 
 
+# clocks ramp up over the first few hundred ms of sustained MFMA load: warm the part before timing anything
+_x = torch.rand(256, 32, 32, 64, device="cuda"); _f = torch.rand(64, 3, 3, 64, device="cuda"); _b = torch.rand(64, device="cuda"); _y = torch.zeros(256, 32, 32, 64, device="cuda")
+timeit(lambda: k.call("t4k_conv2d_fwd", p(_x), p(_y), p(_f), p(_b), 256, 32, 32, 64, 32, 32, 64, 3, 1, 1, None), iters=1500)
 for (N, H, C1, C0) in [(256, 32, 64, 64), (256, 16, 64, 128), (256, 32, 3, 64), (128, 14, 10, 20)]:
     x = torch.rand(N, H, H, C1, device="cuda"); f = torch.rand(C1, 3, 3, C0, device="cuda") - 0.5; b = torch.rand(C0, device="cuda")
     y = torch.zeros(N, H, H, C0, device="cuda"); dx = torch.zeros_like(x); df = torch.zeros_like(f); db = torch.zeros_like(b)
