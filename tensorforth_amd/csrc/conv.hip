@@ -644,10 +644,80 @@ __global__ void __launch_bounds__(256) k_conv_dx_few(const float *__restrict__ D
     if (b < fa.nfold) conv_df_fold_body(fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot, b);
     else conv_dx_few_body<K, S, P, CO>(DO, DX, DX2, F, N, H0, W0, C0, H1, W1, b - fa.nfold, (int)gridDim.x - fa.nfold);
 }
+// Same layer shape (C1 = CO <= 4 input channels) but MANY output channels (C0 = 32 / 64 / 128, e.g. the 3 -> 64 first layer of a
+// CIFAR net): with a thread per pixel every lane walks its own 4*C0-byte run of dO, a wave touches 64 different runs per load and
+// the L1 thrashes (90 us for N=256, 32x32, 3->64 = 6 % of the vector peak).  Here LPP = C0/4 lanes share a pixel, lane q owns
+// channels 4q..4q+3: a load instruction reads whole pixels (fully coalesced 16 B per lane), the lane's 4 x 9 x CO weights live in
+// registers for the whole grid-stride loop, and the LPP partial sums meet through an xor tree.  3x3, stride 1 only.
+template <int CO, int LPP>
+__device__ __forceinline__ void conv_dx_wide_body(const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2,
+                                                  const float *__restrict__ F, int N, int H0, int W0, int H1, int W1, int bx, int gx) {
+    constexpr int K = 3, KK = 9, C0 = LPP * 4, PPW = 64 / LPP, PPB = 4 * PPW;    // pixels per wave / per workgroup
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane % LPP, sub = lane / LPP;
+    float4 wt[CO][KK];                                                           // F[c1][K-1-ky][K-1-kx][4q..4q+3]
+#pragma unroll
+    for (int c = 0; c < CO; c++)
+#pragma unroll
+        for (int t = 0; t < KK; t++) wt[c][t] = *reinterpret_cast<const float4 *>(F + ((long)c * KK + (KK - 1 - t)) * C0 + 4 * q);
+    const long npix = (long)N * H1 * W1;
+    for (long p0 = (long)bx * PPB; p0 < npix; p0 += (long)gx * PPB) {
+        const long pix = p0 + w * PPW + sub;
+        const bool live = pix < npix;
+        int x, y, n; split3(live ? pix : 0, W1, H1, x, y, n);
+        const float *nD = DO + (long)n * H0 * W0 * C0 + 4 * q;
+        float4 v[KK]; bool ok[KK];
+#pragma unroll
+        for (int ky = 0; ky < K; ky++)
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) {
+                const int gi = y + 1 - ky, gj = x + 1 - kx;                       // P = 1, S = 1
+                ok[ky * K + kx] = live && gi >= 0 && gi < H0 && gj >= 0 && gj < W0;
+                v[ky * K + kx] = *reinterpret_cast<const float4 *>(nD + (ok[ky * K + kx] ? ((long)gi * W0 + gj) * C0 : 0));   // unconditional
+            }
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; c++) acc[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KK; t++) {
+            const float v0 = ok[t] ? v[t].x : 0.f, v1 = ok[t] ? v[t].y : 0.f, v2 = ok[t] ? v[t].z : 0.f, v3 = ok[t] ? v[t].w : 0.f;
+#pragma unroll
+            for (int c = 0; c < CO; c++) {
+                acc[c] = fmaf(v0, wt[c][t].x, acc[c]); acc[c] = fmaf(v1, wt[c][t].y, acc[c]);
+                acc[c] = fmaf(v2, wt[c][t].z, acc[c]); acc[c] = fmaf(v3, wt[c][t].w, acc[c]);
+            }
+        }
+#pragma unroll
+        for (int off = LPP / 2; off > 0; off >>= 1)
+#pragma unroll
+            for (int c = 0; c < CO; c++) acc[c] += __shfl_xor(acc[c], off, 64);
+        if (live && q == 0) {
+#pragma unroll
+            for (int c = 0; c < CO; c++) { DX[pix * CO + c] = acc[c]; if (DX2) DX2[pix * CO + c] = acc[c]; }
+        }
+    }
+}
+template <int CO, int LPP>
+__global__ void __launch_bounds__(256) k_conv_dx_wide(const float *__restrict__ DO, float *__restrict__ DX, float *__restrict__ DX2,
+                                                      const float *__restrict__ F, int N, int H0, int W0, int H1, int W1, FoldArgs fa) {
+    const int b = blockIdx.x;
+    if (b < fa.nfold) conv_df_fold_body(fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot, b);
+    else conv_dx_wide_body<CO, LPP>(DO, DX, DX2, F, N, H0, W0, H1, W1, b - fa.nfold, (int)gridDim.x - fa.nfold);
+}
 template <int CO>
 void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, float *DX, float *DX2, const float *F,
                         int N, int H0, int W0, int C0, int H1, int W1, FoldArgs fa) {
     const long npix = (long)N * H1 * W1;
+    static int wide = -1; if (wide < 0) { const char *e = getenv("T4K_DX_WIDE"); wide = e ? atoi(e) : 1; }
+    if (wide && K == 3 && S == 1 && P == 1 && (C0 == 32 || C0 == 64 || C0 == 128) && aligned16(DO) && aligned16(F)) {
+        const int ppb = 4 * (64 / (C0 / 4));
+        static int wpc = -1; if (wpc < 0) { const char *e = getenv("T4K_DX_WIDE_WPC"); wpc = e ? atoi(e) : 8; }
+        long gw = (npix + ppb - 1) / ppb; if (gw > (long)st().cu_count * wpc) gw = (long)st().cu_count * wpc;   // the weights are loaded once per workgroup
+        const dim3 gg((unsigned)gw + fa.nfold), bb(256);
+        if (C0 == 32)      hipLaunchKernelGGL((k_conv_dx_wide<CO, 8>),  gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
+        else if (C0 == 64) hipLaunchKernelGGL((k_conv_dx_wide<CO, 16>), gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
+        else               hipLaunchKernelGGL((k_conv_dx_wide<CO, 32>), gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
+        return;
+    }
     long gx = (npix + 255) / 256; if (gx > 8192) gx = 8192;
     const dim3 g((unsigned)gx + fa.nfold), b(256);
     switch ((K << 8) | (S << 4) | P) {

@@ -532,6 +532,9 @@ def test_poolblock_matches_unfused_oracle(t4k, dev, oracle, pre, pool, post, fla
     (4, 8, 6, 40, 3, "dropout", "leaky", True, False),         # two output-channel tiles (40 > 32), Cout % 4 == 0 -> quad-shared Philox
     (3, 6, 5, 7, 3, "dropout", None, False, False),            # Cout % 4 != 0 -> per-element Philox path
     (2, 16, 64, 64, 3, None, "relu", False, False),            # many channels: not fusable in-kernel, the entry composes the launches
+    (3, 10, 3, 64, 3, None, "relu", False, True),              # image-input layer with many output channels: coalesced dX (16 lanes per pixel)
+    (2, 8, 1, 32, 3, None, None, False, False),                # ... 8 lanes per pixel
+    (1, 6, 4, 128, 3, "relu", None, False, False),             # ... 32 lanes per pixel
 ])
 def test_conv_block_forward_and_dual_store_backward(t4k, dev, oracle, N, H, C1, C0, K, pre, post, flat, icopy):
     """t4k_conv2d_block_fwd == t4k_conv2d_fwd + the element-wise run as separate oracle layers (every tensor of the run, the
