@@ -270,6 +270,11 @@ int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *blk, int N
  * Y as above, ACT_O / ACT_F = activation output / derivative mask of Y; dropout draws the Philox slice t4k_rand would */
 int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y, int layer, float alpha,
                        float *ACT_F, float *ACT_O, int N, int E0, int E1, t4k_stream_t s);
+/* classifier head in one call: [linear E1 -> H + element-wise layer] + [linear H -> E2 (+ softmax when P2 != NULL)] =
+ * t4k_linear_act_fwd(X, W1, B1, Y1, layer, alpha, F1, A1) then t4k_linear_softmax_fwd / t4k_linear_fwd on A1, with every
+ * tensor written; when the first GEMM is split along K the second layer's launch folds the slabs itself (one launch fewer) */
+int t4k_mlp_head_fwd(const float *X, const float *W1, const float *B1, float *Y1, int layer, float alpha, float *F1, float *A1,
+                     const float *W2, const float *B2, float *Y2, float *P2, int N, int H, int E1, int E2, t4k_stream_t s);
 /* linear layer followed by a softmax layer (_flinear + _fsoftmax forward.cu:157-198, 229-243): Y as above,
  * P[N,E0] = row softmax of Y; both tensors are written */
 int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P,

@@ -146,6 +146,12 @@ int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, 
     if (DXM) return rc(t4o_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1), "k_tt_op");
     return T4K_OK;
 }
+int t4k_mlp_head_fwd(const float *X, const float *W1, const float *B1, float *Y1, int layer, float alpha, float *F1, float *A1,
+                     const float *W2, const float *B2, float *Y2, float *P2, int N, int H, int E1, int E2, t4k_stream_t st) {
+    int r = t4k_linear_act_fwd(X, W1, B1, Y1, layer, alpha, F1, A1, N, H, E1, st); if (r) return r;
+    if (P2) return t4k_linear_softmax_fwd(A1, W2, B2, Y2, P2, N, E2, H, st);
+    return t4k_linear_fwd(A1, W2, B2, Y2, N, E2, H, st);
+}
 int t4k_loss_linear_bwd(const float *X, const float *W, float *OUT, const float *TGT, float *OUT2, float *DX, const float *MASK, float *DXM,
                         float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t st) {
     int r = t4k_tt_op2(T4K_SUB, OUT, TGT, OUT, OUT2, (long)N * E0, st); if (r) return r;

@@ -772,7 +772,6 @@ void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
 // Optional activation epilogue (the layer that follows a linear layer: relu / tanh / ... / dropout): O keeps the linear
 // output, ACT_O / ACT_F receive the activation output and derivative mask (k_activate nmath.cu:37-70); dropout draws its
 // Philox slice here, exactly the values t4k_rand would have stored in the mask tensor.
-struct ActEpi { int layer; float alpha; float *F, *A; RngArg rng; };
 __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ part, float *O, long mn, int nsplit,
                                                      float alpha, float beta, const float *__restrict__ bias, int N, ActEpi ep) {
     uint64_t base = 0, seed = 0;
@@ -862,8 +861,9 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
 }
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,
                 int tA, int tB, int M, int N, int K, int C, t4k_stream_t s, const ActEpi *epi = nullptr, bool *epi_done = nullptr,
-                ColSum *cs = nullptr) {
+                ColSum *cs = nullptr, XFold *defer = nullptr) {
     if (epi_done) *epi_done = false;
+    if (defer) defer->part = nullptr;
     if (!A || !B || !O || M < 0 || N < 0 || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_gemm: bad argument");
     if (M == 0 || N == 0) return T4K_OK;
     GemmP p;
@@ -938,7 +938,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             }
         } else launch_variant<64, 64, 64, true, true, false>(p, grid, tA, tB, hs);
     }
-    if (nsplit > 1 && !p.pair) {
+    if (nsplit > 1 && !p.pair && defer && alpha == 1.0f && beta == 0.0f) {      // the consumer folds the slabs (fused head)
+        defer->part = p.part; defer->nsplit = nsplit; defer->mn = (long)M * N;
+    } else if (nsplit > 1 && !p.pair) {
         const long mn = (long)M * N;
         ActEpi ep = {0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
         if (epi && epi->layer) {
@@ -957,7 +959,7 @@ namespace t4k {
 int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
 // linear_small.hip: classifier-head sized layers on the vector ALUs, one launch each way
 bool linear_small_ok(int E0, int E1);
-int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs);
+int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xf = nullptr);
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, bool train, hipStream_t hs,
                       const float *MASK = nullptr, float *DXM = nullptr, const float *TGT = nullptr, float *DY2 = nullptr);
 }
@@ -998,6 +1000,32 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;
+}
+// classifier head: [linear + element-wise layer] + [linear (+ softmax)].  When the first GEMM is split along K and the second
+// layer is head-sized, the second layer's kernel folds the slabs, applies bias + activation (writing Y1, F1, A1 as the fold
+// launch would) while staging its input rows: two launches instead of three.  Otherwise the two fused entries in sequence.
+int t4k_mlp_head_fwd(const float *X, const float *W1, const float *B1, float *Y1, int layer, float alpha, float *F1, float *A1,
+                     const float *W2, const float *B2, float *Y2, float *P2, int N, int H, int E1, int E2, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X || !W1 || !Y1 || !F1 || !A1 || !W2 || !Y2 || N < 0) return fail(T4K_ERR_ARG, "t4k_mlp_head_fwd: bad argument");
+    if (N == 0) return T4K_OK;
+    if (!linear_small_ok(H, E1) && linear_small_ok(E2, H)) {
+        XFold xf; xf.part = nullptr;
+        int rc = gemm_launch(X, W1, Y1, B1, 1.0f, 0.0f, 0, 1, N, H, E1, 1, s, nullptr, nullptr, nullptr, &xf); if (rc) return rc;
+        if (xf.part) {
+            xf.bias = B1; xf.Y = Y1; xf.ep = ActEpi{ layer, alpha, F1, A1, RngArg{0, 0, nullptr} };
+            if (layer == T4K_L_DROPOUT) xf.ep.rng = rng_draw(S(s), (uint64_t)((xf.mn + 3) >> 2));
+            linear_small_fwd(A1, W2, B2, Y2, P2, N, E2, H, S(s), &xf);
+            T4K_LAUNCH_CHECK(); return T4K_OK;
+        }
+        const long n = (long)N * H;                         // the GEMM ran unsplit: Y1 is complete, continue layer by layer
+        if (layer == T4K_L_DROPOUT) { rc = t4k_rand(F1, n, T4K_UNIFORM, 0.0f, 1.0f, s); if (rc) return rc; }
+        rc = t4k_activate(layer, Y1, A1, F1, alpha, n, s); if (rc) return rc;
+    } else {
+        int rc = t4k_linear_act_fwd(X, W1, B1, Y1, layer, alpha, F1, A1, N, H, E1, s); if (rc) return rc;
+    }
+    if (P2) return t4k_linear_softmax_fwd(A1, W2, B2, Y2, P2, N, E2, H, s);
+    return t4k_linear_fwd(A1, W2, B2, Y2, N, E2, H, s);
 }
 // linear followed by a softmax layer: Y = X W^T + b, P = softmax(Y); one launch when the head is small
 int t4k_linear_softmax_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, t4k_stream_t s) {

@@ -18,25 +18,56 @@ namespace {
 
 constexpr int LS_MAX_FLOATS = 12288;          // 48 KiB of dynamic LDS
 
-// rows per wave = 64 / LG, lanes of a group = output index e0
-template <int LG>
+// rows per wave = 64 / LG, lanes of a group = output index e0.  NARROW (fold mode): a workgroup owns only ONE wave's worth of rows -
+// all 256 threads fold / stage them (4x the workgroups and threads on the slab reads), wave 0 alone computes the few dot products
+template <int LG, bool NARROW = false>
 __global__ void __launch_bounds__(256) k_linsmall_fwd(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ B,
-                                                      float *__restrict__ Y, float *__restrict__ P, int N, int E0, int E1) {
+                                                      float *__restrict__ Y, float *__restrict__ P, int N, int E0, int E1, XFold xf) {
     extern __shared__ float sm[];
-    constexpr int RPW = 64 / LG, RPB = 4 * RPW;
+    constexpr int RPW = 64 / LG, RPB = NARROW ? RPW : 4 * RPW;
     const int ldw = E1 + 1;                                      // odd-ish stride: lanes (= rows of W) hit different banks
     float *Ws = sm, *Xs = sm + E0 * ldw;
     const int tid = threadIdx.x;
     for (int r = tid / 64; r < E0; r += 4)                       // one wave per row of W: coalesced reads
         for (int k = tid & 63; k < E1; k += 64) Ws[r * ldw + k] = W[(long)r * E1 + k];
     const int row0 = blockIdx.x * RPB;
+    if (xf.part) {
+        // the input rows are still split-K slabs of the layer in front: fold, add its bias, apply its element-wise layer (same
+        // arithmetic and Philox positions as k_splitk_fold, gemm.hip) and publish Y / mask / activation for these rows
+        uint64_t base = 0, seed = 0;
+        const bool draw = xf.ep.layer == T4K_L_DROPOUT;
+        if (draw) rng_begin(xf.ep.rng, base, seed);
+        for (int e = tid; e < RPB * E1; e += 256) {               // one element per thread and trip, its slab loads all independent
+            const int r = e / E1, k = e - r * E1, n = row0 + r;
+            {
+                float a = 0.f;
+                if (n < N) {
+                    const long z = (long)n * E1 + k;
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) v[j] = xf.part[(long)(j < xf.nsplit ? j : 0) * xf.mn + z];
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) s += (j < xf.nsplit) ? v[j] : 0.f;
+                    for (int j = 16; j < xf.nsplit; j++) s += xf.part[(long)j * xf.mn + z];
+                    float o = s;
+                    if (xf.bias) o += xf.bias[k];
+                    xf.Y[z] = o;
+                    float f; act_rt(xf.ep.layer, o, draw ? philox_u01_at(base, seed, z) : 0.f, xf.ep.alpha, a, f);
+                    xf.ep.F[z] = f; xf.ep.A[z] = a;
+                }
+                Xs[r * E1 + k] = a;
+            }
+        }
+        if (draw && xf.ep.rng.state) rng_advance_last_block(xf.ep.rng.state, base, (uint64_t)((xf.mn + 3) >> 2));
+    } else
     for (int r = tid / 64; r < RPB; r += 4) {
         const int n = row0 + r;
         for (int k = tid & 63; k < E1; k += 64) Xs[r * E1 + k] = n < N ? X[(long)n * E1 + k] : 0.f;
     }
     __syncthreads();
-    const int lane = tid & 63, w = tid >> 6, e0 = lane % LG, rloc = w * RPW + lane / LG, n = row0 + rloc;
-    const bool live = e0 < E0 && n < N;
+    const int lane = tid & 63, w = tid >> 6, e0 = lane % LG, rloc = (NARROW ? 0 : w * RPW) + lane / LG, n = row0 + rloc;
+    const bool live = e0 < E0 && n < N && (!NARROW || w == 0);
     float acc = 0.f;
     if (live) {
         const float *xs = Xs + rloc * E1, *ws = Ws + e0 * ldw;
@@ -187,9 +218,10 @@ bool linear_small_ok(int E0, int E1) {
     return E0 >= 1 && E0 <= 64 && E1 >= 1 && E1 <= 512 && E0 * (E1 + 1) + 16 * E1 <= LS_MAX_FLOATS && E0 * E1 + 64 * E0 <= LS_MAX_FLOATS;
 }
 
-int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs) {
+int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xfp) {
+    XFold xf; if (xfp) xf = *xfp; else { xf.part = nullptr; xf.nsplit = 0; xf.mn = 0; xf.bias = nullptr; xf.Y = nullptr; xf.ep = ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}}; }
     const int LG = E0 <= 16 ? 16 : (E0 <= 32 ? 32 : 64);
-    const int RPB = 4 * (64 / LG);
+    const int RPB = (xfp ? 1 : 4) * (64 / LG);
     const size_t lds = sizeof(float) * (size_t)(E0 * (E1 + 1) + RPB * E1);
     const dim3 g((N + RPB - 1) / RPB), b(256);
     static bool attr = false;
@@ -200,9 +232,15 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4);
         attr = true;
     }
-    if (LG == 16)      hipLaunchKernelGGL(k_linsmall_fwd<16>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1);
-    else if (LG == 32) hipLaunchKernelGGL(k_linsmall_fwd<32>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1);
-    else               hipLaunchKernelGGL(k_linsmall_fwd<64>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1);
+    if (xfp) {
+        if (LG == 16)      hipLaunchKernelGGL((k_linsmall_fwd<16, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
+        else if (LG == 32) hipLaunchKernelGGL((k_linsmall_fwd<32, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
+        else               hipLaunchKernelGGL((k_linsmall_fwd<64, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
+        return T4K_OK;
+    }
+    if (LG == 16)      hipLaunchKernelGGL(k_linsmall_fwd<16>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
+    else if (LG == 32) hipLaunchKernelGGL(k_linsmall_fwd<32>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
+    else               hipLaunchKernelGGL(k_linsmall_fwd<64>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
     return T4K_OK;
 }
 

@@ -162,6 +162,11 @@ __device__ __forceinline__ void act_rt_lean(int L, float i, float u, float alpha
     else if (L == T4K_L_LEAKYRL) { if (i > 0.0f) { f = 1.0f; o = i; } else { f = alpha; o = alpha * i; } }
     else { const float2 r = act_rt_slow(L, i, alpha); o = r.x; f = r.y; }
 }
+// activation epilogue of a linear layer (k_splitk_fold / the fused head): F = derivative mask, A = activation output
+struct ActEpi { int layer; float alpha; float *F, *A; RngArg rng; };
+// a linear layer's input that does not exist yet: X[z] = act(sum_k part[k][z] + bias[z % E]) - the split-K slabs of the layer in
+// front; the consumer folds them while staging its rows and writes Y (pre-activation), F and A exactly as k_splitk_fold would
+struct XFold { const float *part; int nsplit; long mn; const float *bias; float *Y; ActEpi ep; };
 // element `a` of a tensor whose Philox slice starts at counter `base` (units of 4 elements): the same value
 // t4k_rand(uniform, bias 0, scale 1) would have stored at index a
 __device__ __forceinline__ float philox_u01_at(uint64_t base, uint64_t seed, long a) {

@@ -259,6 +259,15 @@ void Model::run_forward(Tensor &input) {
         if (fused && in.grad_fn == T4K_L_LINEAR && i + 2 < L && is_eltwise(out.grad_fn) &&
             (run_of_[i + 1] < 0 || runs_[run_of_[i + 1]].count == 1)) {   // linear + lone activation / dropout: the activation rides in the GEMM's fold launch
             Tensor &act = at(i + 2);
+            if (act.grad_fn == T4K_L_LINEAR && i + 4 < L && at(i + 3).grad_fn == T4K_L_SOFTMAX) {
+                // classifier head: [linear + activation] + [linear + softmax] - the second launch folds the first GEMM's split-K slabs
+                Tensor &y2 = at(i + 3), &prob = at(i + 4);
+                chk(t4k_mlp_head_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.grad_fn, out.xparm, out.grad[4]->data, act.data,
+                                     act.grad[0]->data, act.grad[1]->data, y2.data, prob.data, out.N(), (int)out.HWC(), (int)in.HWC(), (int)y2.HWC(), stream()),
+                    "nn#fhead");
+                x = prob.data; i += 3;
+                continue;
+            }
             chk(t4k_linear_act_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.grad_fn, out.xparm, out.grad[4]->data, act.data,
                                    out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+act");
             x = act.data; i++;

@@ -699,6 +699,39 @@ def test_linear_with_activation_epilogue(t4k, dev, oracle, N, E0, E1, layer):
         assert np.array_equal(dev.down(dF), f) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
 
 
+@pytest.mark.parametrize("N,E1,H,E2,layer,softmax", [(128, 980, 100, 10, "dropout", True), (128, 980, 100, 10, "relu", True), (64, 2048, 64, 16, "dropout", False),
+                                                      (32, 40, 16, 4, "relu", True), (128, 256, 512, 10, "dropout", True), (7, 1000, 30, 3, "tanh", True)])
+def test_mlp_head_forward(t4k, dev, oracle, N, E1, H, E2, layer, softmax):
+    """t4k_mlp_head_fwd == [linear + element-wise layer] + [linear (+ softmax)] layer by layer: every tensor (Y1, mask, A1, Y2, P2), the
+    dropout mask bit-exact and the Philox stream advanced identically - whether the second launch folds the first GEMM's split-K
+    slabs (980 -> 100 -> 10), the first layer is itself head-sized, or the shapes fall back to the separate entries."""
+    o = oracle.lib(); P = oracle.P
+    LAY = {"dropout": (oracle.L_DROPOUT, 0.5), "relu": (oracle.L_RELU, 0.0), "tanh": (oracle.L_TANH, 0.0)}
+    L, alpha = LAY[layer]
+    rng = np.random.default_rng(E1 + H)
+    X = rng.standard_normal((N, E1)).astype(np.float32)
+    W1 = (rng.standard_normal((H, E1)) * 0.05).astype(np.float32); b1 = rng.standard_normal(H).astype(np.float32)
+    W2 = (rng.standard_normal((E2, H)) * 0.2).astype(np.float32); b2 = rng.standard_normal(E2).astype(np.float32)
+    Y1 = np.zeros((N, H), np.float32); o.t4o_linear_fwd(P(X), P(W1), P(b1), P(Y1), N, H, E1)
+    seed, off = 3, 1 << 22
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    f = np.zeros(N * H, np.float32); A1 = np.zeros((N, H), np.float32)
+    if layer == "dropout": o.t4o_rand(P(f), N * H, 0, 0.0, 1.0)
+    o.t4o_activate(L, P(Y1), P(A1), P(f), alpha, N * H)
+    Y2 = np.zeros((N, E2), np.float32); o.t4o_linear_fwd(P(A1), P(W2), P(b2), P(Y2), N, E2, H)
+    P2 = np.zeros_like(Y2); o.t4o_softmax(P(Y2), P(P2), N, E2)
+    t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+    dY1, dF, dA1, dY2, dP2 = dev.zeros((N, H)), dev.zeros(N * H), dev.zeros((N, H)), dev.zeros((N, E2)), dev.zeros((N, E2))
+    for rep_ in range(2):                                                          # second call: same stream position again
+        t4k.call("t4k_rand_set_offset", off)
+        t4k.call("t4k_mlp_head_fwd", p(dev.up(X)), p(dev.up(W1)), p(dev.up(b1)), p(dY1), L, alpha, p(dF), p(dA1),
+                 p(dev.up(W2)), p(dev.up(b2)), p(dY2), p(dP2) if softmax else None, N, H, E1, E2, None)
+        assert rel(dev.down(dY1), Y1) < RTOL and rel(dev.down(dA1), A1) < RTOL and rel(dev.down(dY2), Y2) < RTOL
+        if softmax: assert rel(dev.down(dP2), P2) < RTOL
+        if layer == "dropout":
+            assert np.array_equal(dev.down(dF), f) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
+
+
 # ----------------------------------------------------------------------------- error behaviour (reference: print-and-continue, never abort)
 def test_error_paths_return_status_and_reference_messages(t4k, dev):
     """Unsupported geometry / bad arguments come back as negative status codes with the reference's own message text
