@@ -181,7 +181,7 @@ def main():
                            "avg_launch_us": round(avg_ms * 1e3, 2), "best_launch_us": round(best * 1e3, 2),
                            "flop_per_launch": flops}
         # ---- CPU baseline: the oracle ("port"), bounded sample
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported by the 1-GPU run only (rank 0 of an N-GPU job just prints)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import t4oracle
             rng = np.random.default_rng(42)
