@@ -732,6 +732,40 @@ def test_mlp_head_forward(t4k, dev, oracle, N, E1, H, E2, layer, softmax):
             assert np.array_equal(dev.down(dF), f) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
 
 
+def test_conv_random_shapes_non_square(t4k, dev, oracle):
+    """Seeded sweep over non-square grids, odd batches and channel counts on every kernel family (direct image-input kernels,
+    gather-MFMA, LDS-staged many-channel tiling): forward (+ the fused pool block where the grid is even) and backward vs the oracle."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(2024)
+    combos = [(1, 10), (3, 16), (3, 64), (4, 7), (5, 9), (10, 20), (12, 33), (20, 10), (32, 16), (64, 24), (64, 64), (96, 20)]
+    for case in range(24):
+        C1, C0 = combos[case % len(combos)]
+        K = (3, 5, 3, 1)[case % 4]; Pd = K // 2
+        N = int(rng.integers(1, 6)); H = int(rng.integers(2, 8)) * 2; W = int(rng.integers(2, 9)) * 2 + (2 if case % 3 == 0 else 0)
+        X = rng.standard_normal((N, H, W, C1)).astype(np.float32); F = (rng.standard_normal((C1, K, K, C0)) * 0.2).astype(np.float32)
+        B = rng.standard_normal(C0).astype(np.float32)
+        Y = np.zeros((N, H, W, C0), np.float32); o.t4o_conv2d_fwd(P(X), P(Y), P(F), P(B), N, H, W, C1, H, W, C0, K, 1, Pd)
+        tag = "case %d: N=%d %dx%d %d->%d K=%d" % (case, N, H, W, C1, C0, K)
+        dX, dF, dB, dY = dev.up(X), dev.up(F), dev.up(B), dev.zeros(Y.shape)
+        t4k.call("t4k_conv2d_fwd", p(dX), p(dY), p(dF), p(dB), N, H, W, C1, H, W, C0, K, 1, Pd, None)
+        assert rel(dev.down(dY), Y) < RTOL, tag
+        if K in (3, 5):                                               # fused block: maxpool + relu behind the conv
+            q = np.zeros((N, H // 2, W // 2, C0), np.float32); o.t4o_pool(oracle.L_MAXPOOL, P(Y), P(q), N, H, W, H // 2, W // 2, C0, 2)
+            f = np.zeros(q.size, np.float32); r = np.zeros_like(q); o.t4o_activate(oracle.L_RELU, P(q), P(r), P(f), 0.0, q.size)
+            dq, dm, dr, dY2 = dev.zeros(q.shape), dev.zeros(q.size), dev.zeros(q.shape), dev.zeros(Y.shape)
+            blk = PoolBlock(); blk.KS = 2; blk.pool_layer = oracle.L_MAXPOOL; blk.pool_out = p(dq)
+            blk.post_layer = oracle.L_RELU; blk.post_mask = p(dm); blk.post_out = p(dr)
+            t4k.call("t4k_conv2d_block_fwd", p(dX), None, p(dY2), p(dF), p(dB), ctypes.byref(blk), N, H, W, C1, H, W, C0, K, 1, Pd, None)
+            assert rel(dev.down(dY2), Y) < RTOL and rel(dev.down(dq), q) < RTOL and rel(dev.down(dr), r) < RTOL, tag
+        G = rng.standard_normal(Y.shape).astype(np.float32)
+        DX = np.zeros_like(X); DF = np.zeros_like(F); DB = np.zeros_like(B)
+        o.t4o_conv2d_bwd(P(X), P(G), P(DX), P(F), P(DF), P(DB), N, H, W, C1, H, W, C0, K, 1, Pd, 1)
+        dDX, dDX2, dDF, dDB = dev.zeros(X.shape), dev.zeros(X.shape), dev.zeros(F.shape), dev.zeros(B.shape)
+        t4k.call("t4k_conv2d_bwd2", p(dX), p(dev.up(G)), p(dDX), p(dDX2), p(dF), p(dDF), p(dDB), N, H, W, C1, H, W, C0, K, 1, Pd, 1, None)
+        assert rel(dev.down(dDX), DX) < RTOL and np.array_equal(dev.down(dDX2), dev.down(dDX)), tag
+        assert rel(dev.down(dDF), DF) < RTOL and rel(dev.down(dDB), DB) < RTOL, tag
+
+
 # ----------------------------------------------------------------------------- error behaviour (reference: print-and-continue, never abort)
 def test_error_paths_return_status_and_reference_messages(t4k, dev):
     """Unsupported geometry / bad arguments come back as negative status codes with the reference's own message text
