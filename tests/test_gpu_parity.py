@@ -732,6 +732,34 @@ def test_mlp_head_forward(t4k, dev, oracle, N, E1, H, E2, layer, softmax):
             assert np.array_equal(dev.down(dF), f) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
 
 
+def test_poolblock_non_square_grids(t4k, dev, oracle):
+    """Fused element-wise runs on non-square grids (H != W), 2x2 and 3x3 pooling, every vector width (C % 4, % 2, odd): forward
+    tensors and the in-place backward vs the oracle's separate layers."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(77)
+    for case, (KS, C, pool) in enumerate([(2, 8, "max"), (2, 6, "avg"), (2, 5, "min"), (3, 4, "max"), (3, 7, "avg"), (2, 20, "max")]):
+        N = int(rng.integers(1, 5)); H0 = int(rng.integers(2, 6)); W0 = H0 + int(rng.integers(1, 5)); H1, W1 = H0 * KS, W0 * KS
+        L = {"max": oracle.L_MAXPOOL, "avg": oracle.L_AVGPOOL, "min": oracle.L_MINPOOL}[pool]
+        n1, n0 = N * H1 * W1 * C, N * H0 * W0 * C
+        X = rng.standard_normal((N, H1, W1, C)).astype(np.float32); DY = rng.standard_normal((N, H0, W0, C)).astype(np.float32)
+        f1 = np.zeros(n1, np.float32); y1 = np.zeros_like(X); o.t4o_activate(oracle.L_RELU, P(X), P(y1), P(f1), 0.0, n1)
+        q = np.zeros((N, H0, W0, C), np.float32); o.t4o_pool(L, P(y1), P(q), N, H1, W1, H0, W0, C, KS)
+        f0 = np.zeros(n0, np.float32); r = np.zeros_like(q); o.t4o_activate(oracle.L_LEAKYRL, P(q), P(r), P(f0), 0.1, n0)
+        dX, d1, dm1, dq, dm0, dr = dev.up(X), dev.zeros(X.shape), dev.zeros(n1), dev.zeros(q.shape), dev.zeros(n0), dev.zeros(q.shape)
+        blk = PoolBlock(); blk.KS = KS; blk.pre_layer = oracle.L_RELU; blk.pre_mask = p(dm1); blk.pre_out = p(d1)
+        blk.pool_layer = L; blk.pool_out = p(dq); blk.post_layer = oracle.L_LEAKYRL; blk.post_alpha = 0.1; blk.post_mask = p(dm0); blk.post_out = p(dr)
+        t4k.call("t4k_poolblock_fwd", p(dX), ctypes.byref(blk), N, H1, W1, H0, W0, C, None)
+        tag = "case %d" % case
+        assert rel(dev.down(d1), y1) < 1e-6 and rel(dev.down(dq), q) < 1e-6 and rel(dev.down(dr), r) < 1e-6, tag
+        assert np.array_equal(dev.down(dm1), f1) and np.array_equal(dev.down(dm0), f0), tag
+        # backward, layer by layer in the oracle (each stage's input buffer receives its dX)
+        t = np.zeros(n0, np.float32); o.t4o_tt_op(oracle.MUL, P(DY), P(f0), P(t), n0); qb = t.reshape(q.shape).copy()
+        y1b = y1.copy(); o.t4o_dpool(L, P(y1b), P(qb), N, H1, W1, H0, W0, C, KS)
+        t1 = np.zeros(n1, np.float32); o.t4o_tt_op(oracle.MUL, P(y1b), P(f1), P(t1), n1)
+        t4k.call("t4k_poolblock_bwd", p(dev.up(DY)), p(dX), ctypes.byref(blk), N, H1, W1, H0, W0, C, None)
+        assert rel(dev.down(dX), t1.reshape(X.shape)) < 1e-6 and rel(dev.down(d1), y1b) < 1e-6 and rel(dev.down(dq), qb) < 1e-6, tag
+
+
 def test_conv_random_shapes_non_square(t4k, dev, oracle):
     """Seeded sweep over non-square grids, odd batches and channel counts on every kernel family (direct image-input kernels,
     gather-MFMA, LDS-staged many-channel tiling): forward (+ the fused pool block where the grid is even) and backward vs the oracle."""
