@@ -732,6 +732,29 @@ def test_mlp_head_forward(t4k, dev, oracle, N, E1, H, E2, layer, softmax):
             assert np.array_equal(dev.down(dF), f) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
 
 
+def test_linear_random_shapes(t4k, dev, oracle):
+    """Seeded sweep of linear forward / in-place backward over every GEMM regime: unaligned (no 16-byte loads), head-sized,
+    split-K, dual dW|dX launch, interior LDS-DMA tiles, 128x128 tiles."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(99)
+    shapes = [(5, 3, 7), (17, 33, 45), (64, 64, 64), (128, 128, 256), (100, 36, 1000), (30, 130, 70), (256, 256, 512), (48, 20, 2048),
+              (9, 64, 513), (512, 1024, 1024), (1, 10, 100), (200, 7, 19), (96, 72, 516), (64, 1000, 128)]
+    for (N, E0, E1) in shapes:
+        X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) / np.sqrt(E1)).astype(np.float32)
+        b = rng.standard_normal(E0).astype(np.float32)
+        Y = np.zeros((N, E0), np.float32); o.t4o_linear_fwd(P(X), P(W), P(b), P(Y), N, E0, E1)
+        dX, dW, db, dY = dev.up(X), dev.up(W), dev.up(b), dev.zeros((N, E0))
+        t4k.call("t4k_linear_fwd", p(dX), p(dW), p(db), p(dY), N, E0, E1, None)
+        tag = "N=%d E0=%d E1=%d" % (N, E0, E1)
+        assert rel(dev.down(dY), Y) < RTOL, tag
+        G = rng.standard_normal((N, E0)).astype(np.float32)
+        DW = rng.standard_normal((E0, E1)).astype(np.float32); DB = rng.standard_normal(E0).astype(np.float32); DX = np.zeros_like(X)
+        dDW, dDB = dev.up(DW), dev.up(DB)
+        o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)
+        t4k.call("t4k_linear_bwd", p(dX), p(dW), p(dev.up(G)), p(dX), p(dDW), p(dDB), N, E0, E1, 1, None)      # dX over X
+        assert rel(dev.down(dX), DX) < RTOL and rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL, tag
+
+
 def test_poolblock_non_square_grids(t4k, dev, oracle):
     """Fused element-wise runs on non-square grids (H != W), 2x2 and 3x3 pooling, every vector width (C % 4, % 2, odd): forward
     tensors and the in-place backward vs the oracle's separate layers."""
