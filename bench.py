@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--gemm-iters", type=int, default=200)
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); must be set before the HIP runtime starts
     import numpy as np
     import torch
     import torch.distributed as dist
