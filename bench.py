@@ -136,7 +136,7 @@ def main():
     dt = time.perf_counter() - t0
     if dp:
         tmax = torch.tensor([dt], device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.cpu()[0])
-    loss_txt = vm.eval("lbl loss.ce .")
+    loss_txt = vm.eval("img forward lbl loss.ce .")       # a fresh forward: after backprop the output tensor holds out - target (reference in-place convention)
     ms_step = dt / args.steps * 1e3
     img_s = world * N * args.steps / dt
 
@@ -152,7 +152,8 @@ def main():
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
                        "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
-                       "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None},
+                       "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None,
+                       "final_loss_note": "random images and labels, batch-SUM gradients (reference semantics): a throughput run, not a convergence test; training parity vs the oracle is in tests/"},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                               "traffic": None, "algorithmic_bytes_per_step": step_bytes},
