@@ -839,7 +839,10 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     auto big = [&](int m, int n) { return (long)((m + 127) / 128) * ((n + 127) / 128) >= (long)cu * 3 / 4; };
     auto splits = [&](int m, int n, int k) { return tiles(m, n) * 2 <= cu && k >= 256; };
     auto full = [](int m, int n, int k) { return m % 64 == 0 && n % 64 == 0 && k % 64 == 0; };
-    if (big(E0, E1) || big(N, E1) || splits(E0, E1, N) || splits(N, E1, E0)) return false;
+    static int deepk = -1; if (deepk < 0) { const char *e = getenv("T4K_GEMM_DUAL_MAXK"); deepk = e ? atoi(e) : 1024; }
+    // deep-K shapes would go split-K + fold (2 launches per GEMM); up to K = 1024 the single dual launch, unsplit, is faster (GAN round 0.346 -> 0.322 ms)
+    const bool sp = splits(E0, E1, N) || splits(N, E1, E0);
+    if (big(E0, E1) || big(N, E1) || (sp && (N > deepk || E0 > deepk))) return false;
     if ((gemm_variant() & 4) && (full(E0, E1, N) || full(N, E1, E0))) return false;
     const long t1 = tiles(E0, E1), t2 = tiles(N, E1), riders = (E0 + 63) / 64;
     if (t1 + riders + t2 > cu || N > 4096) return false;
