@@ -732,6 +732,25 @@ def test_mlp_head_forward(t4k, dev, oracle, N, E1, H, E2, layer, softmax):
             assert np.array_equal(dev.down(dF), f) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
 
 
+@pytest.mark.parametrize("N,E0,E1", [(128, 10, 100), (256, 512, 784), (256, 256, 512), (64, 100, 980), (33, 70, 45), (256, 784, 512)])
+def test_linear_backward_with_mask_multiply(t4k, dev, oracle, N, E0, E1):
+    """t4k_linear_bwd2: dX (in place over X), dW, dB as t4k_linear_bwd, plus DXM = dX (*) MASK (the element-wise layer in front) -
+    from the small-head kernel, from the dual GEMM launch's dX epilogue, or as a separate launch, depending on the shape."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N + E0 * 3 + E1)
+    X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) / np.sqrt(E0)).astype(np.float32)
+    G = rng.standard_normal((N, E0)).astype(np.float32); M = (rng.random((N, E1)) > 0.4).astype(np.float32) * 1.5
+    DW = rng.standard_normal((E0, E1)).astype(np.float32); DB = rng.standard_normal(E0).astype(np.float32); DX = np.zeros_like(X)
+    dDW, dDB = dev.up(DW), dev.up(DB)
+    o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)
+    for rep_ in range(2):
+        dX, dXM = dev.up(X), dev.zeros((N, E1))
+        if rep_ == 1: o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)     # accumulate dW / dB once more
+        t4k.call("t4k_linear_bwd2", p(dX), p(dev.up(W)), p(dev.up(G)), p(dX), p(dev.up(M)), p(dXM), p(dDW), p(dDB), N, E0, E1, 1, None)
+        assert rel(dev.down(dX), DX) < RTOL and rel(dev.down(dXM), DX * M) < RTOL
+        assert rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL
+
+
 def test_linear_random_shapes(t4k, dev, oracle):
     """Seeded sweep of linear forward / in-place backward over every GEMM regime: unaligned (no 16-byte loads), head-sized,
     split-K, dual dW|dX launch, interior LDS-DMA tiles, 128x128 tiles."""
