@@ -87,6 +87,28 @@ __global__ void __launch_bounds__(256) k_linsmall_fwd(const float *__restrict__ 
     }
 }
 
+// dW row e0: acc[q] += sum over this lane group's rows of dY[n] * X[n, c0 + 256 q]; U independent row loads per trip
+template <int QN, int U>
+__device__ __forceinline__ void dw_rows(const float *X, const float *dys, float (&acc)[2], int N, int E1, int NG, int ng, int c0) {
+#pragma unroll 1
+    for (int nb = ng; nb < N; nb += NG * U) {
+        float xv[U][QN]; float dv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int n = nb + u * NG;
+            const bool ok = n < N;
+            dv[u] = ok ? dys[n] : 0.f;
+            const float *xr = X + (long)(ok ? n : 0) * E1;
+#pragma unroll
+            for (int q = 0; q < QN; q++) { const int c = c0 + q * 256; xv[u][q] = xr[c < E1 ? c : 0]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < QN; q++) acc[q] = fmaf(dv[u], xv[u][q], acc[q]);
+    }
+}
+
 // blocks [0, nB): dW | dB for output row e0 = blockIdx.x; blocks [nB, nB+nA): dX for RA rows each
 __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const float *__restrict__ W, const float *__restrict__ DY,
                                                       float *DX, float *DW, float *DB, int N, int E0, int E1,
@@ -98,56 +120,45 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
     extern __shared__ float sm[];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < nB) {
-        // one output row e0 per workgroup: CL lanes cover the E1 + 1 columns (column E1 = bias gradient), the 256 / CL
-        // lane groups split the batch; all loads of a trip are independent (16 rows in flight), partial sums meet in LDS
+        // one output row e0 per workgroup: CL lanes cover the E1 columns, the 256 / CL lane groups split the batch; all loads of a
+        // trip are independent (U rows in flight per thread - the loop is pure latency, one memory round trip per trip), partial
+        // sums meet in LDS.  The bias gradient is the plain sum of the staged dY column (no pass over X needed).
         const int e0 = blockIdx.x;
-        int CL = 32; while (CL < E1 + 1 && CL < 256) CL <<= 1;
+        int CL = 32; while (CL < E1 && CL < 256) CL <<= 1;
         const int NG = 256 / CL, c0 = tid % CL, ng = tid / CL;
         float *dys = sm;                                         // dY[:, e0] for the whole batch
         for (int n = tid; n < N; n += 256) dys[n] = DY[(long)n * E0 + e0] - (TGT ? TGT[(long)n * E0 + e0] : 0.f);
         __syncthreads();
         if (TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // dY column staged
-        float acc[3] = {0.f, 0.f, 0.f};                          // columns c0, c0 + 256, c0 + 512 when E1 + 1 > 256
-#pragma unroll 1
-        for (int nb = ng; nb < N; nb += NG * 16) {
-            float xv[16][3]; float dv[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int n = nb + u * NG;
-                const bool ok = n < N;
-                dv[u] = ok ? dys[n] : 0.f;
-                const float *xr = X + (long)(ok ? n : 0) * E1;
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const int c = c0 + q * 256;
-                    xv[u][q] = (q == 0 || CL == 256) ? (c < E1 ? xr[c] : 1.f) : 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u++)
-#pragma unroll
-                for (int q = 0; q < 3; q++) acc[q] = fmaf(dv[u], xv[u][q], acc[q]);
-        }
+        float acc[2] = {0.f, 0.f};                               // columns c0 and c0 + 256 (E1 > 256)
+        if (E1 <= 256) dw_rows<1, 64>(X, dys, acc, N, E1, NG, ng, c0);
+        else           dw_rows<2, 32>(X, dys, acc, N, E1, NG, ng, c0);
+        float bsum = 0.f;                                        // dB: fixed-order sum of the column (thread t: rows t, t+256, ...)
+        for (int n = tid; n < N; n += 256) bsum += dys[n];
         __syncthreads();
         if (alias && tid == 0) __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // X fully consumed
-        float *red = sm + N;                                     // [NG][CL][3]
+        float *red = sm + N;                                     // [NG][CL][2], then [256] for the bias sum
         if (NG > 1) {
 #pragma unroll
-            for (int q = 0; q < 3; q++) red[(ng * CL + c0) * 3 + q] = acc[q];
+            for (int q = 0; q < 2; q++) red[(ng * CL + c0) * 2 + q] = acc[q];
             __syncthreads();
             if (ng == 0)
                 for (int g2 = 1; g2 < NG; g2++)
 #pragma unroll
-                    for (int q = 0; q < 3; q++) acc[q] += red[(g2 * CL + c0) * 3 + q];
+                    for (int q = 0; q < 2; q++) acc[q] += red[(g2 * CL + c0) * 2 + q];
+            __syncthreads();
+        }
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) {                                          // 256 -> 64 -> xor tree, fixed order
+            float b = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) b += __shfl_xor(b, off, 64);
+            if (tid == 0) DB[e0] += b;
         }
         if (ng == 0) {
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const int c = c0 + q * 256;
-                if (q > 0 && CL < 256) break;
-                if (c < E1) DW[(long)e0 * E1 + c] += acc[q];
-                else if (c == E1) DB[e0] += acc[q];
-            }
+            if (c0 < E1) DW[(long)e0 * E1 + c0] += acc[0];
+            if (c0 + 256 < E1) DW[(long)e0 * E1 + c0 + 256] += acc[1];
         }
         return;
     }
