@@ -606,30 +606,35 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     const int kend = min(K, kbeg + p.kchunk);
     const int nst  = (kend - kbeg) / BK;
 
-    // per-lane DMA source pointers of stage 0
-    const float *srcA[NJ], *srcB[NJ];
+    // per-lane DMA source offsets (bytes from the operand base) of stage 0; the launcher guarantees both operands span < 4 GiB
+    unsigned voffA[NJ], voffB[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int i = w * NJ + j;
         if (AKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
-                   srcA[j] = p.A + (long)(m0 + r) * K + kbeg + q * 4; }
+                   voffA[j] = (unsigned)(((long)(m0 + r) * K + kbeg + q * 4) * 4); }
         else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
-                   srcA[j] = p.A + (long)(kbeg + kk) * M + m0 + ch * 4; }
+                   voffA[j] = (unsigned)(((long)(kbeg + kk) * M + m0 + ch * 4) * 4); }
         if (BKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
-                   srcB[j] = p.B + (long)(n0 + r) * K + kbeg + q * 4; }
+                   voffB[j] = (unsigned)(((long)(n0 + r) * K + kbeg + q * 4) * 4); }
         else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
-                   srcB[j] = p.B + (long)(kbeg + kk) * N + n0 + ch * 4; }
+                   voffB[j] = (unsigned)(((long)(kbeg + kk) * N + n0 + ch * 4) * 4); }
     }
     const long stepA = AKC ? BK : (long)BK * M, stepB = BKC ? BK : (long)BK * N;
 
+    // The DMA is issued from inline asm (saddr form: scalar base + each lane's fixed 32-bit byte offset).  Through the
+    // __builtin_amdgcn_global_load_lds builtin hipcc books the load as "flat, may touch LDS": while one is pending it turns every LDS
+    // dependency into s_waitcnt lgkmcnt(0), so the operand reads just issued for the NEXT chunk were waited for at once - one exposed LDS
+    // round trip per 8 MFMAs (1024^3: 21.5 us).  Invisible to the compiler, it emits counted lgkmcnt(N) ladders instead (19.4 us); the
+    // DMA's own completion is waited for by the explicit vmcnt waits in wait_next().
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
     auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        float *base = lds + buf * STAGE + (w * NJ) * 256;
+        const float *ba = p.A + kt * stepA, *bb = p.B + kt * stepB;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[j] + kt * stepA),
-                                             (__attribute__((address_space(3))) void *)(base + j * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[j] + kt * stepB),
-                                             (__attribute__((address_space(3))) void *)(base + BM * BK + j * 256), 16, 0, 0);
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
         }
     };
 
@@ -656,8 +661,11 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     auto mm = [&](float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
         if (PRIO) __builtin_amdgcn_s_setprio(2);                 // keep the matrix pipe fed: the MFMA burst outranks the other wave's loads
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                       // keep the two accumulators alternating (hipcc pairs them otherwise)
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
@@ -729,9 +737,127 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
             float o = v * alpha;
             if (beta != 0.f) o += p.O[z] * beta;
             if (p.bias) o += p.bias[gn];
-            p.O[z] = o;
+            __builtin_nontemporal_store(o, &p.O[z]);        // streaming store: no dirty L2 lines left for the kernel-end write-back (-0.27 us at 1024^3)
         }
     }
+}
+
+
+// The plain product O = A @ B (word `matmul`, tA = tB = 0, alpha = 1, beta = 0, no bias, interior 64x64 tiles, K % 128 == 0) has its own
+// copy of the 8-wave kernel with nothing else in it: the same loop inside the general template above measures 20.1 us at 1024^3, this
+// one 19.4 (tools/gemm_lab.hip: every variant with in-kernel cycle stamps; the loop is sensitive to the code around it).
+struct PlainP { const float *A, *B; float *O; int M, N, K; };
+__global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
+    constexpr int BM = 64, BN = 64, BK = 128;
+    constexpr int NC = BK / 8, CH = BK / 4;
+    constexpr int STAGE = (BM + BN) * BK, NI = BK / 4, NJ = NI / 8, NCG = NC / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = w >> 2, w4 = w & 3, wm = w4 >> 1, wn = w4 & 1, h = lane >> 5, l31 = lane & 31;
+    const int c0 = kg * NCG;
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = M / BM, tiles_n = N / BN, T = tiles_m * tiles_n;
+    int L;
+    {
+        const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
+        L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i;
+    }
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = L / per_group, first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (L % per_group) % gsz, tn = (L % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN, nst = K / BK;
+    unsigned voffA[NJ], voffB[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int i = w * NJ + j;
+        { const int r = i * 2 + lane / CH, ql = lane % CH, q = ql ^ (r & (CH - 1)); voffA[j] = (unsigned)(((m0 + r) * K + q * 4) * 4); }
+        { const int kk = i * 4 + lane / 16, ch = lane % 16; voffB[j] = (unsigned)((kk * N + n0 + ch * 4) * 4); }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        const float *ba = p.A + (long)kt * BK, *bb = p.B + (long)kt * BK * N;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
+        }
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int ra_ = wm * 32 + l31, rb_ = wn * 32 + l31;
+    auto rd = [&](const float *a, const float *b, int ci, float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
+        const v4f t = *reinterpret_cast<const v4f *>(a + ra_ * BK + (((ci * 2 + h) ^ (ra_ & (CH - 1))) << 2));
+        av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bv[j] = b[(ci * 8 + 4 * h + j) * BN + rb_];
+    };
+    auto mm = [&](float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
+    };
+    float ca[4], cb[4];
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    rd(lds, lds + BM * BK, c0, ca, cb);
+    int buf = 0;
+    for (int kt = 0; kt < nst; kt++) {
+        const int b1 = buf ^ 1;
+        if (kt + 1 < nst) issue(kt + 1, b1);
+        const float *a = lds + buf * STAGE, *b = a + BM * BK;
+#pragma unroll
+        for (int ci = 0; ci + 1 < NCG; ci++) {
+            float na[4], nbv[4];
+            rd(a, b, c0 + ci + 1, na, nbv);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float na[4], nbv[4];
+        if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, c0, na, nbv);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ca, cb);
+        if (kt + 1 < nst) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
+        }
+        buf = b1;
+    }
+    const int gn = n0 + wn * 32 + l31;
+    float add[16];
+    __syncthreads();
+    if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[(w4 * 16 + r) * 64 + lane] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) add[r] = lds[(w4 * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        __builtin_nontemporal_store((acc0[r] + acc1[r]) + add[r], &p.O[(long)gm * N + gn]);
+    }
+}
+void launch_nn_plain(const GemmP &p, dim3 grid, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)2 * 128 * 128 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
+    PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K };
+    hipLaunchKernelGGL(k_gemm_nn_plain, dim3(grid.x), dim3(512), lds_bytes, s, q);
 }
 
 template <int BK>
@@ -927,8 +1053,10 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     } else {
         const bool full = M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
         if (full && (var & 4)) {
-            if ((var & 16) && !p.pair) {
-                if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs);   // bit5: 128-deep stages, 2 buffers
+            const bool span32 = (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);   // 32-bit DMA lane offsets
+            if ((var & 16) && !p.pair && span32) {
+                if ((var & 32) && kchunk % 128 == 0 && !tA && !tB && nsplit == 1 && alpha == 1.0f && beta == 0.0f && !bias && !(var & 64)) launch_nn_plain(p, grid, hs);   // `matmul`
+                else if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs);   // bit5: 128-deep stages, 2 buffers
                 else if (var & 1) launch_glds8<64>(p, grid, tA, tB, hs); else launch_glds8<32>(p, grid, tA, tB, hs);
             }
             else if ((var & 1) && !p.pair) launch_glds<64>(p, grid, tA, tB, hs); else launch_glds<32>(p, grid, tA, tB, hs);   // pair: 2 x 48 KiB LDS per CU
