@@ -30,6 +30,43 @@ NETS = {"nn_f": dict(bytes_per_img=494720, params=101030, flop_per_img=3134160),
         "nn_c": dict(bytes_per_img=294800, params=197210, flop_per_img=1605360)}
 
 
+def dry_run(rank, world, args):
+    """The N-rank plumbing without a GPU: gloo rendezvous on 127.0.0.1, the bench contract's barrier and MAX-over-ranks time
+    reduction, one JSON line from rank 0 with n_gpus = ranks that really joined.  No metric is measured (`value` is null)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter(); dist.barrier(); dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt]); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ones = torch.ones(1); dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": BASELINE_METRIC, "value": None, "unit": "images/s", "n_gpus": int(ones.item()), "steps": 0, "warmup": 0,
+                          "dry_run": True, "config": {"workload": "launch / rendezvous / reduction plumbing only", "parallelism": "dp%d" % world,
+                                                      "allreduce": "gloo"}}), flush=True)
+    dist.barrier(); dist.destroy_process_group()
+    return 0
+
+
+def cpu_workers(mode_args, n_workers, timeout=120):
+    """Run n_workers copies of oracle/cpu_baseline.py side by side (plain subprocesses: this process holds a HIP runtime and must
+    not fork); returns their parsed stdout lines."""
+    import subprocess
+    script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, script] + [str(a) for a in mode_args], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+             for _ in range(n_workers)]
+    out = []
+    for p_ in procs:
+        try:
+            o, _ = p_.communicate(timeout=timeout)
+            out.append([float(x) for x in o.split()])
+        except Exception:
+            p_.kill()
+    return [o for o in out if o]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,23 +76,31 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-iters", type=int, default=200)
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction plumbing only (gloo, no GPU work, no metric): CPU test of the N-rank path")
     args = ap.parse_args()
+
+    # ---- N > 1 asked for from a plain `python bench.py --gpus N`: become N ranks (one process per GPU) or fail - never a 1-rank record
+    from tensorforth_amd import launch
+    if launch.need_spawn(args.gpus):
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:], dry_run=args.dry_run))
+    rank, world, local = launch.check_world(args.gpus)
+    if args.dry_run:
+        return dry_run(rank, world, args)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); must be set before the HIP runtime starts
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    if local >= torch.cuda.device_count():
+        sys.stderr.write("bench: rank %d has no device %d (%d visible)\n" % (rank, local, torch.cuda.device_count())); sys.exit(2)
     torch.cuda.set_device(local)
     dp = world > 1 or os.environ.get("T4_BENCH_FORCE_DP") == "1"     # FORCE_DP: exercise the all-reduce path on one GPU
     if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     from tensorforth_amd import lib as t4lib, pymodel
     from tensorforth_amd.vm import VM
@@ -68,16 +113,21 @@ def main():
                  "nn_c": "0.5 10 conv2d 2 maxpool relu flatten 100 linear relu 10 linear softmax"}
     vm.eval("0 trace\n%d 28 28 1 nn.model %s constant net\n" % (N, NET_WORDS[args.net]))
     k = t4lib.load()
-    if world > 1:                                         # replicas are identical (same Philox seed and offsets so far);
-        k.call("t4k_rand_set_offset", (rank + 1) << 36)   # from here each rank draws its own shard and dropout masks
+    # replicas are identical (same Philox seed, same draws so far).  The synthetic batch is the rank's rows of the WHOLE batch's draw
+    # (stream slice [rank*n, (rank+1)*n) of a world*n-element draw), like the dropout masks later (t4k_rand_set_shard):
+    # N ranks x 128 images see exactly the data and masks of 1 rank x 128N images
+    n_img = N * 28 * 28
+    off0 = k.lib.t4k_rand_offset()
+    k.call("t4k_rand_set_offset", off0 + rank * n_img)
+    vm.eval("%d 28 28 1 tensor rand constant img\n" % N)
+    k.call("t4k_rand_set_offset", off0 + world * n_img)
     out_txt = vm.eval(
-        "%d 28 28 1 tensor rand constant img\n"
         ": hot ( T -- T ) %d 0 do 1 i 10 * i 7 * %d + 10 mod + t! loop ;\n"
         "%d vector zeros hot %d 1 10 1 reshape4 constant lbl\n"
         ": fb ( N -- N ) img forward lbl backprop ;\n"
         ": opt ( N -- N ) 0.01 0.0 nn.sgd ;\n"
         ": steps ( N n -- N ) 1- for fb opt next ;\n"
-        "net 2 steps\n" % (N, N, rank, N * 10, N))
+        "net 2 steps\n" % (N, rank, N * 10, N))
     assert "?" not in out_txt.replace("-> ok", ""), out_txt
     # ---- data parallel: the VM owns an RCCL communicator (t4k_comm_*) and sums its gradient slab in-order on its own
     # stream inside `nn.sgd`, so the training loop stays inside the VM exactly as on one GPU.  torch.distributed only
@@ -100,6 +150,13 @@ def main():
             native = float(good.item()) > 0
             if not native:
                 k.lib.t4k_comm_destroy()
+            elif k.lib.t4k_comm_world() != world or k.lib.t4k_comm_rank() != rank:
+                sys.stderr.write("bench: RCCL communicator has %d ranks, %d asked for\n" % (k.lib.t4k_comm_world(), world)); sys.exit(3)
+    if dp and not native:
+        k.call("t4k_rand_set_shard", rank, world)         # torch.distributed reduces the slab; the masks are still keyed by sample
+    joined = k.lib.t4k_comm_world() if native else (dist.get_world_size() if dp else 1)
+    if joined != world:
+        sys.stderr.write("bench: %d ranks joined the reduction, %d asked for\n" % (joined, world)); sys.exit(3)
     slab = vm.grad_slab() if (dp and not native) else None
     vstream = vm.stream() if (dp and not native) else None
     reducer = None
@@ -146,7 +203,7 @@ def main():
         step_bytes = N * net["bytes_per_img"] + 4 * net["params"] * 7            # k_opt = 7 for SGD
         out = {
             "metric": BASELINE_METRIC,   # `value` = CNN train images/sec; the GEMM TFLOP/s (% of MFMA peak) part is the `roofline` object
-            "value": round(img_s, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(img_s, 1), "unit": "images/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
@@ -182,6 +239,15 @@ def main():
                            "traffic": GEMM_TRAFFIC_BYTES, "traffic_source": "profiles/r01_bench_pmc_hbm.txt (TCC_EA0_RDREQ*64B x2 gfx950 correction + WRREQ_64B*64B, separate --pmc pass)",
                            "avg_launch_us": round(avg_ms * 1e3, 2), "best_launch_us": round(best * 1e3, 2),
                            "flop_per_launch": flops}
+        # ---- the same product through the Forth word, reference idiom `for @ drop next` (examples/t4_20a.4th:20-29): per call an arena
+        # allocation for the result, the VM's dispatch, the launch, and `drop` freeing the tensor again
+        vm.eval("1024 1024 matrix rand constant ma\n1024 1024 matrix rand constant mb\n: mx ( A B n -- A B ) 1- for matmul drop next ;\nma mb 1500 mx 2drop\n")
+        torch.cuda.synchronize()
+        wl = []
+        for _ in range(3):
+            t0w = time.perf_counter(); vm.eval("ma mb %d mx 2drop\n" % args.gemm_iters); torch.cuda.synchronize(); wl.append((time.perf_counter() - t0w) / args.gemm_iters * 1e6)
+        out["roofline"]["word_level_us"] = round(sum(wl) / len(wl), 2)
+        out["roofline"]["word_level_note"] = "`ma mb N mx` with `: mx 1- for matmul drop next ;` (t4_20a.4th:20-29 idiom), host clock around the VM call + device sync, %d words per sample" % args.gemm_iters
         # ---- CPU baseline: the oracle ("port"), bounded sample
         if not args.no_cpu_baseline and world == 1:       # the CPU baseline is reported by the 1-GPU run only (rank 0 of an N-GPU job just prints)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -194,18 +260,33 @@ def main():
             t0 = time.perf_counter(); nst = 0
             while True:
                 om.forward(x); om.backprop(); om.sgd(0.01, 0.0); nst += 1
-                if time.perf_counter() - t0 > 12.0 or nst >= 50:
+                if time.perf_counter() - t0 > 6.0 or nst >= 50:
                     break
             cdt = time.perf_counter() - t0
             a = np.random.default_rng(1).random((1024, 1024)).astype(np.float32); o_ = np.zeros((1024, 1024), np.float32)
             t1 = time.perf_counter()
             t4oracle.lib().t4o_gemm_host_blocked(t4oracle.P(a), t4oracle.P(a), t4oracle.P(o_), 1.0, 0.0, 1024, 1024, 1024)
             gdt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": round(N * nst / cdt, 1), "unit": "images/s", "cores": 1, "kind": "port",
-                                   "sample": "%d oracle training steps of the same %s batch-%d workload (single thread)" % (nst, args.net, N),
+            # all cores: one worker process per core the bench may run on, each training its own batch-N replica (the CPU analogue of
+            # sample sharding), and the blocked host GEMM on row slabs of the same 1024^3 product
+            try:
+                ncore = len(os.sched_getaffinity(0))
+            except Exception:
+                ncore = os.cpu_count() or 1
+            wr = cpu_workers(["step", args.net, N, 6.0], ncore)
+            all_img_s = sum(N * r[0] / r[1] for r in wr if len(r) == 2 and r[1] > 0)
+            rows = max(4, 1024 // ncore)
+            gr = cpu_workers(["gemm", rows, 1024, 1024, 3.0], ncore)
+            all_gflops = sum(r[0] * 2.0 * rows * 1024 * 1024 / r[1] for r in gr if len(r) == 2 and r[1] > 0) / 1e9
+            out["cpu_baseline"] = {"value": round(all_img_s, 1), "unit": "images/s", "cores": len(wr), "kind": "port",
+                                   "sample": "%d worker processes (one per core), each ~6 s of oracle training steps of the same %s batch-%d workload "
+                                             "(%d steps in total); single thread: %d steps in %.1f s" % (len(wr), args.net, N, int(sum(r[0] for r in wr)), nst, cdt),
+                                   "single_thread_value": round(N * nst / cdt, 1),
                                    "host_cores_available": os.cpu_count(),
                                    "gemm_1024_host_blocked_ms": round(gdt * 1e3, 1),
-                                   "gemm_1024_host_gflops": round(flops / gdt / 1e9, 2)}
+                                   "gemm_1024_host_gflops": round(flops / gdt / 1e9, 2),
+                                   "gemm_1024_host_gflops_all_cores": round(all_gflops, 1), "gemm_all_cores_workers": len(gr),
+                                   "gemm_note": "reference's blocked host GEMM (tensor.cu:97-123 restated): one thread on the full 1024^3 product, then %d workers on %d-row slabs for ~3 s" % (len(gr), rows)}
         print(json.dumps(out), flush=True)
     if dp:
         if native:

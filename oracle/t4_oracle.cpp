@@ -384,6 +384,21 @@ int t4o_rand(float *d, long n, int opt, float bias, float scale) {
     return OK;
 }
 
+/* data-parallel shard of the stream (include/t4k.h t4k_rand_set_shard): a dropout mask of n elements is elements
+ * [rank*n, (rank+1)*n) of the whole batch's n*world-element draw */
+static int g_shard_rank = 0, g_shard_world = 1;
+int t4o_rand_set_shard(int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) return ERR_ARG;
+    g_shard_rank = rank; g_shard_world = world; return OK;
+}
+int t4o_dropout_mask(float *mask, long n) {
+    const uint64_t nq = (uint64_t)((n + 3) / 4), off0 = g_off;
+    g_off = off0 + (uint64_t)g_shard_rank * nq * 4;
+    int rc = t4o_rand(mask, n, 0, 0.0f, 1.0f);
+    g_off = off0 + (uint64_t)g_shard_world * nq * 4;
+    return rc;
+}
+
 /* ------------------------------------------------------------------------ nn */
 /* k_bias src/nn/nmath.cu:27-35 */
 int t4o_bias(const float *B, float *O, int N, int E0) {

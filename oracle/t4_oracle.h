@@ -49,6 +49,8 @@ int      t4o_rand_init(uint64_t seed);
 int      t4o_rand(float *d, long n, int opt, float bias, float scale);
 uint64_t t4o_rand_offset(void);
 int      t4o_rand_set_offset(uint64_t off);
+int      t4o_rand_set_shard(int rank, int world);   /* include/t4k.h t4k_rand_set_shard */
+int      t4o_dropout_mask(float *mask, long n);      /* include/t4k.h t4k_dropout_mask   */
 
 int t4o_bias(const float *B, float *O, int N, int E0);
 int t4o_activate(int layer, const float *I, float *O, float *F, float alpha, long n);

@@ -87,6 +87,8 @@ int t4k_rand_init(uint64_t seed) { return t4o_rand_init(seed); }
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t) { return t4o_rand(d, n, opt, bias, scale); }
 uint64_t t4k_rand_offset(void) { return t4o_rand_offset(); }
 int t4k_rand_set_offset(uint64_t o) { return t4o_rand_set_offset(o); }
+int t4k_rand_set_shard(int r, int w) { return t4o_rand_set_shard(r, w); }
+int t4k_dropout_mask(float *m, long n, t4k_stream_t) { return t4o_dropout_mask(m, n); }
 int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t) { return t4o_bias(B, O, N, E0); }
 int t4k_activate(int l, const float *I, float *O, float *F, float a, long n, t4k_stream_t) { return rc(t4o_activate(l, I, O, F, a, n), "k_activate"); }
 int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t) { return t4o_softmax(I, O, N, C); }
@@ -138,7 +140,7 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int
 }
 int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y, int layer, float alpha, float *F, float *A, int N, int E0, int E1, t4k_stream_t st) {
     int r = t4k_linear_fwd(X, W, B, Y, N, E0, E1, st); if (r) return r;
-    if (layer == T4K_L_DROPOUT) t4o_rand(F, (long)N * E0, T4K_UNIFORM, 0.0f, 1.0f);
+    if (layer == T4K_L_DROPOUT) t4o_dropout_mask(F, (long)N * E0);
     return rc(t4o_activate(layer, Y, A, F, alpha, (long)N * E0), "k_activate");
 }
 int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, const float *MASK, float *DXM, float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t st) {
@@ -173,7 +175,7 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
     const long n1 = (long)N * H1 * W1 * C, n0 = (long)N * H0 * W0 * C;
     const float *x = X;
     if (b->pre_layer) {
-        if (b->pre_layer == T4K_L_DROPOUT) t4o_rand(b->pre_mask, n1, T4K_UNIFORM, 0.0f, 1.0f);
+        if (b->pre_layer == T4K_L_DROPOUT) t4o_dropout_mask(b->pre_mask, n1);
         int r = t4o_activate(b->pre_layer, x, b->pre_out, b->pre_mask, b->pre_alpha, n1); if (r) return rc(r, "poolblock pre");
         x = b->pre_out;
     }

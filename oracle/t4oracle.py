@@ -208,7 +208,7 @@ class OracleModel:
                 y.ravel()[:] = a.ravel()
             elif fn in (L_RELU, L_TANH, L_SIGMOID, L_SELU, L_LEAKYRL, L_ELU, L_DROPOUT):
                 if fn == L_DROPOUT:
-                    o.t4o_rand(P(L.aux), L.aux.size, 0, 0.0, 1.0)
+                    o.t4o_dropout_mask(P(L.aux), L.aux.size)       # keyed by sample when a data-parallel shard is set
                 o.t4o_activate(fn, P(a), P(y), P(L.aux), L.xparm, a.size)
             elif fn == L_SOFTMAX:
                 n = a.shape[0]; o.t4o_softmax(P(a), P(y), n, a.size // n)

@@ -63,6 +63,7 @@ int t4k_comm_init(const void *id128, int rank, int world) {
     ncclResult_t r = R.CommInitRank(&R.comm, world, id, rank);
     if (r != ncclSuccess) { R.comm = nullptr; return nccl_fail(r, "ncclCommInitRank"); }
     R.rank = rank; R.world = world;
+    st().shard_rank = rank; st().shard_world = world;     // dropout masks are keyed by the sample's place in the whole batch from now on
     return T4K_OK;
 }
 int t4k_comm_world(void) { return R.comm ? R.world : 0; }
@@ -79,6 +80,7 @@ int t4k_allreduce_sum(float *buf, long n, t4k_stream_t s) {
 int t4k_comm_destroy(void) {
     if (R.comm && R.CommDestroy) { (void)hipDeviceSynchronize(); R.CommDestroy(R.comm); }
     R.comm = nullptr; R.world = 0; R.rank = 0;
+    st().shard_rank = 0; st().shard_world = 1;
     return T4K_OK;
 }
 

@@ -838,7 +838,7 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
     pe.pre = blk->pre_layer; pe.pool = blk->pool_layer; pe.post = blk->post_layer; pe.a_pre = blk->pre_alpha; pe.a_post = blk->post_alpha;
     const long npix = (long)N * H0 * W0;
     pe.rng = RngArg{0, 0, nullptr};
-    if (pe.pre == T4K_L_DROPOUT) pe.rng = rng_draw(hs, (uint64_t)((npix * C0 + 3) >> 2));
+    if (pe.pre == T4K_L_DROPOUT) pe.rng = rng_draw(hs, (uint64_t)((npix * C0 + 3) >> 2), true);
     const int ksplit = conv_gemm_ksplit(npix, C0, C1, K);
     const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);
     const dim3 g((unsigned)((npix + (128 / ksplit) - 1) / (128 / ksplit)), (unsigned)((C0 + 31) / 32));

@@ -1076,7 +1076,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
         ActEpi ep = {0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
         if (epi && epi->layer) {
             ep = *epi; if (epi_done) *epi_done = true;
-            if (ep.layer == T4K_L_DROPOUT) ep.rng = rng_draw(hs, (uint64_t)((mn + 3) >> 2));
+            if (ep.layer == T4K_L_DROPOUT) ep.rng = rng_draw(hs, (uint64_t)((mn + 3) >> 2), true);
         }
         hipLaunchKernelGGL(k_splitk_fold, dim3(grid_for(mn)), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N, ep);
     }
@@ -1126,7 +1126,7 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
     }
     if (!done) {
         const long n = (long)N * E0;
-        if (layer == T4K_L_DROPOUT) { int rc = t4k_rand(ACT_F, n, T4K_UNIFORM, 0.0f, 1.0f, s); if (rc) return rc; }
+        if (layer == T4K_L_DROPOUT) { int rc = t4k_dropout_mask(ACT_F, n, s); if (rc) return rc; }
         return t4k_activate(layer, Y, ACT_O, ACT_F, alpha, n, s);
     }
     T4K_LAUNCH_CHECK();
@@ -1145,12 +1145,12 @@ int t4k_mlp_head_fwd(const float *X, const float *W1, const float *B1, float *Y1
         int rc = gemm_launch(X, W1, Y1, B1, 1.0f, 0.0f, 0, 1, N, H, E1, 1, s, nullptr, nullptr, nullptr, &xf); if (rc) return rc;
         if (xf.part) {
             xf.bias = B1; xf.Y = Y1; xf.ep = ActEpi{ layer, alpha, F1, A1, RngArg{0, 0, nullptr} };
-            if (layer == T4K_L_DROPOUT) xf.ep.rng = rng_draw(S(s), (uint64_t)((xf.mn + 3) >> 2));
+            if (layer == T4K_L_DROPOUT) xf.ep.rng = rng_draw(S(s), (uint64_t)((xf.mn + 3) >> 2), true);
             linear_small_fwd(A1, W2, B2, Y2, P2, N, E2, H, S(s), &xf);
             T4K_LAUNCH_CHECK(); return T4K_OK;
         }
         const long n = (long)N * H;                         // the GEMM ran unsplit: Y1 is complete, continue layer by layer
-        if (layer == T4K_L_DROPOUT) { rc = t4k_rand(F1, n, T4K_UNIFORM, 0.0f, 1.0f, s); if (rc) return rc; }
+        if (layer == T4K_L_DROPOUT) { rc = t4k_dropout_mask(F1, n, s); if (rc) return rc; }
         rc = t4k_activate(layer, Y1, A1, F1, alpha, n, s); if (rc) return rc;
     } else {
         int rc = t4k_linear_act_fwd(X, W1, B1, Y1, layer, alpha, F1, A1, N, H, E1, s); if (rc) return rc;

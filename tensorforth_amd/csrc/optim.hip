@@ -102,10 +102,12 @@ namespace t4k {
 __global__ void k_rng_seed_dev(uint64_t *state, uint64_t ctr, uint64_t seed) { state[0] = ctr; state[1] = 0; state[2] = seed; }
 // Reserve nq counters for one launch.  Eager: by-value (base, seed), host counter advances.  While a graph is being
 // captured: the launch reads the device copy instead and advances it itself; the host only totals the draw.
-RngArg rng_draw(hipStream_t hs, uint64_t nq) {
+RngArg rng_draw(hipStream_t hs, uint64_t nq, bool sample_keyed) {
     State &g = st();
     RngArg a = { g.rng_ctr, g.seed, nullptr };
-    if (g.capturing) {
+    if (sample_keyed && g.shard_world > 1) {              // this rank's rows of the whole batch's draw (eager only: DP does not replay graphs)
+        a.base += (uint64_t)g.shard_rank * nq; g.rng_ctr += (uint64_t)g.shard_world * nq;
+    } else if (g.capturing) {
         if (!g.d_rng) (void)hipMalloc((void **)&g.d_rng, 4 * sizeof(uint64_t));   // allocated by t4k_graph_begin normally
         a.state = g.d_rng; g.cap_adv += nq;
     } else g.rng_ctr += nq;
@@ -154,6 +156,19 @@ int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long ma
 int t4k_rand_init(uint64_t seed) { T4K_REQUIRE_INIT(); State &g = st(); g.seed = seed; g.rng_ctr = 0; g.d_rng_ctr = ~0ull; return T4K_OK; }
 uint64_t t4k_rand_offset(void) { return st().rng_ctr * 4; }
 int t4k_rand_set_offset(uint64_t off) { T4K_REQUIRE_INIT(); State &g = st(); g.rng_ctr = off / 4; g.d_rng_ctr = ~0ull; return T4K_OK; }
+int t4k_rand_set_shard(int rank, int world) {
+    T4K_REQUIRE_INIT();
+    if (world < 1 || rank < 0 || rank >= world) return fail(T4K_ERR_ARG, "t4k_rand_set_shard: rank %d of %d", rank, world);
+    State &g = st(); g.shard_rank = rank; g.shard_world = world;
+    return T4K_OK;
+}
+int t4k_dropout_mask(float *mask, long n, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
+    if (!mask) return fail(T4K_ERR_ARG, "t4k_dropout_mask: null");
+    const RngArg ra = rng_draw(S(s), (uint64_t)((n + 3) / 4), true);
+    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), mask, n, (int)T4K_UNIFORM, 0.0f, 1.0f, ra);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!d) return fail(T4K_ERR_ARG, "t4k_rand: null");

@@ -27,6 +27,9 @@ struct State {
     uint64_t   *d_rng   = nullptr;
     uint64_t    d_rng_ctr = ~0ull;     // what the device copy holds (after pending stream work); ~0 = unknown
     uint64_t    cap_adv = 0;           // counters drawn by the capture in progress
+    // data-parallel shard (t4k_rand_set_shard): a SAMPLE-KEYED draw (dropout masks) of nq counters takes the slice
+    // [ctr + rank*nq, ctr + (rank+1)*nq) and moves the stream by world*nq - the draw the rank's samples would get inside the whole batch
+    int         shard_rank = 0, shard_world = 1;
     bool        capturing = false;
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
@@ -37,7 +40,7 @@ struct State {
 State &st();
 // what a drawing kernel receives: eager = (base, seed) by value and state == nullptr; inside a graph = the device copy
 struct RngArg { uint64_t base, seed; uint64_t *state; };
-RngArg rng_draw(hipStream_t hs, uint64_t nq);    // host: reserve nq counters (4 elements each) of the stream for one launch (optim.hip)
+RngArg rng_draw(hipStream_t hs, uint64_t nq, bool sample_keyed = false);    // host: reserve nq counters (4 elements each) of the stream for one launch (optim.hip)
 
 int  fail(int code, const char *fmt, ...);
 int  hip_fail(hipError_t e, const char *what);

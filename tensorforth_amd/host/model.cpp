@@ -239,7 +239,7 @@ void Model::run_forward(Tensor &input) {
         for (int i = 0; i + 1 < L; i++)
             if (at(i).grad_fn == T4K_L_DROPOUT) {
                 Tensor &m = *at(i).grad[4];
-                chk(t4k_rand(m.data, (long)m.numel, T4K_UNIFORM, 0.0f, 1.0f, fork()), "rand"); masks = true;
+                chk(t4k_dropout_mask(m.data, (long)m.numel, fork()), "rand"); masks = true;
             }
     const float *x = input.data;
     for (int i = 0; i + 1 < L; i++) {
@@ -311,7 +311,7 @@ const float *Model::fstep(Tensor &in, Tensor &out, const float *x) {
         chk(t4k_linear_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.N(), (int)out.HWC(), (int)in.HWC(), s), "nn#flinear"); break;
     case T4K_L_FLATTEN: lazy_copy(x, out); return x;    // a copy in the reference (forward.cu:96); the next layer reads the source
     case T4K_L_DROPOUT:                                 // mask = fresh uniform draws (already drawn up front on the side-stream schedule)
-        if (!concurrent()) chk(t4k_rand(in.grad[4]->data, (long)in.grad[4]->numel, T4K_UNIFORM, 0.0f, 1.0f, s), "rand");
+        if (!concurrent()) chk(t4k_dropout_mask(in.grad[4]->data, (long)in.grad[4]->numel, s), "rand");
         /* fall through */
     case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SIGMOID: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU:
         chk(t4k_activate(fn, x, out.data, in.grad[4]->data, in.xparm, (long)in.numel, s), "nn#factivate"); break;
@@ -366,11 +366,22 @@ void Model::hit_lazy() {                                 // count on the GPU now
     chk(t4k_hit(out.data, hot->data, out.N(), (int)out.HWC(), hit_dev, stream()), "nn#hit");
     hit_pending_ = true;
 }
+// data parallel: `nn.hit` and the loss words report the WHOLE batch when the library owns a communicator - one small
+// all-reduce(SUM) of the rank-local value on the VM stream (hit counts are exact in fp32 below 2^24; every rank must run the word)
+DU Model::dp_sum(DU v) {
+    if (t4k_comm_world() < 2) return v;
+    if (!hit_dev) { void *p; t4k_malloc(&p, 64); hit_dev = (int *)p; }
+    float *d = (float *)hit_dev + 8, r = v;               // second half of the 64-byte scratch
+    t4k_memcpy_h2d(d, &r, sizeof(float), stream());
+    chk(t4k_allreduce_sum(d, 1, stream()), "allreduce (scalar)");
+    t4k_memcpy_d2h(&r, d, sizeof(float), stream()); t4k_sync(stream());
+    return r;
+}
 int Model::hit(bool recalc) {                           // loss.cpp:75-107
     if (recalc) hit_lazy();
     if (hit_pending_) {
         int c = 0; t4k_memcpy_d2h(&c, hit_dev, sizeof(int), stream()); t4k_sync(stream());
-        hit_ = c; hit_pending_ = false;
+        hit_ = (int)dp_sum((DU)c); hit_pending_ = false;
     }
     return hit_;
 }
@@ -382,7 +393,9 @@ DU Model::loss(Loss op, Tensor &tgt) {                  // loss.cpp:119-136: non
         return 0;
     }
     if (loss_t) *loss_t = out; else loss_t = &Store::get().copy(out);
-    return loss_t->loss(op, tgt);
+    const DU z = loss_t->loss(op, tgt);                  // = sum over the local rows / N_local
+    const int world = t4k_comm_world();
+    return world < 2 ? z : SCALAR(dp_sum(z) / (DU)world);   // equal shards: mean of the rank means = whole-batch mean
 }
 
 // ---------------------------------------------------------------- backprop

@@ -206,6 +206,7 @@ struct Model : Obj {
     Tensor &onehot(Tensor &t);
     Tensor &onehot(Dataset &d);
     int  hit(bool recalc = true);
+    DU   dp_sum(DU v);                         // SUM over the data-parallel ranks (identity without a communicator)
     void hit_lazy();                           // forward(dataset): enqueue the count, defer the read-back
     bool hit_pending_ = false;
     DU   loss(Loss op);

@@ -135,7 +135,7 @@ class Model:
                 k.call("t4k_copy", _p(a), _p(y), a.numel(), s)
             elif fn in (L_RELU, L_TANH, L_SIGMOID, L_SELU, L_LEAKYRL, L_ELU, L_DROPOUT):
                 if fn == L_DROPOUT:
-                    k.call("t4k_rand", _p(L.aux), L.aux.numel(), 0, 0.0, 1.0, s)
+                    k.call("t4k_dropout_mask", _p(L.aux), L.aux.numel(), s)
                 k.call("t4k_activate", fn, _p(a), _p(y), _p(L.aux), L.xparm, a.numel(), s)
             elif fn == L_SOFTMAX:
                 n = a.shape[0]; k.call("t4k_softmax", _p(a), _p(y), n, a.numel() // n, s)

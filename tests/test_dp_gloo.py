@@ -22,10 +22,13 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 GLOBAL_N = 8
 
 
-def _build(n):
+def _build(n, dropout=False):
     import t4oracle
     m = t4oracle.OracleModel(n, 12, 12, 1, seed=99)
-    m.conv2d(4, 0.5).maxpool(2).relu().flatten().linear(16).relu().linear(10).softmax()
+    if dropout:      # dropout behind the conv AND inside the head, as in the LeNet net of bench.py (t4_30e nn_f)
+        m.conv2d(4, 0.5).dropout(0.5).maxpool(2).relu().flatten().linear(16).dropout(0.25).linear(10).softmax()
+    else:
+        m.conv2d(4, 0.5).maxpool(2).relu().flatten().linear(16).relu().linear(10).softmax()
     return m
 
 
@@ -44,14 +47,22 @@ def _params(m):
     return [g for L in m.layers for g in (L.w, L.b) if g is not None]
 
 
-def _worker(rank, world, port, out_dir):
+def _masks(m):
+    import t4oracle
+    return [L.aux for L in m.layers if L.fn == t4oracle.L_DROPOUT]
+
+
+def _worker(rank, world, port, out_dir, dropout=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tensorforth_amd import dp
     x, lab = _data()
     lo, hi = dp.shard_rows(GLOBAL_N, rank, world)
-    m = _build(hi - lo)
+    m = _build(hi - lo, dropout)
+    if dropout:                                             # weights above were replicated draws; masks are keyed by sample from here on
+        import t4oracle
+        assert t4oracle.lib().t4o_rand_set_shard(rank, world) == 0
     for it in range(2):
         m.forward(x[lo:hi]); m.onehot_labels(lab[lo:hi]); m.backprop()
         gs = _grads(m)
@@ -71,7 +82,7 @@ def _worker(rank, world, port, out_dir):
         m.sgd(0.05, 0.0)
     loss_n = float(m.loss_ce()) * (hi - lo) if hasattr(m, "loss_ce") else 0.0
     tot = dp.allreduce_scalars([loss_n, float(hi - lo)])
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), *[p for p in _params(m)], tot=np.array(tot))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), *[p for p in _params(m)], tot=np.array(tot), **{"mask%d" % i: a for i, a in enumerate(_masks(m))})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -101,6 +112,25 @@ def test_two_rank_gloo_equals_single_process_large_batch(tmp_path):
         assert np.array_equal(a, b), "replicas diverged"                            # same slab on both ranks => bit-identical updates
         np.testing.assert_allclose(a, p, rtol=2e-5, atol=2e-6)                       # == large-batch update up to summation order
     assert r0["tot"][1] == GLOBAL_N
+
+
+def test_two_rank_gloo_with_dropout_equals_single_process_large_batch(tmp_path):
+    """dropout draws are keyed by the sample's place in the WHOLE batch (t4k_rand_set_shard / t4o_rand_set_shard), so
+    2 ranks x 4 samples draw exactly the masks of 1 rank x 8 samples and the two runs train to the same weights."""
+    world = 2
+    port = 29900 + (os.getpid() % 90)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), True), nprocs=world, join=True, start_method="spawn")
+    x, lab = _data()
+    m = _build(GLOBAL_N, dropout=True)
+    for _ in range(2):
+        m.forward(x); m.onehot_labels(lab); m.backprop(); m.sgd(0.05, 0.0)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    for i, mk in enumerate(_masks(m)):                      # derivative masks of the last step (0/1): bit-exact rows of the big-batch mask
+        got = np.concatenate([r[k]["mask%d" % i] for k in range(world)], axis=0)
+        assert np.array_equal(got.reshape(mk.shape), mk), "dropout mask %d differs from the whole-batch draw" % i
+    for i, p in enumerate(_params(m)):
+        assert np.array_equal(r[0]["arr_%d" % i], r[1]["arr_%d" % i]), "replicas diverged"
+        np.testing.assert_allclose(r[0]["arr_%d" % i], p, rtol=2e-5, atol=2e-6)
 
 
 def test_sharded_batchnorm_sums_reproduce_whole_batch_oracle():
