@@ -14,6 +14,8 @@ ten4_vm *ten4_new(int device, unsigned long long seed, int trace_level) {
     ten4_vm *h = new ten4_vm();
     h->vm.trace_lvl = trace_level;
     h->vm.init();
+    t4::die_if_no_backend();                            // the backend seeds itself once per process from T4_SEED ...
+    t4k_rand_init(seed);                                // ... every embedded VM starts its own stream at `seed` (a second VM in one process used to inherit the first one's position)
     return h;
 }
 void ten4_free(ten4_vm *h) { delete h; }
