@@ -228,6 +228,16 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
                     float *DF, float *DB,
                     int N, int H1, int W1, int C1, int H0, int W0, int C0,
                     int K, int S, int P, int train, t4k_stream_t s);
+/* Transposed convolution layer (word `dconv2d`, L_DCONV; allocation Model::_iconv txn model.cpp:121-180, dispatch forward.cu:110 /
+ * backprop.cu:137 - the reference routes the layer's forward through the conv backward routine and vice versa but never finished it, see
+ * csrc/dconv.hip).  I[N,H1,W1,C1] -> O[N,H0,W0,C0], F = T4(C1,K,K,C0), (H0-K+2P)/S+1 == H1:
+ *   O[n,i*S+ky-P,j*S+kx-P,co] = B[co] + sum_ci F[ci,ky,kx,co] * I[n,i,j,ci]        (= torch ConvTranspose2d, weight[ci][co][ky][kx]) */
+int t4k_dconv2d_fwd(const float *I, float *O, const float *F, const float *B,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t s);
+/* its backward: DX (overwritten) = conv(DO, F) with the same taps, DF += I x DO, DB[co] += sum DO (DF, DB only if train);
+ * DX == NULL or DF == DB == NULL as for t4k_conv2d_bwd */
+int t4k_dconv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, int train, t4k_stream_t s);
 /* k_pool<KS> nmath.tcu:122 (layer in AVGPOOL/MAXPOOL/MINPOOL/USAMPLE), KS in {2,3} */
 int t4k_pool(int layer, const float *I, float *O, int N, int H1, int W1, int H0, int W0, int C,
              int KS, t4k_stream_t s);

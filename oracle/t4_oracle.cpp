@@ -537,6 +537,51 @@ int t4o_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F,
     }
     return OK;
 }
+/* Transposed convolution layer (word `dconv2d`).  The reference allocates it (Model::_iconv txn, src/nn/model.cpp:121-180) and routes its
+ * forward to _bconv / its backward to _fconv (src/nn/forward.cu:110, backprop.cu:137) with the operands unswapped - code that never ran.
+ * The oracle states the finished layer by its definition (the scatter form of that dispatch, no tap flip):
+ *   O[n, i*S+ky-P, j*S+kx-P, co] = B[co] + sum_ci F[ci,ky,kx,co] * I[n,i,j,ci]          F = T4(C1,K,K,C0)
+ * pinned against torch.nn.functional.conv_transpose2d in tests/test_oracle_vs_torch.py. */
+int t4o_dconv2d_fwd(const float *I, float *O, const float *F, const float *B,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P) {
+    if (!conv_supported(K, S, P)) return ERR_UNSUPPORTED;
+    for (long z = 0; z < (long)N * H0 * W0; z++) for (int co = 0; co < C0; co++) O[z * C0 + co] = B[co];
+    for (int n = 0; n < N; n++) for (int i = 0; i < H1; i++) for (int j = 0; j < W1; j++)
+        for (int ky = 0; ky < K; ky++) for (int kx = 0; kx < K; kx++) {
+            const int y = i * S + ky - P, x = j * S + kx - P;
+            if (y < 0 || y >= H0 || x < 0 || x >= W0) continue;
+            const float *in = I + (((long)n * H1 + i) * W1 + j) * C1;
+            float *out = O + (((long)n * H0 + y) * W0 + x) * C0;
+            for (int ci = 0; ci < C1; ci++) {
+                const float v = in[ci]; const float *f = F + (((long)ci * K + ky) * K + kx) * C0;
+                for (int co = 0; co < C0; co++) out[co] += f[co] * v;
+            }
+        }
+    return OK;
+}
+int t4o_dconv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, int train) {
+    if (!conv_supported(K, S, P)) return ERR_UNSUPPORTED;
+    if (DX) memset(DX, 0, sizeof(float) * (size_t)N * H1 * W1 * C1);
+    for (int n = 0; n < N; n++) for (int i = 0; i < H1; i++) for (int j = 0; j < W1; j++)
+        for (int ky = 0; ky < K; ky++) for (int kx = 0; kx < K; kx++) {
+            const int y = i * S + ky - P, x = j * S + kx - P;
+            if (y < 0 || y >= H0 || x < 0 || x >= W0) continue;
+            const float *in = I + (((long)n * H1 + i) * W1 + j) * C1;
+            const float *go = DO + (((long)n * H0 + y) * W0 + x) * C0;
+            for (int ci = 0; ci < C1; ci++) {
+                const long fo = (((long)ci * K + ky) * K + kx) * C0;
+                float acc = 0.f;
+                for (int co = 0; co < C0; co++) {
+                    acc += F[fo + co] * go[co];
+                    if (train && DF) DF[fo + co] += in[ci] * go[co];
+                }
+                if (DX) DX[(((long)n * H1 + i) * W1 + j) * C1 + ci] += acc;
+            }
+        }
+    if (train && DB) for (long z = 0; z < (long)N * H0 * W0; z++) for (int co = 0; co < C0; co++) DB[co] += DO[z * C0 + co];
+    return OK;
+}
 /* k_pool<KS> src/nn/nmath.tcu:122-186.  The reference reads full KSxKS tiles with no bounds
  * check (UB for odd H/W, SURVEY a-15); the oracle defines the edge: out-of-range cells are skipped. */
 int t4o_pool(int layer, const float *I, float *O, int N, int H1, int W1, int H0, int W0, int C, int KS) {

@@ -66,6 +66,11 @@ int t4o_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F,
                    float *DF, float *DB,
                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, int train);
+/* transposed convolution layer (include/t4k.h t4k_dconv2d_fwd / _bwd): direct loops over the definition */
+int t4o_dconv2d_fwd(const float *I, float *O, const float *F, const float *B,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P);
+int t4o_dconv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, int train);
 int t4o_pool(int layer, const float *I, float *O, int N, int H1, int W1, int H0, int W0, int C, int KS);
 int t4o_dpool(int layer, float *I, const float *DY, int N, int H1, int W1, int H0, int W0, int C, int KS);
 int t4o_sgd(float *G, float *DG, float *M, int Nw, float lr, float beta, long n);

@@ -120,6 +120,13 @@ int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, f
     if (r) snprintf(g_err, sizeof(g_err), "nn#bconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
     return r;
 }
+int t4k_dconv2d_fwd(const float *I, float *O, const float *F, const float *B, int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t) {
+    return rc(t4o_dconv2d_fwd(I, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P), "nn#fdconv");
+}
+int t4k_dconv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB, int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                    int K, int S, int P, int tr, t4k_stream_t) {
+    return rc(t4o_dconv2d_bwd(I, DO, DX, F, DF, DB, N, H1, W1, C1, H0, W0, C0, K, S, P, tr), "nn#bdconv");
+}
 int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, const float *F, float *DF, float *DB, int N, int H1, int W1, int C1,
                     int H0, int W0, int C0, int K, int S, int P, int tr, t4k_stream_t st) {
     int r = t4k_conv2d_bwd(I, DO, DX, F, DF, DB, N, H1, W1, C1, H0, W0, C0, K, S, P, tr, st);

@@ -307,6 +307,9 @@ const float *Model::fstep(Tensor &in, Tensor &out, const float *x) {
     case T4K_L_CONV:
         chk(t4k_conv2d_fwd(x, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
                            out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], s), "nn#fconv"); break;
+    case T4K_L_DCONV:                                   // transposed convolution: the scatter form of the conv backward (forward.cu:110, see csrc/dconv.hip)
+        chk(t4k_dconv2d_fwd(x, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
+                            out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], s), "nn#fdconv"); break;
     case T4K_L_LINEAR:
         chk(t4k_linear_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.N(), (int)out.HWC(), (int)in.HWC(), s), "nn#flinear"); break;
     case T4K_L_FLATTEN: lazy_copy(x, out); return x;    // a copy in the reference (forward.cu:96); the next layer reads the source
@@ -550,6 +553,13 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
         lazy_copy(dx.data, in);                         // x = dX (overwrite), backprop.cu:185 - after dF has consumed x
         return dx.data;
     }
+    case T4K_L_DCONV: {                                 // backprop.cu:137: the conv forward routine gives dX; dF|dB read x first, then `in = dx`
+        Tensor &dx = *in.grad[4];
+        chk(t4k_dconv2d_bwd(in.data, dy, dx.data, in.grad[0]->data, train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr,
+                            in.N(), in.H(), in.W(), in.C(), out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], train, s), "nn#bdconv");
+        chk(t4k_copy(dx.data, in.data, (long)in.numel, s), "nn#bdconv in = dx");
+        return in.data;
+    }
     case T4K_L_LINEAR: {
         if (last) { lazy_copy(dy, in); return dy; }     // linear as the last layer: pass dY (backprop.cu:119-121)
         const int N = in.N(), E0 = (int)out.HWC(), E1 = (int)in.HWC();
@@ -673,7 +683,7 @@ int model_save(Model &m, const char *fname) {
     };
     for (int i = 0; i + 1 < L; i++) {
         Tensor &in = m.at(i); const int fn = in.grad_fn;
-        if ((fn == T4K_L_CONV || fn == T4K_L_LINEAR || fn == T4K_L_DCONV) && in.grad[0] && in.grad[1]) { if (fn != T4K_L_DCONV) { dump('w', LAYER_NAME[fn], *in.grad[0]); dump('b', LAYER_NAME[fn], *in.grad[1]); } }
+        if ((fn == T4K_L_CONV || fn == T4K_L_LINEAR || fn == T4K_L_DCONV) && in.grad[0] && in.grad[1]) { dump('w', LAYER_NAME[fn], *in.grad[0]); dump('b', LAYER_NAME[fn], *in.grad[1]); }   // (the reference skips dconv2d blobs, aio_model.cpp:170: a net it cannot run)
         else if (fn == T4K_L_BATCHNM && in.grad[0]) dump('w', LAYER_NAME[fn], *in.grad[0]);
     }
     fprintf(f, "\n---\n");
@@ -698,7 +708,7 @@ int model_load(Model &m, const char *fname) {
     const int L = (int)m.layer.size();
     for (int i = 0; i + 1 < L && !err; i++) {
         Tensor &in = m.at(i); const int fn = in.grad_fn;
-        if ((fn == T4K_L_CONV || fn == T4K_L_LINEAR) && in.grad[0] && in.grad[1]) { rd(*in.grad[0]); if (!err) rd(*in.grad[1]); }
+        if ((fn == T4K_L_CONV || fn == T4K_L_LINEAR || fn == T4K_L_DCONV) && in.grad[0] && in.grad[1]) { rd(*in.grad[0]); if (!err) rd(*in.grad[1]); }
         else if (fn == T4K_L_BATCHNM && in.grad[0]) rd(*in.grad[0]);
     }
     fclose(f);

@@ -890,3 +890,32 @@ def test_conv2d_many_channels_full_size_spot_checks(t4k, dev):
         want = float(np.sum(Ip[:, ky:ky + H, kx:kx + H, ci] * G[:, :, :, co].astype(np.float64)))
         assert abs(DF[ci, ky, kx, co] - want) <= 2e-4 * max(1.0, abs(want))            # 65536-term fp32 accumulation
     np.testing.assert_allclose(DB, G.astype(np.float64).sum(axis=(0, 1, 2)), rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("N,H1,C1,C0", [(6, 4, 12, 8), (2, 7, 3, 4), (4, 8, 64, 32), (3, 16, 8, 1), (2, 5, 32, 64)])
+def test_transposed_conv_layer(t4k, dev, oracle, N, H1, C1, C0):
+    """t4k_dconv2d_fwd / _bwd (word `dconv2d`: K=4, S=2, P=1, output padding for odd grids) against the oracle's direct-loop definition
+    (itself pinned to torch ConvTranspose2d in test_oracle_vs_torch.py): few-channel, many-channel (LDS-staged MFMA) and image-output
+    shapes; DX overwritten, DF / DB accumulated over two calls, the dX-only and dF-only forms."""
+    o = oracle.lib(); P = oracle.P
+    K, S, Pd = 4, 2, 1
+    H0 = (H1 - 1) * S - 2 * Pd + K + (H1 + 2 * Pd - K) % S
+    rng = np.random.default_rng(N * 100 + C0)
+    I = rng.standard_normal((N, H1, H1, C1)).astype(np.float32); F = (rng.standard_normal((C1, K, K, C0)) * 0.2).astype(np.float32)
+    B = rng.standard_normal(C0).astype(np.float32); G = rng.standard_normal((N, H0, H0, C0)).astype(np.float32)
+    O = np.zeros((N, H0, H0, C0), np.float32)
+    assert o.t4o_dconv2d_fwd(P(I), P(O), P(F), P(B), N, H1, H1, C1, H0, H0, C0, K, S, Pd) == 0
+    dI, dF, dB, dO, dG = dev.up(I), dev.up(F), dev.up(B), dev.zeros(O.shape), dev.up(G)
+    t4k.call("t4k_dconv2d_fwd", p(dI), p(dO), p(dF), p(dB), N, H1, H1, C1, H0, H0, C0, K, S, Pd, None)
+    assert rel(dev.down(dO), O) < RTOL
+    DX = np.zeros_like(I); DF = np.zeros_like(F); DB = np.zeros_like(B)
+    dDX, dDF, dDB = dev.up(np.full_like(I, 3.0)), dev.zeros(F.shape), dev.zeros(B.shape)
+    for rep in range(2):
+        assert o.t4o_dconv2d_bwd(P(I), P(G), P(DX), P(F), P(DF), P(DB), N, H1, H1, C1, H0, H0, C0, K, S, Pd, 1) == 0
+        t4k.call("t4k_dconv2d_bwd", p(dI), p(dG), p(dDX), p(dF), p(dDF), p(dDB), N, H1, H1, C1, H0, H0, C0, K, S, Pd, 1, None)
+        assert rel(dev.down(dDX), DX) < RTOL and rel(dev.down(dDF), DF) < RTOL and rel(dev.down(dDB), DB) < RTOL
+    dDX2 = dev.zeros(I.shape); t4k.call("t4k_dconv2d_bwd", p(dI), p(dG), p(dDX2), p(dF), None, None, N, H1, H1, C1, H0, H0, C0, K, S, Pd, 0, None)
+    assert np.array_equal(dev.down(dDX2), dev.down(dDX))
+    before = dev.down(dDF).copy(); t4k.call("t4k_dconv2d_bwd", p(dI), p(dG), None, p(dF), p(dDF), p(dDB), N, H1, H1, C1, H0, H0, C0, K, S, Pd, 0, None)
+    assert np.array_equal(dev.down(dDF), before)                                    # train == 0: parameter gradients untouched
+    assert t4k.lib.t4k_dconv2d_fwd(p(dI), p(dO), p(dF), p(dB), N, H1, H1, C1, H0 + 2, H0 + 2, C0, K, S, Pd, None) == -1   # inconsistent geometry is reported

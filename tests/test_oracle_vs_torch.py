@@ -213,3 +213,35 @@ def test_philox_stream_properties(oracle):
     kat = np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], np.uint64)
     exp = (kat.astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float32)
     assert np.allclose(d, exp, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("H1", [4, 7])                  # even: H0 = 2*H1; odd: the reference's output padding P0 = 1 gives H0 = 2*H1 + 1
+def test_transposed_conv_layer_is_torch_conv_transpose2d(oracle, H1):
+    """Word `dconv2d` (L_DCONV, K=4 S=2 P=1; allocation Model::_iconv txn, model.cpp:121-180).  The reference never finished the layer
+    (forward.cu:110 / backprop.cu:137 call the conv routines with the operands unswapped); the oracle states the finished one:
+    torch ConvTranspose2d with weight[ci][co][ky][kx] = F[ci,ky,kx,co] (+ output padding P0), gradients textbook, DF/DB accumulating."""
+    o = oracle.lib(); P_ = oracle.P
+    K, S, P = 4, 2, 1
+    rng = np.random.default_rng(H1)
+    N, C1, C0 = 2, 5, 3
+    P0 = (H1 + 2 * P - K) % S
+    H0 = (H1 - 1) * S - 2 * P + K + P0
+    I = rng.standard_normal((N, H1, H1, C1)).astype(np.float32)
+    F = rng.standard_normal((C1, K, K, C0)).astype(np.float32)
+    B = rng.standard_normal(C0).astype(np.float32)
+    O = np.zeros((N, H0, H0, C0), np.float32)
+    assert o.t4o_dconv2d_fwd(P_(I), P_(O), P_(F), P_(B), N, H1, H1, C1, H0, H0, C0, K, S, P) == 0
+    ti = torch.tensor(I).permute(0, 3, 1, 2).requires_grad_(True)
+    tw = torch.tensor(F).permute(0, 3, 1, 2).contiguous().requires_grad_(True)     # [C1, C0, K, K]
+    tb = torch.tensor(B).requires_grad_(True)
+    to = Fn.conv_transpose2d(ti, tw, tb, stride=S, padding=P, output_padding=P0)
+    assert tuple(to.shape[2:]) == (H0, H0)
+    assert rel(O, nhwc(to.detach())) < RTOL
+    dO = rng.standard_normal(O.shape).astype(np.float32)
+    to.backward(torch.tensor(dO).permute(0, 3, 1, 2))
+    DX = np.full_like(I, 7.0); DF = np.zeros_like(F); DB = np.zeros_like(B)          # DX is overwritten, DF / DB accumulate
+    for rep in (1, 2):
+        assert o.t4o_dconv2d_bwd(P_(I), P_(dO), P_(DX), P_(F), P_(DF), P_(DB), N, H1, H1, C1, H0, H0, C0, K, S, P, 1) == 0
+        assert rel(DX, nhwc(ti.grad)) < RTOL
+        assert rel(DF, rep * tw.grad.permute(0, 2, 3, 1).numpy()) < RTOL
+        assert rel(DB, rep * tb.grad.numpy()) < RTOL
