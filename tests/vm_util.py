@@ -80,4 +80,7 @@ def synth_mnist_dir(tmp_path_factory):
     d = tmp_path_factory.mktemp("t4data")
     subprocess.run(["python3", os.path.join(ROOT, "tools", "make_synth_mnist.py"), os.path.join(str(d), "data", "MNIST", "raw"), "1024", "256"],
                    check=True, capture_output=True)
+    # ... and ./data/CIFAR10/cifar-10-batches-bin with the synthetic CIFAR-10-shaped batches (seed 7 / 8)
+    subprocess.run(["python3", os.path.join(ROOT, "tools", "make_synth_cifar.py"), os.path.join(str(d), "data", "CIFAR10", "cifar-10-batches-bin"), "256", "64"],
+                   check=True, capture_output=True)
     return str(d)
