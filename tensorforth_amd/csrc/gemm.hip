@@ -959,7 +959,8 @@ bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEM
 // shapes belong to the other kernels (interior tiles -> LDS-DMA kernels, deep K -> split-K, large -> 128x128 tiles)
 bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, hipStream_t hs) {
     State &g = st();
-    if (!dual_on() || !g.d_sync || (E0 & 3) || (E1 & 3) || !aligned16(DY) || !aligned16(X) || !aligned16(W) || N < 1) return false;
+    int *gate = gate_for(hs, 1);                             // nullptr: unknown stream, the two GEMMs go out as separate launches
+    if (!dual_on() || !g.d_sync || !gate || (E0 & 3) || (E1 & 3) || !aligned16(DY) || !aligned16(X) || !aligned16(W) || N < 1) return false;
     const int cu = g.cu_count;
     auto tiles = [](int m, int n) { return (long)((m + 63) / 64) * ((n + 63) / 64); };
     auto big = [&](int m, int n) { return (long)((m + 127) / 128) * ((n + 127) / 128) >= (long)cu * 3 / 4; };
@@ -985,7 +986,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     auto kern = k_gemm_dual<false, false, true, false>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(t1 + riders + t2)), dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate_for(hs, 1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(t1 + riders + t2)), dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate);
     return true;
 }
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,
@@ -1026,7 +1027,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     // pair mode (variant bit 3): an interior 64x64-tiled problem that gives each CU at most one workgroup is split in
     // two K halves combined in the epilogue => 2 workgroups (8 waves) per CU hide each other's LDS / barrier stalls
     p.pair = 0; p.sync = st().d_sync;
-    if (!big && vec && nsplit == 1 && C == 1 && (var & 4) && (var & 8) && p.sync && tiles <= st().cu_count && tiles <= 2048 &&
+    if (!big && vec && nsplit == 1 && C == 1 && (var & 4) && (var & 8) && p.sync && lane_of(S(s)) == 0 && tiles <= st().cu_count && tiles <= 2048 &&   // tickets are per tile, not per stream: default stream only
         M % 64 == 0 && N % 64 == 0 && K % 128 == 0 && K >= 256 && (size_t)tiles * 4096 * sizeof(float) <= st().ws_bytes / 2) {
         p.pair = 1; nsplit = 2; kchunk = K / 2;
     }

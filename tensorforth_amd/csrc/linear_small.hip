@@ -265,13 +265,15 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     const bool alias = DX && nB > 0 && (const float *)DX == X;
     if (TGT && !alias) return false;                                       // the in-place `out -= target` needs the arrival counters
     State &g = st();
-    if (alias && (nA + nB > g.cu_count || !g.d_sync)) return false;       // the arrival counter needs every workgroup resident
+    static int gate_on = -1; if (gate_on < 0) { const char *e = getenv("T4K_LINSMALL_GATE"); gate_on = e ? atoi(e) : 1; }
+    int *gate = gate_for(hs, 0);                                           // nullptr: a stream the library does not know -> no private counters
+    if (alias && (nA + nB > g.cu_count || !g.d_sync || !gate || !gate_on)) return false;   // the arrival counter needs every workgroup resident
     size_t lds = sizeof(float) * (size_t)(E0 * E1 + RA * E0);
     if (nB > 0 && sizeof(float) * (size_t)(N + 768) > lds) lds = sizeof(float) * (size_t)(N + 768);
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate_for(hs, 0), alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2);
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate ? gate : g.d_sync, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2);
     return true;
 }
 

@@ -48,14 +48,25 @@ inline hipStream_t S(t4k_stream_t s) { return s ? (hipStream_t)s : st().stream; 
 // workspace of the stream a kernel is launched on: work forked to a side stream must not share partial slabs
 // arrival gates of the one-launch producer/consumer kernels (self re-arming ints, zero between launches): one block of 64
 // ints per stream (kernels on different streams may overlap), `slot` picks 4 ints inside it
-inline int *gate_for(const void *s, int slot) {
+// Returns nullptr for a stream the library does not know (neither its default stream nor one made by t4k_stream_create, e.g. a caller's
+// own hipStream_t): such launches could run beside a gated launch of the default stream and must not share its counters - the callers
+// then take their ungated path (separate launches).  Launches on ONE stream are ordered, so a lane's gates are never used concurrently.
+// Co-residency: the gated kernels spin until every workgroup of the launch has arrived, which needs all of them resident at once; the
+// launchers only take the gated path for grids <= the CU count of an exclusively owned device (one process per GPU) - on a
+// partitioned or shared device set T4K_GEMM_DUAL=0 / T4K_LINSMALL_GATE=0.
+inline int lane_of(const void *s) {                      // 0 = default stream, i+1 = library stream i, -1 = unknown
     State &g = st();
-    int li = 0;
-    if (s) for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) { li = i + 1; break; }
-    return g.d_sync + 8192 + li * 2048 + slot * 4;
+    if (!s || s == (const void *)g.stream) return 0;
+    for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) return i + 1;
+    return -1;
+}
+inline int *gate_for(const void *s, int slot) {
+    const int li = lane_of(s);
+    if (li < 0) return nullptr;
+    return st().d_sync + 8192 + li * 2048 + slot * 4;
 }
 // 16 broadcast flags of the same stream, one per 64-byte line (hundreds of waiting workgroups poll these instead of the counter)
-inline int *flags_for(const void *s) { return gate_for(s, 0) + 1024; }
+inline int *flags_for(const void *s) { int *g0 = gate_for(s, 0); return g0 ? g0 + 1024 : nullptr; }
 inline float *ws_for(const void *s) {            // accepts a t4k_stream_t or an already resolved hipStream_t
     State &g = st();
     if (s) for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) return (float *)g.lane[i].ws;

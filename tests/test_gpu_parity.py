@@ -919,3 +919,42 @@ def test_transposed_conv_layer(t4k, dev, oracle, N, H1, C1, C0):
     before = dev.down(dDF).copy(); t4k.call("t4k_dconv2d_bwd", p(dI), p(dG), None, p(dF), p(dDF), p(dDB), N, H1, H1, C1, H0, H0, C0, K, S, Pd, 0, None)
     assert np.array_equal(dev.down(dDF), before)                                    # train == 0: parameter gradients untouched
     assert t4k.lib.t4k_dconv2d_fwd(p(dI), p(dO), p(dF), p(dB), N, H1, H1, C1, H0 + 2, H0 + 2, C0, K, S, Pd, None) == -1   # inconsistent geometry is reported
+
+
+@pytest.mark.parametrize("N,E0,E1", [(128, 100, 980), (128, 10, 100)])     # dW || dX dual launch with an arrival gate; small head with arrival counters
+def test_gated_linear_backward_on_concurrent_streams(t4k, dev, oracle, N, E0, E1):
+    """the one-launch producer / consumer kernels synchronise through counters in library memory.  Three streams run the
+    in-place linear backward (dX lands in X's buffer) at the same time on different data: the library's default stream and a
+    t4k_stream_create()d one have private counters, a stream the library does not know (torch's) must fall back to ungated launches."""
+    torch = dev.torch
+    o = oracle.lib(); P = oracle.P
+    s_lib = ctypes.c_void_p(); t4k.call("t4k_stream_create", ctypes.byref(s_lib))
+    s_ext = torch.cuda.Stream()
+    streams = [None, s_lib, ctypes.c_void_p(s_ext.cuda_stream)]
+    rng = np.random.default_rng(E1)
+    W = (rng.standard_normal((E0, E1)) * 0.1).astype(np.float32); dW_ = dev.up(W)
+    jobs = []
+    for k, s in enumerate(streams):
+        X = rng.standard_normal((N, E1)).astype(np.float32); DY = rng.standard_normal((N, E0)).astype(np.float32)
+        DX = np.zeros_like(X); DW = np.zeros_like(W); DB = np.zeros(E0, np.float32)
+        o.t4o_linear_bwd(P(X), P(W), P(DY), P(DX), P(DW), P(DB), N, E0, E1, 1)
+        jobs.append(dict(s=s, X0=dev.up(X), X=dev.zeros(X.shape), DY=dev.up(DY), DW=dev.zeros(W.shape), DB=dev.zeros(E0), ref=(DX, DW, DB)))
+    torch.cuda.synchronize()
+    REPS = 30
+    try:
+        for it in range(REPS):
+            for j in jobs:                                    # interleaved issue: the three streams overlap on the device
+                t4k.call("t4k_copy", p(j["X0"]), p(j["X"]), N * E1, j["s"])
+                if it == REPS - 1:
+                    t4k.call("t4k_memset", p(j["DW"]), 0, 4 * E0 * E1, j["s"]); t4k.call("t4k_memset", p(j["DB"]), 0, 4 * E0, j["s"])
+                t4k.call("t4k_linear_bwd", p(j["X"]), p(dW_), p(j["DY"]), p(j["X"]), p(j["DW"]), p(j["DB"]), N, E0, E1, 1, j["s"])
+        for j in jobs:
+            t4k.call("t4k_sync", j["s"])
+        torch.cuda.synchronize()
+        for k, j in enumerate(jobs):
+            DX, DW, DB = j["ref"]
+            assert rel(j["X"].cpu().numpy(), DX) < RTOL, "dX stream %d" % k
+            assert rel(j["DW"].cpu().numpy(), DW) < RTOL, "dW stream %d" % k
+            assert rel(j["DB"].cpu().numpy(), DB) < RTOL, "dB stream %d" % k
+    finally:
+        t4k.call("t4k_stream_destroy", s_lib)
