@@ -103,6 +103,10 @@ int t4k_comm_world(void);                          /* 0 = no communicator */
 int t4k_comm_rank(void);
 int t4k_allreduce_sum(float *buf, long n, t4k_stream_t s);
 int t4k_comm_destroy(void);
+/* Batch-norm statistics over the WHOLE batch (all ranks) instead of the rank's shard: off by default.  When on, every
+ * t4k_batchnorm_fwd / _bwd issues one [2C] all-reduce, so EVERY rank must make the same batch-norm calls in the same order - the host
+ * switches it on for training passes only (an evaluation pass that only some ranks run would hang in the collective). */
+int t4k_comm_sync_batchnorm(int on);
 
 /* hipGraph capture of a launch sequence (replaces ~40 launch+sync pairs per training
  * step of the reference).  begin..end captures every t4k_* kernel call

@@ -50,6 +50,7 @@ int t4k_comm_world(void) { return 0; }
 int t4k_comm_rank(void) { return 0; }
 int t4k_allreduce_sum(float *, long, t4k_stream_t) { return T4K_OK; }
 int t4k_comm_destroy(void) { return T4K_OK; }
+int t4k_comm_sync_batchnorm(int) { return T4K_OK; }
 int t4k_graph_begin(t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
 int t4k_graph_end(t4k_stream_t, t4k_graph_t *) { return T4K_ERR_UNSUPPORTED; }
 int t4k_graph_launch(t4k_graph_t, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }

@@ -77,10 +77,11 @@ int t4k_allreduce_sum(float *buf, long n, t4k_stream_t s) {
     if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
     return T4K_OK;
 }
+int t4k_comm_sync_batchnorm(int on) { st().bn_sync = on != 0; return T4K_OK; }
 int t4k_comm_destroy(void) {
     if (R.comm && R.CommDestroy) { (void)hipDeviceSynchronize(); R.CommDestroy(R.comm); }
     R.comm = nullptr; R.world = 0; R.rank = 0;
-    st().shard_rank = 0; st().shard_world = 1;
+    st().shard_rank = 0; st().shard_world = 1; st().bn_sync = false;
     return T4K_OK;
 }
 

@@ -349,7 +349,7 @@ int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const
                       float *stat, int N, int HW, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_fwd: shape");
     const long NHW = (long)N * HW, total = NHW * C;
-    if (t4k_comm_world() > 0) {                          // data parallel: statistics over every rank's shard
+    if (st().bn_sync && t4k_comm_world() > 0) {          // data parallel (opt-in, t4k_comm_sync_batchnorm): statistics over every rank's shard
         int rc = bn_stats_sync<0>(I, nullptr, stat, nullptr, nullptr, NHW, C, 0, s); if (rc != T4K_OK) return rc;
     } else if (NHW >= 2048) {                            // image-sized: chunked coalesced column sums + per-channel fold
         long nch = (NHW + 255) / 256; if (nch > 2048) nch = 2048;
@@ -366,7 +366,7 @@ int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *D
                       float *DW, float *DB, float *stat, int N, int HW, int C, int train, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_bwd: shape");
     const long NHW = (long)N * HW, total = NHW * C;
-    if (t4k_comm_world() > 0) {
+    if (st().bn_sync && t4k_comm_world() > 0) {
         int rc = bn_stats_sync<1>(DY, XH, stat, DW, DB, NHW, C, train, s); if (rc != T4K_OK) return rc;
     } else if (NHW >= 2048) {
         long nch = (NHW + 255) / 256; if (nch > 2048) nch = 2048;

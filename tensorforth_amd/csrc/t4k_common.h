@@ -30,6 +30,7 @@ struct State {
     // data-parallel shard (t4k_rand_set_shard): a SAMPLE-KEYED draw (dropout masks) of nq counters takes the slice
     // [ctr + rank*nq, ctr + (rank+1)*nq) and moves the stream by world*nq - the draw the rank's samples would get inside the whole batch
     int         shard_rank = 0, shard_world = 1;
+    bool        bn_sync = false;       // batchnorm statistics over all ranks (t4k_comm_sync_batchnorm; needs a communicator)
     bool        capturing = false;
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;

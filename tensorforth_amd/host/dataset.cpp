@@ -31,17 +31,17 @@ bool Corpus::init(int batch) {
     N = batch; eof = false; batch_sz = 0;
     if (fd) { fclose(fd); fd = nullptr; } if (fl) { fclose(fl); fl = nullptr; }
     fd = fopen(f_data.c_str(), "rb");
-    if (!fd) { printf("failed to open file %s\n", f_data.c_str()); return false; }
+    if (!fd) { hprintf("failed to open file %s\n", f_data.c_str()); return false; }
     if (cifar) {                                         // 1 label byte + 3x32x32 planar bytes per sample
         H = W = 32; C = 3;
         fseek(fd, 0, SEEK_END); corpus_sz = (int)(ftell(fd) / 3073); fseek(fd, 0, SEEK_SET);
         return true;
     }
     fl = fopen(f_label.c_str(), "rb");
-    if (!fl) { printf("failed to open file %s\n", f_label.c_str()); return false; }
+    if (!fl) { hprintf("failed to open file %s\n", f_label.c_str()); return false; }
     be32(fl); const uint32_t n1 = be32(fl);              // label magic 0x0801, count
     be32(fd); const uint32_t n = be32(fd); H = be32(fd); W = be32(fd); C = 1;   // image magic 0x0803
-    if (n != n1) { printf("Mnist::init label count %d != image count %d\n", n1, n); return false; }
+    if (n != n1) { hprintf("Mnist::init label count %d != image count %d\n", n1, n); return false; }
     corpus_sz = n;
     return true;
 }
@@ -92,14 +92,14 @@ int Corpus::read_into(int bid, int slot) {               // returns the number o
         const size_t nl = fread(l8.data(), 1, N, fl);
         fseek(fd, 16 + off * (long)cell, SEEK_SET);
         n = fread(data, 1, (size_t)N * cell, fd) / cell;
-        if (nl != n) { printf("Mnist::fetch #label=%d != #image=%d\n", (int)nl, (int)n); return 0; }
+        if (nl != n) { hprintf("Mnist::fetch #label=%d != #image=%d\n", (int)nl, (int)n); return 0; }
         for (size_t i = 0; i < n; i++) label[i] = l8[i];
     }
     return (int)n;
 }
 bool Corpus::fetch(int bid) {
     const long off = (long)N * bid;
-    if (eof || off >= corpus_sz) { printf("%s::fetch EOF reached (needs rewind)\n", cifar ? "Cifar10" : "Mnist"); eof = true; return false; }
+    if (eof || off >= corpus_sz) { hprintf("%s::fetch EOF reached (needs rewind)\n", cifar ? "Cifar10" : "Mnist"); eof = true; return false; }
     const size_t cell = (size_t)H * W * C;
     for (int s = 0; s < 2; s++) {
         if (!pix[s]) { void *p; t4k_host_alloc(&p, (size_t)N * cell); pix[s] = (uint8_t *)p; t4k_host_alloc(&p, sizeof(uint32_t) * N); lab[s] = (uint32_t *)p; t4k_event_create(&copied[s]); }
@@ -128,17 +128,17 @@ bool Corpus::fetch(int bid) {
 int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     if (ds_name) {
         auto it = corpora().find(ds_name);
-        if (it == corpora().end()) { printf("  } dataset#fetch => not found in Loader\n"); return -1; }
+        if (it == corpora().end()) { hprintf("  } dataset#fetch => not found in Loader\n"); return -1; }
         cp = it->second;
-        if (!cp->init(N())) { printf("  } dataset#fetch => corpus init failed!\n"); return -2; }
+        if (!cp->init(N())) { hprintf("  } dataset#fetch => corpus init failed!\n"); return -2; }
         dataset_size = cp->corpus_sz;
         numel = (uint64_t)cp->N * cp->H * cp->W * cp->C;
         rank = 4; shape[0] = cp->H; shape[1] = cp->W; shape[2] = cp->C; shape[3] = cp->N;
     }
-    if (!cp) { printf("  } dataset#fetch => not found in Loader\n"); return -1; }
+    if (!cp) { hprintf("  } dataset#fetch => not found in Loader\n"); return -1; }
     if (rewind) { cp->rewind(); batch_id = done = 0; }
     die_if_no_backend();
-    if (!cp->fetch(batch_id)) { printf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
+    if (!cp->fetch(batch_id)) { hprintf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
     const int n = batch_sz = cp->batch_sz;
     done = cp->eof;
     die_if_no_backend();

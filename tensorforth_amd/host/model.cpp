@@ -7,7 +7,7 @@
 
 namespace t4 {
 
-#define NLOG(...) do { if (trace && *trace) printf(__VA_ARGS__); } while (0)
+#define NLOG(...) do { if (trace && *trace) hprintf(__VA_ARGS__); } while (0)
 
 Tensor &Model::T4(uint32_t n, uint32_t h, uint32_t w, uint32_t c) { return Store::get().tensor(n, h, w, c); }
 Tensor &Model::VEC(uint64_t n) { return Store::get().tensor(n); }
@@ -31,7 +31,7 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
         if (txn) { const uint16_t P0 = (H1 + P * 2 - K) % S; H0 = (H1 - 1) * S - P * 2 + K + P0; W0 = (W1 - 1) * S - P * 2 + K + P0; }
         else     { H0 = (H1 - K + P * 2) / S + 1; W0 = (H1 - K + P * 2) / S + 1; }      // W0 from H1: reference quirk :137
         if ((!txn && K != 1 && K != 3 && K != 5) || (txn && K != 4)) {
-            printf("nn#iconv %s f=[%d,%d]? 1x1, 3x3, 4x4, and 5x5 supported only.\n", LAYER_NAME[fn], K, K);
+            hprintf("nn#iconv %s f=[%d,%d]? 1x1, 3x3, 4x4, and 5x5 supported only.\n", LAYER_NAME[fn], K, K);
             return *this;
         }
         in.stride[0] = in.stride[1] = S; in.stride[2] = in.stride[3] = P; in.xparm = bias;
@@ -49,7 +49,7 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
         Tensor *b = in.grad[1] = &VEC(E0);
         in.grad[2] = &T4(1, E0, (uint32_t)E1, 1).zeros();
         in.grad[3] = &VEC(E0).zeros();
-        if (in.W() != E1) printf("    WARN linear: treats in[%d,%d,%d,%d] as [%d,1,%ld,1]\n", N1, in.H(), in.W(), in.C(), N1, (long)E1);
+        if (in.W() != E1) hprintf("    WARN linear: treats in[%d,%d,%d,%d] as [%d,1,%ld,1]\n", N1, in.H(), in.W(), in.C(), N1, (long)E1);
         in.xparm = bias;
         RAND(*w, sqrtf(1.0f / (E0 + E1))); RAND(*b, bias);
         layer.push_back(&T4(N1, 1, E0, 1));
@@ -63,7 +63,7 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
         layer.push_back(&T4(in.N(), in.H(), in.W(), in.C())); break;
     case T4K_L_AVGPOOL: case T4K_L_MAXPOOL: case T4K_L_MINPOOL: {    // _ipool model.cpp:260-274 (ceil dims)
         const uint16_t k = (uint16_t)n;
-        if (k != 2 && k != 3) { printf("nn#ipool k=%dx%d? 2x2 and 3x3 supported only\n", k, k); return *this; }
+        if (k != 2 && k != 3) { hprintf("nn#ipool k=%dx%d? 2x2 and 3x3 supported only\n", k, k); return *this; }
         in.stride[0] = k; in.stride[1] = 1; in.stride[2] = 1; in.stride[3] = 0;
         layer.push_back(&T4(in.N(), (in.H() + k - 1) / k, (in.W() + k - 1) / k, in.C()));
     } break;
@@ -78,12 +78,12 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
     } break;
     case T4K_L_USAMPLE: {                               // _iup model.cpp:294-310
         const uint16_t k = (uint16_t)n;
-        if (k != 2 && k != 3) { printf("nn#iup k=%dx%d? only 2x2 and 3x3 supported\n", k, k); return *this; }
+        if (k != 2 && k != 3) { hprintf("nn#iup k=%dx%d? only 2x2 and 3x3 supported\n", k, k); return *this; }
         in.iparm = (int)bias;
         in.stride[0] = k; in.stride[1] = 1; in.stride[2] = 1; in.stride[3] = 1;
         layer.push_back(&T4(in.N(), in.H() * k, in.W() * k, in.C()));
     } break;
-    default: printf("Model#add layer %d not supported\n", fn); return *this;
+    default: hprintf("Model#add layer %d not supported\n", fn); return *this;
     }
     in.grad_fn = fn;
     invalidate();
@@ -212,7 +212,7 @@ void Model::end_capture(GraphSlot &slot, bool capturing) {
 Model &Model::forward(Tensor &input) {
     Tensor &n0 = at(0);
     if (input.numel != n0.numel) {
-        printf("nn#forward dataset wrong shape[%d,%d,%d,%d] != model input[%d,%d,%d,%d]\n",
+        hprintf("nn#forward dataset wrong shape[%d,%d,%d,%d] != model input[%d,%d,%d,%d]\n",
                input.N(), input.H(), input.W(), input.C(), n0.N(), n0.H(), n0.W(), n0.C());
         return *this;
     }
@@ -227,7 +227,14 @@ Model &Model::forward(Tensor &input) {
     NLOG("\n} Model::forward\n");
     return *this;
 }
+// data parallel: batch-norm statistics span all ranks during TRAINING passes only (every rank runs those in lock step); an
+// evaluation pass (`0 trainable`, possibly on one rank only) uses the rank's own statistics and issues no collective
+static void dp_bn_mode(bool train) {
+    static const bool want = getenv("T4_DP_SYNC_BN") ? atoi(getenv("T4_DP_SYNC_BN")) != 0 : true;
+    if (t4k_comm_world() > 0) t4k_comm_sync_batchnorm(train && want);
+}
 void Model::run_forward(Tensor &input) {
+    dp_bn_mode(train);
     const int L = (int)layer.size();
     Tensor &n0 = at(0);
     const bool fused = use_fusion && !(trace && *trace) && !concurrent();
@@ -245,7 +252,7 @@ void Model::run_forward(Tensor &input) {
     for (int i = 0; i + 1 < L; i++) {
         Tensor &in = at(i), &out = at(i + 1);
         if (trace && *trace)
-            printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
+            hprintf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.sum() / in.N() / in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
         if (masks && in.grad_fn == T4K_L_DROPOUT) { join(); masks = false; }
         if (fused && run_of_[i] >= 0) {                 // one launch for the whole element-wise run
@@ -294,7 +301,7 @@ void Model::run_forward(Tensor &input) {
             continue;
         }
         x = fstep(in, out, x);
-        if (trace && *trace && out.has_nan()) { printf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+        if (trace && *trace && out.has_nan()) { hprintf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
     }
     join();
 }
@@ -335,7 +342,7 @@ const float *Model::fstep(Tensor &in, Tensor &out, const float *x) {
                               out.N(), out.H() * out.W(), out.C(), s), "nn#fbatchnorm"); break;
     case T4K_L_USAMPLE:                                 // nearest: broadcast each cell to a kxk tile
         chk(t4k_dpool(T4K_L_USAMPLE, out.data, x, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#fupsample"); break;
-    default: printf("nn#fstep layer=%d not supported\n", fn);
+    default: hprintf("nn#fstep layer=%d not supported\n", fn);
     }
     return out.data;
 }
@@ -343,14 +350,14 @@ const float *Model::fstep(Tensor &in, Tensor &out, const float *x) {
 // ---------------------------------------------------------------- one-hot / hit / loss
 Tensor &Model::onehot() {
     if (hot) return *hot;
-    printf("Model.onehot not provided by dataset, use nn.onehot= to setup!\n");
+    hprintf("Model.onehot not provided by dataset, use nn.onehot= to setup!\n");
     return at(-1);
 }
 Tensor &Model::onehot(Tensor &t) {
     Tensor &out = at(-1);
     const uint32_t N = out.N(), E = (uint32_t)out.HWC();
-    if (hot) { printf("WARN: Model.onehot exists, replaced\n"); Store::get().free(*hot); }
-    else if (t.N() != N || (uint32_t)t.HWC() != E) { printf("Model.onehot dimension is not [%d,1,%d,1]\n", N, E); return t; }
+    if (hot) { hprintf("WARN: Model.onehot exists, replaced\n"); Store::get().free(*hot); }
+    else if (t.N() != N || (uint32_t)t.HWC() != E) { hprintf("Model.onehot dimension is not [%d,1,%d,1]\n", N, E); return t; }
     hot = &t; hit_ = hit(true);
     return *hot;
 }
@@ -392,7 +399,7 @@ DU Model::loss(Loss op) { return hot ? loss(op, *hot) : 0.0f; }
 DU Model::loss(Loss op, Tensor &tgt) {                  // loss.cpp:119-136: non-destructive (works on a copy)
     Tensor &out = at(-1);
     if (out.numel != tgt.numel) {
-        printf("nn::loss model output shape[%d,%d,%d,%d] != tgt[%d,%d,%d,%d]\n", out.N(), out.H(), out.W(), out.C(), tgt.N(), tgt.H(), tgt.W(), tgt.C());
+        hprintf("nn::loss model output shape[%d,%d,%d,%d] != tgt[%d,%d,%d,%d]\n", out.N(), out.H(), out.W(), out.C(), tgt.N(), tgt.H(), tgt.W(), tgt.C());
         return 0;
     }
     if (loss_t) *loss_t = out; else loss_t = &Store::get().copy(out);
@@ -413,13 +420,13 @@ Model &Model::broadcast(Tensor &tgt) {                  // backprop.cu:17-29: [N
 }
 Model &Model::backprop() {
     if (hot) return backprop(*hot);
-    printf("nn#backprop missing onehot vector?\n");
+    hprintf("nn#backprop missing onehot vector?\n");
     return *this;
 }
 Model &Model::backprop(Tensor &tgt) {
     Tensor &out = at(-1);
     if (out.numel != tgt.numel) {                       // _bprep backprop.cu:75-109
-        printf("Model#bprep: Onehot wrong shape[%d,%d,%d,%d] != [%d,%d,%d,%d], numel=%ld,%ld ", tgt.N(), tgt.H(), tgt.W(), tgt.C(),
+        hprintf("Model#bprep: Onehot wrong shape[%d,%d,%d,%d] != [%d,%d,%d,%d], numel=%ld,%ld ", tgt.N(), tgt.H(), tgt.W(), tgt.C(),
                out.N(), out.H(), out.W(), out.C(), (long)tgt.numel, (long)out.numel);
         return *this;
     }
@@ -485,6 +492,7 @@ void Model::dp_finish() {                                // before the update: r
     dp_done_lo_ = dp_pend_lo_ = -1; dp_mixed_ = false;
 }
 void Model::run_backward(Tensor &tgt) {
+    dp_bn_mode(train);
     dp_begin_backward();
     Tensor &out = at(-1);
     t4k_stream_t s = stream();
@@ -505,7 +513,7 @@ void Model::run_backward(Tensor &tgt) {
     for (int i = (int)layer.size() - 2 - skip, j = skip; i >= 0; i--, j++) {
         Tensor &in = at(i), &o = at(i + 1);
         if (trace && *trace)
-            printf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
+            hprintf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.xparm, o.sum() / o.N() / o.C(), o.N(), o.H(), o.W(), o.C());
         if (fused && j > 0) {                           // does a fused run END at op i?
             int rf = -1;
@@ -527,7 +535,7 @@ void Model::run_backward(Tensor &tgt) {
             continue;
         }
         grads_ready(i, in);
-        if (trace && *trace && in.has_nan()) { printf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+        if (trace && *trace && in.has_nan()) { hprintf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
     }
     join();
 }
@@ -602,7 +610,7 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
     case T4K_L_USAMPLE:                                 // gradient of nearest upsampling = sum over the tile = k*k * avgpool
         chk(t4k_pool(T4K_L_AVGPOOL, dy, in.data, in.N(), out.H(), out.W(), in.H(), in.W(), in.C(), in.stride[0], s), "nn#bupsample");
         in.map(T4K_SCALE, (DU)(in.stride[0] * in.stride[0])); break;
-    default: printf("nn#bstep layer=%d not supported\n", fn);
+    default: hprintf("nn#bstep layer=%d not supported\n", fn);
     }
     return in.data;
 }
@@ -672,7 +680,7 @@ Model &Model::adamw(DU lr, DU wd, DU b1, DU b2) { return gradient("adamw", OPTI_
 // layer order (the reference's own reload of the layer section is unfinished: `_parm` text is not Forth source).
 int model_save(Model &m, const char *fname) {
     FILE *f = fopen(fname, "wb");
-    if (!f) { printf("} => failed to open for output\n"); return 1; }
+    if (!f) { hprintf("} => failed to open for output\n"); return 1; }
     fprintf(f, "\\ tensorForth v4.0 model\n");
     const int L = (int)m.layer.size();
     for (int i = 0; i + 1 < L; i++) { Tensor &in = m.at(i), &out = m.at(i + 1); fprintf(f, "%s%s\n", fmt_parm(in, out).c_str(), LAYER_NAME[in.grad_fn]); }
@@ -692,17 +700,21 @@ int model_save(Model &m, const char *fname) {
 }
 int model_load(Model &m, const char *fname) {
     FILE *f = fopen(fname, "rb");
-    if (!f) { printf("} => failed to open for input\n"); return 1; }
+    if (!f) { hprintf("} => failed to open for input\n"); return 1; }
     auto getline_ = [&](std::string &line) { line.clear(); int c; bool any = false; while ((c = fgetc(f)) != EOF) { any = true; if (c == '\n') break; line.push_back((char)c); } return any; };
     std::string line;
+    if (m.layer.size() <= 1) {                           // nothing to load into: the reference would rebuild the layers by replaying the file's
+        hprintf(" model load: no layers - build the network first (the layer section of a .t4 file is not replayed)\n");   // layer section as Forth source
+        fclose(f); return 2;                             // (aio_model.cpp:183-204, unfinished there: it ends with an undefined word)
+    }
     while (getline_(line) && line.length()) {}           // skip the layer section (model already built)
     std::vector<float> h;
     int err = 0;
     auto rd = [&](Tensor &t) {
         while (getline_(line) && !line.length()) {}      // skip blank lines
-        if (line.size() < 3 || line[0] != '-' || line[1] != '-' || line[2] != '-') { printf(" model format error\n"); err = 1; return; }
+        if (line.size() < 3 || line[0] != '-' || line[1] != '-' || line[2] != '-') { hprintf(" model format error\n"); err = 1; return; }
         h.resize(t.numel);
-        if (fread(h.data(), sizeof(float), t.numel, f) != t.numel) { printf(" model format error (short read)\n"); err = 1; return; }
+        if (fread(h.data(), sizeof(float), t.numel, f) != t.numel) { hprintf(" model format error (short read)\n"); err = 1; return; }
         t.from_host(h.data(), t.numel);
     };
     const int L = (int)m.layer.size();
@@ -710,6 +722,10 @@ int model_load(Model &m, const char *fname) {
         Tensor &in = m.at(i); const int fn = in.grad_fn;
         if ((fn == T4K_L_CONV || fn == T4K_L_LINEAR || fn == T4K_L_DCONV) && in.grad[0] && in.grad[1]) { rd(*in.grad[0]); if (!err) rd(*in.grad[1]); }
         else if (fn == T4K_L_BATCHNM && in.grad[0]) rd(*in.grad[0]);
+    }
+    if (!err) {                                          // the blob list must end here: a closing `---` line and nothing else
+        while (getline_(line) && !line.length()) {}
+        if (line != "---") { hprintf(" model format error (layers of the file and of the model differ)\n"); err = 1; }
     }
     fclose(f);
     return err;

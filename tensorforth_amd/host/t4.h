@@ -38,6 +38,10 @@ extern const char *LAYER_NAME[];     // 7-char names, src/nn/ntypes.h:47-51
 
 void die_if_no_backend();            // lazily t4k_init(); prints and exits when no gfx950 device
 int  chk(int rc, const char *what);  // prints t4k_last_error() on failure (print-and-continue)
+// Host-layer diagnostics (model / tensor / dataset messages): printed through the VM's output buffer when a VM is attached, so that
+// embedded users (ten4_eval / ten4_output, vm.py) see them and they stay in order with the text the words print; stdout otherwise.
+void hprintf(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void set_host_sink(void (*fn)(const char *text, void *user), void *user);
 t4k_stream_t stream();
 
 // ---------------------------------------------------------------- HBM arena

@@ -3,6 +3,7 @@
 // their quirks (std() = sqrt(sum)/numel, SCALAR() LSB clearing, small-sum host loop); every
 // device operation goes through the t4k_* C-ABI.
 #include "t4.h"
+#include <stdarg.h>
 #include <stdlib.h>
 #include <time.h>
 #include <algorithm>
@@ -31,8 +32,16 @@ void die_if_no_backend() {
     t4k_malloc(&p, 256); g_scalar = (float *)p; g_iscalar = (int *)(g_scalar + 16);
     g_ready = true;
 }
+static void (*g_sink)(const char *, void *) = nullptr;
+static void *g_sink_user = nullptr;
+void set_host_sink(void (*fn)(const char *, void *), void *user) { g_sink = fn; g_sink_user = user; }
+void hprintf(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (g_sink) g_sink(buf, g_sink_user); else fputs(buf, stdout);
+}
 int chk(int rc, const char *what) {
-    if (rc != T4K_OK) printf("%s failed: %s\n", what, t4k_last_error());     // print-and-continue (ten4_types.h:25)
+    if (rc != T4K_OK) hprintf("%s failed: %s\n", what, t4k_last_error());     // print-and-continue (ten4_types.h:25)
     return rc;
 }
 t4k_stream_t stream() { return nullptr; }
@@ -121,7 +130,7 @@ Tensor &Store::dim(Tensor &t0) {                        // MMU::dim mmu.cu:296-3
     return t;
 }
 Tensor &Store::slice(Tensor &t0, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {   // mmu.cu:307-330
-    if (t0.rank < 2) { printf("dim?"); return t0; }
+    if (t0.rank < 2) { hprintf("dim?"); return t0; }
     if (x1 == (uint32_t)-1) x1 = t0.W();
     if (y1 == (uint32_t)-1) y1 = t0.H();
     Tensor &t1 = t0.rank == 2 ? tensor(y1 - y0, x1 - x0) : tensor(t0.N(), y1 - y0, x1 - x0, t0.C());
@@ -163,17 +172,17 @@ void Store::sweep() {
 // ---------------------------------------------------------------- Tensor
 Tensor &Tensor::reshape(uint64_t sz) {
     if (sz == numel) { rank = 1; shape[0] = (uint32_t)sz; shape[1] = shape[2] = shape[3] = 1; stride[0] = stride[1] = stride[2] = stride[3] = 1; }
-    else printf("  tensor#reshape sz != numel (%ld != %ld)\n", (long)sz, (long)numel);
+    else hprintf("  tensor#reshape sz != numel (%ld != %ld)\n", (long)sz, (long)numel);
     return *this;
 }
 Tensor &Tensor::reshape(uint32_t h, uint32_t w) {
     if ((uint64_t)h * w == numel) { rank = 2; shape[0] = h; shape[1] = w; shape[2] = shape[3] = 1; }
-    else printf("  tensor#reshape sz != numel (%ld != %ld)\n", (long)((uint64_t)h * w), (long)numel);
+    else hprintf("  tensor#reshape sz != numel (%ld != %ld)\n", (long)((uint64_t)h * w), (long)numel);
     return *this;
 }
 Tensor &Tensor::reshape(uint32_t n, uint32_t h, uint32_t w, uint32_t c) {
     if ((uint64_t)n * h * w * c == numel) { rank = 4; shape[0] = h; shape[1] = w; shape[2] = c; shape[3] = n; }
-    else printf("  tensor#reshape sz != numel (%ld != %ld)\n", (long)((uint64_t)n * h * w * c), (long)numel);
+    else hprintf("  tensor#reshape sz != numel (%ld != %ld)\n", (long)((uint64_t)n * h * w * c), (long)numel);
     return *this;
 }
 Tensor &Tensor::zeros() { chk(t4k_memset(data, 0, sizeof(float) * numel, stream()), "zeros"); return *this; }
@@ -206,7 +215,7 @@ DU Tensor::max()  { t4k_reduce(T4K_RED_MAX, data, (long)numel, 0, g_scalar, stre
 DU Tensor::min()  { t4k_reduce(T4K_RED_MIN, data, (long)numel, 0, g_scalar, stream()); DU v = read_scalar(); return SCALAR(v); }
 DU Tensor::dot(Tensor &B) {
     if (rank == 1 && B.rank == 1 && numel == B.numel) t4k_dot(data, B.data, g_scalar, 1.0f, 0.0f, (int)numel, 1, stream());
-    else printf("A.dot(B) dim? %ld != %ld)\n", (long)numel, (long)B.numel);
+    else hprintf("A.dot(B) dim? %ld != %ld)\n", (long)numel, (long)B.numel);
     DU v = read_scalar(); return SCALAR(v);
 }
 DU Tensor::loss(Loss op, Tensor &tgt) {                 // tensor.cu:288-325
@@ -216,7 +225,7 @@ DU Tensor::loss(Loss op, Tensor &tgt) {                 // tensor.cu:288-325
     case LOSS_BCE: t4k_bce(tgt.data, data, (long)numel, g_scalar, stream()); z = -read_scalar(); break;
     case LOSS_CE:  map(T4K_LN);                         /* fall through */
     case LOSS_NLL: ten_op(T4K_MUL, *this, tgt, *this); z = -sum(); break;
-    default: printf("Model#loss op=%d not supported!\n", op);
+    default: hprintf("Model#loss op=%d not supported!\n", op);
     }
     z /= N();
     return SCALAR(z);
@@ -245,7 +254,7 @@ Tensor &Tensor::ten_op(int op, Tensor &A, DU v, Tensor &O) {     // tensor.cu:16
 Tensor &Tensor::ten_op(int op, Tensor &A, Tensor &B, Tensor &O) {   // tensor.cu:28-53 (N broadcast)
     const uint32_t Na = A.N(), Nb = B.N(), N = std::max(Na, Nb);
     if (A.HWC() != B.HWC() || (Na == 1 ? B.numel : A.numel) != O.numel) {
-        printf("  tensor#ten_op A.HWC(%ld)!=B.HWC(%ld) or N, C diff\n", (long)A.HWC(), (long)B.HWC());
+        hprintf("  tensor#ten_op A.HWC(%ld)!=B.HWC(%ld) or N, C diff\n", (long)A.HWC(), (long)B.HWC());
         return O;
     }
     if ((Na == 1 || Nb == 1) && Na != Nb) {
@@ -258,7 +267,7 @@ Tensor &Tensor::mm(Tensor &A, Tensor &B, Tensor &O, bool inc, bool tA, bool tB) 
     const uint32_t H = tA ? A.W() : A.H(), W = tB ? B.H() : B.W();
     const uint32_t Ka = tA ? A.H() : A.W(), Kb = tB ? B.W() : B.H();
     const uint32_t Na = A.N(), Nb = B.N(), C = B.C(), N = std::max(Na, Nb);
-    if (Ka != Kb || N != O.N() || C != O.C()) { printf("  tensor#gemm3 ka(%d)!=kb(%d) or N, C diff\n", Ka, Kb); return O; }
+    if (Ka != Kb || N != O.N() || C != O.C()) { hprintf("  tensor#gemm3 ka(%d)!=kb(%d) or N, C diff\n", Ka, Kb); return O; }
     for (uint32_t n = 0; n < N; n++)
         chk(t4k_gemm(A.slice(Na == 1 ? 0 : n), B.slice(Nb == 1 ? 0 : n), O.slice(n), 1.0f, inc ? 1.0f : 0.0f, tA, tB, H, W, Ka, C, stream()), "gemm");
     return O;
@@ -278,7 +287,7 @@ Tensor &Tensor::gemm(int variant, Tensor &A, Tensor &B, Tensor &O, DU alpha, DU 
         O.from_host(o.data(), o.size());
         return O;
     }
-    if (Ka != Kb || N != O.N() || C != O.C()) { printf("  tensor#gemm%d ka(%d)!=kb(%d) or N, C diff\n", variant, Ka, Kb); return O; }
+    if (Ka != Kb || N != O.N() || C != O.C()) { hprintf("  tensor#gemm%d ka(%d)!=kb(%d) or N, C diff\n", variant, Ka, Kb); return O; }
     for (uint32_t n = 0; n < N; n++) {
         float *da = A.slice(Na == 1 ? 0 : n), *db = B.slice(Nb == 1 ? 0 : n);
         if (variant <= 2) chk(t4k_gemm_f64acc(da, db, O.slice(n), alpha, beta, H, W, Ka, C, stream()), "gemm_f64acc");
@@ -292,29 +301,29 @@ Tensor &Tensor::transpose(Tensor &A, Tensor &T) {
 }
 static int read_status() { int s = 0; t4k_memcpy_d2h(&s, g_iscalar, sizeof(int), stream()); t4k_sync(stream()); return s; }
 Tensor &Tensor::inverse(Tensor &A, Tensor &I) {          // tensor.cu:344-369
-    if (A.H() != A.W() || I.H() != I.W()) { printf(" A: square matrix required (%d x %d)\n", A.H(), A.W()); return A; }
+    if (A.H() != A.W() || I.H() != I.W()) { hprintf(" A: square matrix required (%d x %d)\n", A.H(), A.W()); return A; }
     const int K = A.W();
-    printf("  tensor#inverse [%d,%d]\n", K, K);
+    hprintf("  tensor#inverse [%d,%d]\n", K, K);
     chk(t4k_inverse(A.data, I.data, K, g_iscalar, stream()), "inverse");
     int st = read_status();
-    if (st) { printf("  tensor#inverse: singular matrix at column %d\n", st - 1); return A; }
+    if (st) { hprintf("  tensor#inverse: singular matrix at column %d\n", st - 1); return A; }
     return I;
 }
 Tensor &Tensor::plu(Tensor &A, Tensor &I, int *piv_dev) {
-    if (A.H() != A.W()) { printf(" A: square matrix required (%d x %d)\n", A.H(), A.W()); return A; }
+    if (A.H() != A.W()) { hprintf(" A: square matrix required (%d x %d)\n", A.H(), A.W()); return A; }
     chk(t4k_plu(A.data, (&A == &I) ? nullptr : I.data, piv_dev, A.W(), g_iscalar, stream()), "plu");
     int st = read_status();
-    if (st) { printf("  tensor#plu: singular at column %d\n", st - 1); return A; }
+    if (st) { hprintf("  tensor#plu: singular at column %d\n", st - 1); return A; }
     return I;
 }
 Tensor &Tensor::lu_inverse(Tensor &A, Tensor &I) {
     if (A.H() != A.W() || I.H() != I.W()) return I;
     const int K = A.W();
-    printf("  tensor#lu_inverse [%d,%d]\n", K, K);
+    hprintf("  tensor#lu_inverse [%d,%d]\n", K, K);
     Tensor &piv = Store::get().tensor(K);
     chk(t4k_lu_inverse(A.data, I.data, (int *)piv.data, K, g_iscalar, stream()), "lu_inverse");
     int st = read_status();
-    if (st) printf("  tensor#plu: singular at column %d\n", st - 1);
+    if (st) hprintf("  tensor#plu: singular at column %d\n", st - 1);
     Store::get().free(piv);
     return I;
 }

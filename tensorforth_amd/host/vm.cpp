@@ -409,7 +409,7 @@ void VM::init_core() {
     });
     CODE("[to]", [this] {
         uint32_t a = (cell(ip_) & 0xFFFFFFu) + 4; DU d = POP(); ip_ += 4;
-        if (a < PMEM_SZ) set_du(a, d); else { pstr("is ?"); stop_ = true; }
+        if (a + 4 <= (uint32_t)PMEM_SZ) set_du(a, d); else { pstr("is ?"); stop_ = true; }
     });
     // memory
     CODE("@",  [this] { uint32_t i = (uint32_t)POPi(); PUSH(mem_du(i)); });
@@ -482,6 +482,7 @@ void VM::init_core() {
 }
 
 void VM::init() {
+    set_host_sink([](const char *t, void *u) { ((VM *)u)->pstr(t); }, this);     // host-layer messages join this VM's output, in order
     dict_.clear();
     init_core();
     init_tensor();

@@ -88,8 +88,8 @@ private:
     int  add_str(const std::string &s);
     uint32_t cell(uint32_t a) { uint32_t v; memcpy(&v, &pmem_[a], 4); return v; }
     void set_cell(uint32_t a, uint32_t v) { memcpy(&pmem_[a], &v, 4); }
-    DU   mem_du(uint32_t a) { DU v; memcpy(&v, &pmem_[a], 4); return v; }
-    void set_du(uint32_t a, DU v) { memcpy(&pmem_[a], &v, 4); }
+    DU   mem_du(uint32_t a) { DU v = 0; if ((uint64_t)a + 4 <= pmem_.size()) memcpy(&v, &pmem_[a], 4); return v; }   // user addresses (`@ ? +!`): a 4-byte access must end inside pmem
+    void set_du(uint32_t a, DU v) { if ((uint64_t)a + 4 <= pmem_.size()) memcpy(&pmem_[a], &v, 4); }
     void setjmp_at(uint32_t a) { set_cell(a, (cell(a) & 0xFF000000u) | (here_ & 0xFFFFFFu)); }
     bool new_word();
     // ---- execution

@@ -435,7 +435,7 @@ void VM::init_nn() {
         else pstr("TOS not a tensor nor NOS a model?\n");
     });
     CODE("network", [this] { if (is_m(tos_)) { pstr(fmt_model(MTOS())); pstr(" "); } });
-    CODE(">n", [this] { if (M1V()) { DU t = POP(); if (IS_OBJ(t)) MTOS().layer.push_back(&(Tensor &)st().du2obj(t)); } });
+    CODE(">n", [this] { if (M1V()) { DU t = POP(); if (IS_OBJ(t)) { MTOS().layer.push_back(&(Tensor &)st().du2obj(t)); MTOS().invalidate(); } } });   // a new layer: fused-run plan and slab are stale
     CODE("n@", [this] { if (!M1V()) return; int i = POPi(); DU v = st().obj2du(MTOS().at(i)); PUSH(DUP(v)); });
     CODE("nn.len", [this] {
         if (IS_OBJ(tos_)) {

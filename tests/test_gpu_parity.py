@@ -302,7 +302,9 @@ def test_batchnorm_synchronised_statistics_world_one(t4k, dev, oracle, N, HW, C)
     raw = (ctypes.c_ubyte * 128)()
     assert lib.t4k_comm_unique_id(raw) == 0 and lib.t4k_comm_init(raw, 0, 1) == 0, lib.t4k_last_error()
     try:
-        _batchnorm_case(t4k, dev, oracle, N, HW, C)
+        _batchnorm_case(t4k, dev, oracle, N, HW, C)          # a communicator alone changes nothing: synchronised statistics are opt-in
+        assert lib.t4k_comm_sync_batchnorm(1) == 0
+        _batchnorm_case(t4k, dev, oracle, N, HW, C)          # ... and this is the all-reduce path
     finally:
         lib.t4k_comm_destroy()
 
