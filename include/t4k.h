@@ -323,6 +323,12 @@ typedef struct { float *G, *DG, *M, *V; long n; int Nw; int pad; } t4k_param_rec
 int t4k_opt_multi(int kind /*0 sgd,1 adam,2 adamw*/, const t4k_param_rec *tab_dev, int n_tensors,
                   long max_n, float lr, float b1, float b2, float wd, t4k_stream_t s);
 
+/* the same step with the launch sized to the parameters (k_opt_multi starts max_n/256 workgroups for EVERY tensor: 8192 waves for the
+ * LeNet net's 101 030 parameters).  The caller fills each record's `pad` with the tensor's first 1024-element chunk - the running sum of
+ * ceil(n / 1024) over the records before it - and passes the total; one workgroup per chunk. */
+int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n_chunks,
+                    float lr, float b1, float b2, float wd, t4k_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,5 +223,8 @@ int t4k_opt_multi(int kind, const t4k_param_rec *tab, int nt, long, float lr, fl
     }
     return T4K_OK;
 }
+int t4k_opt_chunked(int kind, const t4k_param_rec *tab, int nt, int, float lr, float b1, float b2, float wd, t4k_stream_t st) {
+    return t4k_opt_multi(kind, tab, nt, 0, lr, b1, b2, wd, st);
+}
 
 } // extern "C"

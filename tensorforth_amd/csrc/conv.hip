@@ -17,6 +17,8 @@
 #include "t4k_common.h"
 #include <float.h>
 
+namespace t4k { bool conv_img_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
+                                        int N, int H, int W, int C1, int C0, hipStream_t hs); }
 using namespace t4k;
 
 namespace t4k {                                   // conv_big.hip: LDS-staged MFMA GEMM tiling for many channels
@@ -830,6 +832,8 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
         return t4k_poolblock_fwd(O, blk, N, H0, W0, H0 / blk->KS, W0 / blk->KS, C0, s);
     }
     hipStream_t hs = t4k::S(s);
+    // image-input layer (1 or 3 channels in, <= 16 out): the thread-per-pool-window vector kernel of conv_img.hip
+    if (K == 3 && P == 1 && H1 == H0 && W1 == W0 && conv_img_block_fwd(I, ICOPY, O, F, B, blk, N, H0, W0, C1, C0, hs)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     // layer-0 copy: written by the conv launch itself when input and output share the pixel grid and the channels are few
     float *xc = (ICOPY && H1 == H0 && W1 == W0 && C1 <= 4) ? ICOPY : nullptr;
     if (ICOPY && !xc) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, hs));

@@ -747,6 +747,7 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
 // copy of the 8-wave kernel with nothing else in it: the same loop inside the general template above measures 20.1 us at 1024^3, this
 // one 19.4 (tools/gemm_lab.hip: every variant with in-kernel cycle stamps; the loop is sensitive to the code around it).
 struct PlainP { const float *A, *B; float *O; int M, N, K; };
+template <bool POW2>
 __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
     constexpr int BM = 64, BN = 64, BK = 128;
     constexpr int NC = BK / 8, CH = BK / 4;
@@ -758,23 +759,33 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
     const int c0 = kg * NCG;
     const int M = p.M, N = p.N, K = p.K;
     const int tiles_m = M / BM, tiles_n = N / BN, T = tiles_m * tiles_n;
-    int L;
-    {
-        const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
-        L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i;
+    int tm, tn;
+    if (POW2) {                                             // power-of-two tile grid with T % 32 == 0 (1024^2: 16 x 16): the XCD-aware tile order in shifts -
+        const int tnb = 31 - __builtin_clz(tiles_n), b = blockIdx.x;     // the general form below costs three integer divisions (~400 cycles) before the first DMA
+        const int L = (b & 7) * (T >> 3) + (b >> 3), pg = 2 + tnb, r = L & ((1 << pg) - 1);
+        tm = ((L >> pg) << 2) + (r & 3); tn = r >> 2;
+    } else {
+        int L;
+        {
+            const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
+            L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i;
+        }
+        constexpr int GROUP_M = 4;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = L / per_group, first_m = grp * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        tm = first_m + (L % per_group) % gsz; tn = (L % per_group) / gsz;
     }
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * tiles_n;
-    const int grp = L / per_group, first_m = grp * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (L % per_group) % gsz, tn = (L % per_group) / gsz;
     const int m0 = tm * BM, n0 = tn * BN, nst = K / BK;
     unsigned voffA[NJ], voffB[NJ];
+    {
+        const int r0 = w * 8 + (lane >> 5), ql = lane & 31, kk0 = w * 16 + (lane >> 4);
+        const unsigned ba = (unsigned)((m0 + r0) * K) * 4u, bb = (unsigned)(kk0 * N + n0 + (lane & 15) * 4) * 4u;   // one multiply per operand
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        const int i = w * NJ + j;
-        { const int r = i * 2 + lane / CH, ql = lane % CH, q = ql ^ (r & (CH - 1)); voffA[j] = (unsigned)(((m0 + r) * K + q * 4) * 4); }
-        { const int kk = i * 4 + lane / 16, ch = lane % 16; voffB[j] = (unsigned)((kk * N + n0 + ch * 4) * 4); }
+        for (int j = 0; j < NJ; j++) {
+            voffA[j] = ba + (unsigned)(2 * j * K) * 4u + (unsigned)((ql ^ ((r0 + 2 * j) & 31)) << 4);
+            voffB[j] = bb + (unsigned)(4 * j * N) * 4u;
+        }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
     auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
@@ -855,9 +866,17 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
 void launch_nn_plain(const GemmP &p, dim3 grid, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)2 * 128 * 128 * sizeof(float);
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_done = true;
+    }
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K };
-    hipLaunchKernelGGL(k_gemm_nn_plain, dim3(grid.x), dim3(512), lds_bytes, s, q);
+    const int tmq = p.M / 64, tnq = p.N / 64;
+    static int fastpro = -1; if (fastpro < 0) { const char *e = getenv("T4K_GEMM_FASTPRO"); fastpro = e ? atoi(e) : 1; }
+    const bool pow2 = fastpro && (tmq & (tmq - 1)) == 0 && (tnq & (tnq - 1)) == 0 && tmq >= 4 && (tmq * tnq) % 32 == 0;
+    if (pow2) hipLaunchKernelGGL(k_gemm_nn_plain<true>,  dim3(grid.x), dim3(512), lds_bytes, s, q);
+    else      hipLaunchKernelGGL(k_gemm_nn_plain<false>, dim3(grid.x), dim3(512), lds_bytes, s, q);
 }
 
 template <int BK>

@@ -70,6 +70,33 @@ __global__ void __launch_bounds__(BLK) k_opt_multi(int kind, const t4k_param_rec
     }
 }
 
+// the same step with the grid sized to the parameters: workgroup b owns 1024-element chunk b of the concatenation of all tensors; the
+// record's `pad` field holds the tensor's first chunk (host-filled prefix), found by a short scan of the table (uniform -> scalar loads)
+__global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_rec *__restrict__ tab, int nt,
+                                                     float lr, float b1, float b2, float wd) {
+    int i = 0;
+    while (i + 1 < nt && (int)blockIdx.x >= tab[i + 1].pad) i++;
+    const t4k_param_rec r = tab[i];
+    const bool mom = !(fabsf(b1) < DU_EPS);
+    const long j0 = ((long)blockIdx.x - r.pad) * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const long j = j0 + q * BLK + threadIdx.x;
+        if (j >= r.n) break;
+        float g = r.G[j], dg = r.DG[j];
+        if (kind == 0) {
+            float m = mom ? r.M[j] : 0.f;
+            sgd1(g, dg, m, r.Nw, lr, b1, mom);
+            if (mom) r.M[j] = m;
+        } else {
+            float m = r.M[j], v = r.V[j];
+            if (kind == 1) adam1(g, dg, m, v, lr, b1, b2); else adamw1(g, dg, m, v, lr, b1, b2, wd);
+            r.M[j] = m; r.V[j] = v;
+        }
+        r.G[j] = g; r.DG[j] = 0.f;
+    }
+}
+
 // d[i] = scale * (bias + u_i): element i <- Philox(counter = (off+i)/4)[i%4].
 // The stream state (counter, seed) is read from device memory and advanced by the last workgroup to
 // finish, so the same launch captured in a hipGraph draws a fresh slice of the stream on every replay.
@@ -150,6 +177,14 @@ int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long ma
     if (!tab_dev || kind < 0 || kind > 2) return fail(T4K_ERR_ARG, "t4k_opt_multi: bad argument");
     int gx = grid_for(max_n); if (gx > 256) gx = 256;
     hipLaunchKernelGGL(k_opt_multi, dim3(gx, n_tensors), dim3(BLK), 0, S(s), kind, tab_dev, lr, b1, b2, wd);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+
+int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n_chunks,
+                    float lr, float b1, float b2, float wd, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n_tensors <= 0 || n_chunks <= 0) return T4K_OK;
+    if (!tab_dev || kind < 0 || kind > 2) return fail(T4K_ERR_ARG, "t4k_opt_chunked: bad argument");
+    hipLaunchKernelGGL(k_opt_chunked, dim3((unsigned)n_chunks), dim3(BLK), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

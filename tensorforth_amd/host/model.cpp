@@ -618,7 +618,7 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
 // ---------------------------------------------------------------- optimizers
 void Model::build_table(Optim op) {                      // one multi-tensor launch replaces 6-8 launch+sync pairs
     std::vector<t4k_param_rec> recs;
-    tab_max = 0;
+    tab_max = 0; tab_chunks = 0;
     for (int i = 0; i + 1 < (int)layer.size(); i++) {
         Tensor &in = at(i);
         for (int k = 0; k < 2; k++) {
@@ -626,7 +626,8 @@ void Model::build_table(Optim op) {                      // one multi-tensor lau
             t4k_param_rec r;
             r.G = in.grad[k]->data; r.DG = in.grad[k + 2]->data; r.M = in.mtum[k]->data;
             r.V = in.mtum[k + 2] ? in.mtum[k + 2]->data : in.mtum[k]->data;
-            r.n = (long)in.grad[k]->numel; r.Nw = (int)in.grad[k]->N(); r.pad = 0;     // g.N(): C1 for conv filters (quirk a-19)
+            r.n = (long)in.grad[k]->numel; r.Nw = (int)in.grad[k]->N(); r.pad = tab_chunks;     // g.N(): C1 for conv filters (quirk a-19); pad = first 1024-element chunk
+            tab_chunks += (int)((r.n + 1023) / 1024);
             recs.push_back(r); tab_max = std::max(tab_max, r.n);
         }
     }
@@ -663,7 +664,7 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     dp_finish();
     if (!replay(g_opt_, tab_dev, (int)op, p)) {
         const bool cap = capturing_;
-        chk(t4k_opt_multi(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_max, lr, b1, b2, wd, stream()), nm);
+        chk(t4k_opt_chunked(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_chunks, lr, b1, b2, wd, stream()), nm);   // one workgroup per 1024 parameters
         end_capture(g_opt_, cap);
     }
     NLOG("} Model::%s\n", nm);

@@ -240,7 +240,7 @@ private:
     void run_backward(Tensor &tgt);
     Model &gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd);
     // one-launch optimizer over a device parameter table
-    void *tab_dev = nullptr; int tab_n = 0; long tab_max = 0; Optim tab_kind = OPTI_SGD;
+    void *tab_dev = nullptr; int tab_n = 0; long tab_max = 0; int tab_chunks = 0; Optim tab_kind = OPTI_SGD;
     void build_table(Optim op);
     // ---- execution engine: the critical path (activations fwd, dX chain bwd) runs on the main stream;
     // copies the reference makes for bookkeeping (n0 = input, flatten, in = dX), dropout-mask generation

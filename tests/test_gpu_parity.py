@@ -361,6 +361,18 @@ def test_optimizers_and_multi_tensor_step(t4k, dev, oracle):
     t4k.call("t4k_opt_multi", 1, p(tab), len(sizes), max(sizes), 1e-3, 0.9, 0.999, 0.0, None)
     for dW, dG, dM, dV, W in bufs:
         assert rel(dev.down(dW), W) < 1e-5 and not dev.down(dG).any()
+    # launch sized to the parameters (t4k_opt_chunked): `pad` = the tensor's first 1024-element chunk; SGD with momentum, second step
+    bufs = []; recs = b""; chunk = 0
+    for i, sz in enumerate(sizes):
+        W = rng.standard_normal(sz).astype(np.float32); G = rng.standard_normal(sz).astype(np.float32); M = (rng.standard_normal(sz) * 0.1).astype(np.float32)
+        dW, dG, dM = dev.up(W), dev.up(G), dev.up(M)
+        o.t4o_sgd(P(W), P(G), P(M), 1 + i % 3, 0.01, 0.9, sz)
+        bufs.append((dW, dG, dM, W, M))
+        recs += struct.pack("<QQQQqii", p(dW), p(dG), p(dM), p(dM), sz, 1 + i % 3, chunk); chunk += (sz + 1023) // 1024
+    tab = dev.up(np.frombuffer(recs, np.uint8))
+    t4k.call("t4k_opt_chunked", 0, p(tab), len(sizes), chunk, 0.01, 0.9, 0.0, 0.0, None)
+    for dW, dG, dM, W, M in bufs:
+        assert rel(dev.down(dW), W) < 1e-5 and rel(dev.down(dM), M) < 1e-5 and not dev.down(dG).any()
 
 
 def test_onehot_hit_u8(t4k, dev, oracle):
