@@ -42,6 +42,18 @@ int  chk(int rc, const char *what);  // prints t4k_last_error() on failure (prin
 // embedded users (ten4_eval / ten4_output, vm.py) see them and they stay in order with the text the words print; stdout otherwise.
 void hprintf(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void set_host_sink(void (*fn)(const char *text, void *user), void *user);
+// TensorBoard sink (host/tboard.cpp): inactive - the words only print the reference's hint - until a log directory is given
+struct Tensor;
+bool tb_configure(const char *logdir, const char *run_id);
+bool tb_active();
+void tb_init(const char *run_id);
+void tb_step(int i);
+void tb_scalar(const char *tag, float v);
+void tb_text(const char *tag, const char *txt);
+void tb_histo(const char *tag, Tensor &t, int n_bucket);
+void tb_tile(const char *tag, Tensor &t, int per_row);
+void tb_image(const char *tag, Tensor &t);
+void tb_close();
 t4k_stream_t stream();
 
 // ---------------------------------------------------------------- HBM arena

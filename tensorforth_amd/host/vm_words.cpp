@@ -205,27 +205,41 @@ void VM::init_tensor() {
     };
     CODE("save", [tsave] { tsave(false); });
     CODE("load", [tsave] { tsave(true); });
-    // TensorBoard words parse and report (no writer: SURVEY 2 #13 out of scope); sys.cpp:229-256 message
+    // TensorBoard words (tenvm.cpp:603-612 -> sys.cpp:230-273): written by host/tboard.cpp when a log directory is configured
+    // (`ten4 -t <logdir> -r <run>` / T4_TB_LOGDIR), otherwise the reference's hint is printed, as the reference does without -t
     auto tb = [this](const char *nm, int npop, bool has_tag) {
-        std::string tag;
+        std::string tag, txt;
         if (has_tag) { POPi(); tag = (const char *)&pmem_[(uint32_t)POPi()]; }
         DU n = 0; int i = 0;
-        if (npop == 3) { POPi(); POPi(); }               // .text: second string
-        if (npop == 2) { i = POPi(); n = POP(); if (IS_OBJ(n)) st().mark_free(n); }
-        if (npop == 1) { n = POP(); if (IS_OBJ(n)) st().mark_free(n); }
-        char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%s, n=%g, i=%d%s%s), check TensorBoard param -tlogdir -rrun_id\n", nm, IS_OBJ(n) ? 0.0f : n, i,
-                              has_tag ? ", tag=" : "", tag.c_str());
-        pstr(b);
+        if (npop == 3) { POPi(); txt = (const char *)&pmem_[(uint32_t)POPi()]; }   // .text: ( txt_addr len tag_addr len -- )
+        if (npop == 2) { i = POPi(); n = POP(); }
+        if (npop == 1) { n = POP(); }
+        if (tb_active()) {
+            Tensor *t = IS_OBJ(n) ? &(Tensor &)st().du2obj(n) : nullptr;
+            if (!strcmp(nm, "init")) tb_init(tag.c_str());
+            else if (!strcmp(nm, "scalar")) tb_scalar(tag.c_str(), n);
+            else if (!strcmp(nm, "text")) tb_text(tag.c_str(), txt.c_str());
+            else if (!strcmp(nm, "histo") && t) tb_histo(tag.c_str(), *t, i);
+            else if (!strcmp(nm, "tile") && t) tb_tile(tag.c_str(), *t, i);
+            else if (!strcmp(nm, "image") && t) tb_image(tag.c_str(), *t);
+            else { char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%s, tag=%s): not written by this sink\n", nm, tag.c_str()); pstr(b); }
+        } else {
+            char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%s, n=%g, i=%d%s%s), check TensorBoard param -tlogdir -rrun_id\n", nm, IS_OBJ(n) ? 0.0f : n, i,
+                                  has_tag ? ", tag=" : "", tag.c_str());
+            pstr(b);
+        }
+        if (IS_OBJ(n)) st().mark_free(n);
     };
     CODE(".tbinit", [tb] { tb("init", 0, true); });
-    CODE(".tbstep", [this] { int i = POPi(); char b[96]; snprintf(b, sizeof(b), "  sys#tbx(op=step, i=%d), check TensorBoard param -tlogdir -rrun_id\n", i); pstr(b); });
+    CODE(".tbstep", [this] { int i = POPi(); if (tb_active()) { tb_step(i); return; }
+                             char b[96]; snprintf(b, sizeof(b), "  sys#tbx(op=step, i=%d), check TensorBoard param -tlogdir -rrun_id\n", i); pstr(b); });
     CODE(".scalar", [tb] { tb("scalar", 1, true); });
     CODE(".text",   [tb] { tb("text", 3, true); });
     CODE(".image",  [tb] { tb("image", 1, true); });
     CODE(".tile",   [tb] { tb("tile", 2, true); });
     CODE(".histo",  [tb] { tb("histo", 2, true); });
     CODE(".embed",  [tb] { tb("embed", 1, true); });
-    CODE(".graph",  [this] { POP(); pstr("  sys#tbx(op=graph), check TensorBoard param -tlogdir -rrun_id\n"); });
+    CODE(".graph",  [this] { POP(); pstr(tb_active() ? "  sys#tbx(op=graph): not written by this sink\n" : "  sys#tbx(op=graph), check TensorBoard param -tlogdir -rrun_id\n"); });
     CODE(".png",    [this] { POPi(); POPi(); pstr("  .png: n/a\n"); });
     // redefined words
     CODE("@", [this] { if (TOS2T()) blas2(B_DOT, true); else { uint32_t i = (uint32_t)POPi(); PUSH(DUP(mem_du(i))); } });

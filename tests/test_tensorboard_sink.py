@@ -1,0 +1,170 @@
+"""TensorBoard sink (words .tbinit .tbstep .scalar .histo .text .tile, host/tboard.cpp).
+
+CPU test through the oracle-backed VM (same host sources as the product): a script logs a scalar, a histogram, a text and an image
+tile; the tfevents file is then (1) checked record by record against TensorBoard's framing - length, masked crc32c of the length,
+payload, masked crc32c of the payload - with a crc32c written here, and (2) compared BYTE FOR BYTE with the file this test builds
+itself from the protobuf schema (Event / Summary / HistogramProto / TensorProto / Image) with its own encoder and the bucket rule of
+the reference's writer (underflow bin at min, n equal bins, last limit max + 1e-10).  The clock is pinned with T4_TB_FIXED_TIME."""
+import glob
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from vm_util import ROOT, TEN4, TEN4_ORACLE
+
+T0 = 1700000000.0
+SCRIPT = '''0 trace
+3 .tbstep
+0.5 s" train/loss" .scalar
+8 vector{ -1 0 0.25 0.5 1 2 2 3 } 4 s" nn/w" .histo
+: note s" epoch three" s" notes" .text ;
+note
+7 .tbstep
+2 2 3 1 tensor ={ 0 0.25 0.5 0.75 1 0.125 0.5 0.5 0.5 0.5 0.5 0.5 } 2 s" imgs" .tile
+1.5 s" train/loss" .scalar
+bye
+'''
+
+
+def crc32c(data):
+    tab = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (0x82F63B78 ^ (c >> 1)) if c & 1 else c >> 1
+        tab.append(c)
+    c = 0xFFFFFFFF
+    for b in data:
+        c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def masked(c):
+    return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+
+# ---- a second, independent protobuf encoder (the test's statement of the schema)
+def varint(v):
+    out = b""
+    while v >= 0x80:
+        out += bytes([(v & 0x7F) | 0x80]); v >>= 7
+    return out + bytes([v])
+
+
+def key(f, w): return varint((f << 3) | w)
+def f_i64(f, v): return key(f, 0) + varint(v)
+def f_f64(f, v): return key(f, 1) + struct.pack("<d", v)
+def f_f32(f, v): return key(f, 5) + struct.pack("<f", v)
+def f_len(f, b): return key(f, 2) + varint(len(b)) + b
+def f_pk64(f, vs): return f_len(f, b"".join(struct.pack("<d", x) for x in vs))
+
+
+def event(step, value):
+    return f_f64(1, T0) + f_i64(2, step) + f_len(5, f_len(1, value))
+
+
+def meta(plugin): return f_len(1, f_len(1, plugin.encode()))
+
+
+def histo_value(tag, xs, nb):
+    xs = np.asarray(xs, np.float32).astype(np.float64)
+    vmin, vmax = xs.min(), xs.max()
+    bw = (vmax - vmin) / nb
+    limits = [vmin] + [vmin + (i + 1) * bw for i in range(nb)]; limits[-1] = vmax + 1e-10
+    counts = [0.0] * (nb + 1)
+    for x in xs:
+        counts[max(0, min(nb - 1, int((x - vmin) / bw))) + 1] += 1.0
+    hp = f_f64(1, vmin) + f_f64(2, vmax) + f_f64(3, float(len(xs))) + f_f64(4, xs.sum()) + f_f64(5, (xs * xs).sum()) + f_pk64(6, limits) + f_pk64(7, counts)
+    return f_len(1, tag.encode()) + f_len(9, meta("histograms")) + f_len(5, hp)
+
+
+def png_stored(w, h, rgb):
+    raw = b"".join(b"\x00" + rgb[y * w * 3:(y + 1) * w * 3] for y in range(h))
+    z = b"\x78\x01" + b"\x01" + struct.pack("<HH", len(raw), ~len(raw) & 0xFFFF) + raw + struct.pack(">I", zlib.adler32(raw))
+    def ch(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    return b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + ch(b"IDAT", z) + ch(b"IEND", b"")
+
+
+def tile_pixels(t, per_row):
+    n, h, w, c = t.shape; B = 2
+    WT, HT = (w + B) * per_row + B, (h + B) * ((n + per_row - 1) // per_row) + B
+    px = np.zeros((HT, WT, 3), np.uint8)
+    for i in range(n):
+        ty, tx = divmod(i, per_row)
+        v = np.clip(t[i] * np.float32(256.0), 0, 255).astype(np.uint8)          # [h,w,c]
+        for ch_ in range(3):
+            px[ty * (h + B) + B: ty * (h + B) + B + h, tx * (w + B) + B: tx * (w + B) + B + w, ch_] = v[:, :, min(ch_, c - 1)]
+    return WT, HT, px.tobytes()
+
+
+def records(blob):
+    out = []; off = 0
+    while off < len(blob):
+        (n,) = struct.unpack_from("<Q", blob, off)
+        (lc,) = struct.unpack_from("<I", blob, off + 8)
+        data = blob[off + 12: off + 12 + n]
+        (dc,) = struct.unpack_from("<I", blob, off + 12 + n)
+        assert lc == masked(crc32c(blob[off:off + 8])), "length crc"
+        assert dc == masked(crc32c(data)), "payload crc"
+        out.append(data); off += 16 + n
+    return out
+
+
+@pytest.fixture(scope="module")
+def oracle_vm():
+    if not os.path.exists(TEN4_ORACLE):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ten4_oracle"], check=True, capture_output=True)
+    return TEN4_ORACLE
+
+
+def test_crc32c_known_answer():
+    assert crc32c(b"123456789") == 0xE3069283                  # the standard check value of CRC-32C (Castagnoli)
+
+
+def test_events_file_is_byte_exact(oracle_vm, tmp_path):
+    _byte_exact(oracle_vm, tmp_path)
+
+
+@pytest.mark.gpu
+def test_events_file_is_byte_exact_from_the_product_vm(tmp_path):
+    _byte_exact(TEN4, tmp_path)                                 # tensors come back from HBM here: same bytes
+
+
+def _byte_exact(binary, tmp_path):
+    env = dict(os.environ, T4_SEED="1", T4_TB_FIXED_TIME=str(int(T0)))
+    r = subprocess.run([binary, "-t", str(tmp_path), "-r", "run A/1"], input=SCRIPT, capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "check TensorBoard param" not in r.stdout, r.stdout
+    files = glob.glob(os.path.join(str(tmp_path), "run_A_1", "events.out.tfevents.%d.*.0" % int(T0)))   # run id escaped as the reference does
+    assert len(files) == 1, os.listdir(str(tmp_path))
+    blob = open(files[0], "rb").read()
+    recs = records(blob)                                        # framing + both crcs of every record
+    tile = np.array([0, 0.25, 0.5, 0.75, 1, 0.125, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5], np.float32).reshape(2, 2, 3, 1)
+    WT, HT, px = tile_pixels(tile, 2)
+    img = f_i64(1, HT) + f_i64(2, WT) + f_i64(3, 3) + f_len(4, png_stored(WT, HT, px))
+    text_tensor = f_i64(1, 7) + f_len(2, f_len(2, f_i64(1, 1))) + f_len(8, b"epoch three")
+    want = [
+        f_f64(1, T0) + f_i64(2, 0) + f_len(3, b"brain.Event:2"),
+        event(3, f_len(1, b"train/loss") + f_f32(2, 0.5)),
+        event(3, histo_value("nn/w", [-1, 0, 0.25, 0.5, 1, 2, 2, 3], 4)),
+        event(3, f_len(1, b"notes") + f_len(9, meta("text")) + f_len(8, text_tensor)),
+        event(7, f_len(1, b"imgs") + f_len(4, img)),
+        event(7, f_len(1, b"train/loss") + f_f32(2, 1.5)),
+    ]
+    assert len(recs) == len(want)
+    for i, (g, w) in enumerate(zip(recs, want)):
+        assert g == w, "record %d differs:\n got %s\nwant %s" % (i, g.hex(), w.hex())
+    # and the image decodes with a real inflater to the grid the tile word lays out
+    png = png_stored(WT, HT, px)
+    idat = png[png.index(b"IDAT") + 4: png.index(b"IEND") - 8]
+    raw = zlib.decompress(idat)
+    assert len(raw) == HT * (WT * 3 + 1)
+
+
+def test_words_only_hint_without_a_log_directory(oracle_vm):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("T4_TB_")}
+    r = subprocess.run([oracle_vm], input='0.5 s" x" .scalar\n3 .tbstep\nbye\n', capture_output=True, text=True, env=dict(env, T4_SEED="1"), timeout=60)
+    assert r.stdout.count("check TensorBoard param -tlogdir -rrun_id") == 2
