@@ -190,7 +190,7 @@ void Model::lazy_copy(const float *src, Tensor &dst) {   // bookkeeping copy, of
 }
 bool Model::replay(GraphSlot &slot, const void *key, int flags, const float *p) {
     capturing_ = false;
-    if (!use_graphs || !capturable_ || (trace && *trace)) return false;
+    if (!use_graphs || !capturable_ || (trace && *trace) || t4k_comm_world() > 1) return false;   // data parallel: mask draws are keyed on the host per launch, a replay would repeat them
     const bool same = slot.key == key && slot.flags == flags && (!p || memcmp(slot.p, p, sizeof(slot.p)) == 0);
     if (same && slot.g) { chk(t4k_graph_launch(slot.g, stream()), "graph launch"); return true; }
     if (!same) {                                        // new operands: run eagerly once, capture next time
