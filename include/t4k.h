@@ -270,7 +270,8 @@ int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y,
                    int N, int E0, int E1, t4k_stream_t s);
 /* A run of element-wise layers around one pooling layer, one launch each way (csrc/fused.hip):
  *   X --[pre: dropout | activation]--> pre_out --[pool KSxKS]--> pool_out --[post: activation]--> post_out --[flatten]--> copy_out
- * Absent stages have layer == T4K_L_NONE (KS must be 1 when there is no pooling stage).  Every tensor the
+ * Absent stages have layer == T4K_L_NONE (KS must be 1 when there is no pooling stage).  The post stage may also be a dropout layer
+ * (`leakyrelu dropout`, `maxpool dropout`) when the pre stage is not one: it draws the slice t4k_dropout_mask would draw for post_mask.  Every tensor the
  * separate layers write (_factivate forward.cu:200-209, _fpool :211-227, flatten copy :96) is written with
  * identical values; a dropout pre-stage draws the Philox slice t4k_rand would have drawn for its mask. */
 typedef struct t4k_poolblock {

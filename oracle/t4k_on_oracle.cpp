@@ -188,7 +188,10 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
         x = b->pre_out;
     }
     if (b->pool_layer) { int r = t4o_pool(b->pool_layer, x, b->pool_out, N, H1, W1, H0, W0, C, b->KS); if (r) return rc(r, "poolblock pool"); x = b->pool_out; }
-    if (b->post_layer) { int r = t4o_activate(b->post_layer, x, b->post_out, b->post_mask, b->post_alpha, n0); if (r) return rc(r, "poolblock post"); x = b->post_out; }
+    if (b->post_layer) {
+        if (b->post_layer == T4K_L_DROPOUT) t4o_dropout_mask(b->post_mask, n0);
+        int r = t4o_activate(b->post_layer, x, b->post_out, b->post_mask, b->post_alpha, n0); if (r) return rc(r, "poolblock post"); x = b->post_out;
+    }
     if (b->copy_out) t4o_copy(x, b->copy_out, n0);
     return T4K_OK;
 }

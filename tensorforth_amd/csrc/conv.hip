@@ -825,6 +825,7 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
     if (!blk) return fail(T4K_ERR_ARG, "t4k_conv2d_block_fwd: null block");
     const bool fusable = blk->pool_layer && blk->KS == 2 && (H0 % 2) == 0 && (W0 % 2) == 0 && S == 1 && (K == 3 || K == 5) &&
                          blk->pool_out && (!blk->pre_layer || (blk->pre_mask && blk->pre_out)) && (!blk->post_layer || (blk->post_mask && blk->post_out)) &&
+                         blk->post_layer != T4K_L_DROPOUT &&           // a dropout BEHIND the pool draws in the element-wise run kernel (fused.hip), not in the conv epilogue
                          !(conv_big_on() && conv_big_ok(C1, C0)) &&
                          conv_supported(K, S, P) && I && O && F && B && conv_block_on();
     if (!fusable) {

@@ -20,7 +20,7 @@ struct PB {                                   // device copy of t4k_poolblock + 
     const float *X; float *P, *Q, *R, *R2, *Fpre, *Fpost;
     int pre, pool, post; float a_pre, a_post;
     int N, H1, W1, H0, W0, C;
-    RngArg rng;
+    RngArg rng, rng2;                        // Philox slices of a dropout pre-stage / post-stage (one run holds at most one dropout)
 };
 
 // VW channels per thread (1, 2 or 4; C % VW == 0 and 4*VW-byte aligned tensors): vector loads / stores, and one
@@ -44,8 +44,9 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
     const int CV = p.C / VW;
     const long total = (long)p.N * p.H0 * p.W0 * CV;
     uint64_t base = 0, seed = 0;
-    const bool draw = p.pre == T4K_L_DROPOUT;
+    const bool draw = p.pre == T4K_L_DROPOUT, draw2 = p.post == T4K_L_DROPOUT;
     if (draw) rng_begin(p.rng, base, seed);
+    if (draw2) rng_begin(p.rng2, base, seed);
     for (long z = (long)blockIdx.x * blockDim.x + threadIdx.x; z < total; z += (long)gridDim.x * blockDim.x) {
         int c, j0, i0, n; long t; split2(z, CV, c, t); c *= VW; split3(t, p.W0, p.H0, j0, i0, n);
         Vec<VW> acc; bool first = true;
@@ -83,13 +84,16 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
         if (p.pool) vstore<VW>(p.Q + zo, acc);
         if (p.post) {
             Vec<VW> o, f;
+            uint32_t r[4] = {0, 0, 0, 0};
+            if (draw2) philox4x32_10(base + (uint64_t)(zo >> 2), seed, r);          // zo .. zo+VW-1 sit in one counter block
 #pragma unroll
-            for (int q = 0; q < VW; q++) act_rt(p.post, acc.v[q], 0.f, p.a_post, o.v[q], f.v[q]);
+            for (int q = 0; q < VW; q++) act_rt(p.post, acc.v[q], draw2 ? u01(r[(zo + q) & 3]) : 0.f, p.a_post, o.v[q], f.v[q]);
             vstore<VW>(p.Fpost + zo, f); vstore<VW>(p.R + zo, o); acc = o;
         }
         if (p.R2) vstore<VW>(p.R2 + zo, acc);
     }
     if (draw && p.rng.state) rng_advance_last_block(p.rng.state, base, (uint64_t)(((long)p.N * p.H1 * p.W1 * p.C + 3) >> 2));
+    if (draw2 && p.rng2.state) rng_advance_last_block(p.rng2.state, base, (uint64_t)(((long)p.N * p.H0 * p.W0 * p.C + 3) >> 2));
 }
 
 // backward: DY = gradient w.r.t. the run's last tensor.  Writes (reference in-place convention: each layer's
@@ -184,7 +188,7 @@ int vec_width(int C, const float *X, const t4k_poolblock *b) {
 int check_block(const t4k_poolblock *b, const char *who) {
     if (!b) return fail(T4K_ERR_ARG, "%s: null block", who);
     if (b->pre_layer && !is_act(b->pre_layer))   return fail(T4K_ERR_UNSUPPORTED, "%s: pre layer %d", who, b->pre_layer);
-    if (b->post_layer && (!is_act(b->post_layer) || b->post_layer == T4K_L_DROPOUT)) return fail(T4K_ERR_UNSUPPORTED, "%s: post layer %d", who, b->post_layer);
+    if (b->post_layer && (!is_act(b->post_layer) || (b->post_layer == T4K_L_DROPOUT && b->pre_layer == T4K_L_DROPOUT))) return fail(T4K_ERR_UNSUPPORTED, "%s: post layer %d", who, b->post_layer);   // one dropout per run
     if (b->pool_layer && !is_pool(b->pool_layer)) return fail(T4K_ERR_UNSUPPORTED, "%s: pool layer %d", who, b->pool_layer);
     if (b->pool_layer ? (b->KS != 2 && b->KS != 3) : (b->KS != 1)) return fail(T4K_ERR_UNSUPPORTED, "%s: kernel_size=%d not supported", who, b->KS);
     if (b->pre_layer && (!b->pre_mask || !b->pre_out))    return fail(T4K_ERR_ARG, "%s: pre tensors missing", who);
@@ -207,7 +211,9 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
     p.pre = b->pre_layer; p.pool = b->pool_layer; p.post = b->post_layer; p.a_pre = b->pre_alpha; p.a_post = b->post_alpha;
     p.N = N; p.H1 = H1; p.W1 = W1; p.H0 = H0; p.W0 = W0; p.C = C;
     p.rng = RngArg{0, 0, nullptr};
+    p.rng2 = RngArg{0, 0, nullptr};
     if (b->pre_layer == T4K_L_DROPOUT) p.rng = rng_draw(S(s), (uint64_t)(((long)N * H1 * W1 * C + 3) >> 2), true);
+    if (b->post_layer == T4K_L_DROPOUT) p.rng2 = rng_draw(S(s), (uint64_t)((total + 3) >> 2), true);   // the slice t4k_dropout_mask would draw for the post tensor
     const int VW = vec_width(C, X, b);
     const long nthr = total / VW;
     const int bs = (nthr < (long)BLK * 2 * st().cu_count) ? 64 : BLK;      // small runs: one-wave workgroups reach every CU

@@ -157,7 +157,9 @@ void Model::plan_runs() {
         int j = i, pre = -1, pool = -1, post = -1, flat = -1;
         if (j < L && (is_mact(at(j).grad_fn) || at(j).grad_fn == T4K_L_DROPOUT)) pre = j++;
         if (j < L && is_pool(at(j).grad_fn) && (at(j).H() % at(j).stride[0] == 0) && (at(j).W() % at(j).stride[0] == 0)) pool = j++;
-        if (j < L && is_mact(at(j).grad_fn) && (pool >= 0 || pre >= 0)) post = j++;
+        if (j < L && (pool >= 0 || pre >= 0) &&
+            (is_mact(at(j).grad_fn) || (at(j).grad_fn == T4K_L_DROPOUT && !(pre >= 0 && at(pre).grad_fn == T4K_L_DROPOUT)))) post = j++;   // activation or dropout behind
+                                                                // (`leakyrelu dropout` of the GAN nets, `maxpool dropout` of the CIFAR nets): one dropout per run
         if (j < L && at(j).grad_fn == T4K_L_FLATTEN && j > i) flat = j++;
         if (j - i < 2 && !(j - i == 1 && pre >= 0 && at(pre).grad_fn == T4K_L_DROPOUT)) { i++; continue; }   // a lone dropout still fuses its mask draw
         Run r; r.first = i; r.count = j - i;

@@ -972,3 +972,50 @@ def test_gated_linear_backward_on_concurrent_streams(t4k, dev, oracle, N, E0, E1
             assert rel(j["DB"].cpu().numpy(), DB) < RTOL, "dB stream %d" % k
     finally:
         t4k.call("t4k_stream_destroy", s_lib)
+
+
+@pytest.mark.parametrize("pre,pool,KS,C", [("leaky", None, 1, 8), ("relu", "max", 2, 6), (None, "max", 2, 5), ("tanh", "avg", 3, 4)])
+def test_poolblock_with_dropout_behind(t4k, dev, oracle, pre, pool, KS, C):
+    """A dropout layer as the LAST stage of an element-wise run (`leakyrelu dropout` of the GAN nets, `maxpool dropout` of the CIFAR nets):
+    one launch each way == the oracle's separate layers; the mask is the Philox slice t4k_dropout_mask draws for that tensor."""
+    o = oracle.lib(); P = oracle.P
+    LAY = {"leaky": (oracle.L_LEAKYRL, 0.2), "relu": (oracle.L_RELU, 0.0), "tanh": (oracle.L_TANH, 0.0), "max": oracle.L_MAXPOOL, "avg": oracle.L_AVGPOOL}
+    rng = np.random.default_rng(KS * 10 + C)
+    N, H1 = 4, 12; H0 = H1 // KS
+    n1, n0 = N * H1 * H1 * C, N * H0 * H0 * C
+    X = rng.standard_normal((N, H1, H1, C)).astype(np.float32); DY = rng.standard_normal((N, H0, H0, C)).astype(np.float32)
+    seed, off = 21, 1 << 12
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    ref = {}; x = X
+    if pre:
+        L, a = LAY[pre]; f = np.zeros(n1, np.float32); y = np.zeros_like(X)
+        o.t4o_activate(L, P(x), P(y), P(f), a, n1); ref["pre_mask"] = f.reshape(X.shape); ref["pre_out"] = y; x = y
+    if pool:
+        q = np.zeros((N, H0, H0, C), np.float32); o.t4o_pool(LAY[pool], P(x), P(q), N, H1, H1, H0, H0, C, KS); ref["pool_out"] = q; x = q
+    m = np.zeros(n0, np.float32); o.t4o_dropout_mask(P(m), n0)
+    y = np.zeros((N, H0, H0, C), np.float32); o.t4o_activate(oracle.L_DROPOUT, P(x), P(y), P(m), 0.3, n0)
+    ref["post_mask"] = m.reshape(y.shape); ref["post_out"] = y
+    t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+    d = {k: dev.zeros(v.shape) for k, v in ref.items()}
+    dX = dev.up(X)
+    blk = PoolBlock(); blk.KS = KS
+    if pre: blk.pre_layer, blk.pre_alpha = LAY[pre]; blk.pre_mask = p(d["pre_mask"]); blk.pre_out = p(d["pre_out"])
+    if pool: blk.pool_layer = LAY[pool]; blk.pool_out = p(d["pool_out"])
+    blk.post_layer, blk.post_alpha = oracle.L_DROPOUT, 0.3; blk.post_mask = p(d["post_mask"]); blk.post_out = p(d["post_out"])
+    t4k.call("t4k_poolblock_fwd", p(dX), ctypes.byref(blk), N, H1, H1, H0, H0, C, None)
+    assert np.array_equal(dev.down(d["post_mask"]), ref["post_mask"]) and t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
+    for k_ in ("post_out", "pool_out", "pre_out"):
+        if k_ in ref: assert rel(dev.down(d[k_]), ref[k_]) < 1e-6, k_
+    # backward: gradient through the dropout mask, the pool scatter and the pre activation
+    g = np.zeros(n0, np.float32); o.t4o_tt_op(oracle.MUL, P(DY), P(ref["post_mask"]), P(g), n0)
+    Xb = X.copy(); src = ref["pre_out"].copy() if pre else Xb
+    if pool:
+        o.t4o_dpool(LAY[pool], P(src), P(g), N, H1, H1, H0, H0, C, KS); g1 = src.ravel().copy()
+    else:
+        g1 = g
+    if pre:
+        t = np.zeros(n1, np.float32); o.t4o_tt_op(oracle.MUL, P(g1), P(ref["pre_mask"]), P(t), n1); want = t
+    else:
+        want = g1
+    t4k.call("t4k_poolblock_bwd", p(dev.up(DY)), p(dX), ctypes.byref(blk), N, H1, H1, H0, H0, C, None)
+    assert rel(dev.down(dX).ravel(), want.ravel()) < 1e-6
