@@ -1063,7 +1063,11 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             grid.x += (unsigned)((cs->E + 63) / 64);
         }
     }
-    if (big) {
+    static int plain_big = -1; if (plain_big < 0) { const char *e = getenv("T4K_GEMM_PLAIN_BIG"); plain_big = e ? atoi(e) : 1; }
+    if (big && plain_big && vec && C == 1 && !tA && !tB && alpha == 1.0f && beta == 0.0f && !bias && !p.cs_X && M % 64 == 0 && N % 64 == 0 && K % 128 == 0 &&
+        (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
+        launch_nn_plain(p, dim3((unsigned)((M / 64) * (N / 64))), hs);      // large plain products on the 64x64 LDS-DMA kernel, several tiles per CU
+    } else if (big) {
         const bool full = vec && M % 128 == 0 && N % 128 == 0 && kchunk % 32 == 0 && K % kchunk == 0;
         if (full)     launch_variant<128, 128, 32, true, true, true>(p, grid, tA, tB, hs);
         else if (vec) launch_variant<128, 128, 32, true, true, false>(p, grid, tA, tB, hs);

@@ -1019,3 +1019,15 @@ def test_poolblock_with_dropout_behind(t4k, dev, oracle, pre, pool, KS, C):
         want = g1
     t4k.call("t4k_poolblock_bwd", p(dev.up(DY)), p(dX), ctypes.byref(blk), N, H1, H1, H0, H0, C, None)
     assert rel(dev.down(dX).ravel(), want.ravel()) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (1024, 4096, 384), (4096, 1024, 128)])
+def test_gemm_large_plain_products_exact_on_integer_operands(t4k, dev, M, N, K):
+    """Large plain products (more than one 64x64 tile per CU) run on the same LDS-DMA kernel as the 1024^3 `matmul`: entries in {-2..2}
+    make every partial sum exact in fp32, so the result must equal numpy's integer product bit for bit, whatever the tile order."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-2, 3, (M, K)).astype(np.float32); B = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    want = (A.astype(np.int64) @ B.astype(np.int64)).astype(np.float32)
+    dO = dev.zeros((M, N))
+    t4k.call("t4k_gemm", p(dev.up(A)), p(dev.up(B)), p(dO), 1.0, 0.0, 0, 0, M, N, K, 1, None)
+    assert np.array_equal(dev.down(dO), want)
