@@ -263,6 +263,10 @@ int t4k_onehot(const uint32_t *label_dev, float *hot, int N, int E, t4k_stream_t
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt_dev, t4k_stream_t s);
 /* Dataset::_load dataset.cu:123-158: dst[i] = ((float)src_u8[i] - mean) * scale */
 int t4k_u8_normalize(const uint8_t *src_dev, float *dst, long n, float mean, float scale, t4k_stream_t s);
+/* Dataset::fetch dataset.cu:64-121 (two host-to-device copies + the _load pass) as ONE launch off device-visible staging memory:
+   dst[i] = ((float)src_u8[i] - mean) * scale for i < n, and lab_dst[j] = lab_src[j] for j < nlab (4-byte labels) */
+int t4k_stage_batch(const uint8_t *src, float *dst, long n, float mean, float scale,
+                    const uint32_t *lab_src, uint32_t *lab_dst, int nlab, t4k_stream_t s);
 
 /* ---------------------------------------------- fused MI355X-native launches */
 /* Model::_flinear forward.cu:157-198 in one launch:  Y[N,E0] = X[N,E1] @ W[E0,E1]^T + B[E0] */

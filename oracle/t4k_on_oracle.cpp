@@ -142,6 +142,10 @@ int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float
 int t4k_onehot(const uint32_t *l, float *hot, int N, int E, t4k_stream_t) { return t4o_onehot(l, hot, N, E); }
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t) { return t4o_hit(out, hot, N, E, cnt); }
 int t4k_u8_normalize(const uint8_t *s, float *d, long n, float mean, float scale, t4k_stream_t) { return t4o_u8_normalize(s, d, n, mean, scale); }
+int t4k_stage_batch(const uint8_t *src, float *dst, long n, float mean, float scale, const uint32_t *ls, uint32_t *ld, int nlab, t4k_stream_t) {
+    if (nlab > 0) memcpy(ld, ls, sizeof(uint32_t) * (size_t)nlab);
+    return n > 0 ? t4o_u8_normalize(src, dst, n, mean, scale) : 0;
+}
 int t4k_linear_fwd(const float *X, const float *W, const float *B, float *Y, int N, int E0, int E1, t4k_stream_t) {
     memset(Y, 0, sizeof(float) * (size_t)N * E0);
     return t4o_linear_fwd(X, W, B, Y, N, E0, E1);

@@ -166,6 +166,25 @@ __global__ void __launch_bounds__(BLK) k_u8norm(const uint8_t *__restrict__ src,
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < n; z += (long)gridDim.x * BLK)
         dst[z] = ((float)(int)src[z] - mean) * scale;
 }
+// one batch of a dataset off its pinned staging slot: pixels four to a lane ((x - mean) * scale, 16-byte stores) and the 4-byte labels
+// in the same launch (dataset.cu:64-121 does two host-to-device copies and a normalise pass)
+__global__ void __launch_bounds__(BLK) k_stage_batch(const uint8_t *__restrict__ src, float *dst, long n, float mean, float scale,
+                                                     const uint32_t *__restrict__ lab_src, uint32_t *lab_dst, int nlab, int vec) {
+    const long t0 = (long)blockIdx.x * BLK + threadIdx.x, step = (long)gridDim.x * BLK;
+    if (t0 < nlab) lab_dst[t0] = lab_src[t0];
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long z = t0; z < n4; z += step) {
+            const uint32_t w = reinterpret_cast<const uint32_t *>(src)[z];
+            float4 o;
+            o.x = ((float)(int)(w & 255u) - mean) * scale;         o.y = ((float)(int)((w >> 8) & 255u) - mean) * scale;
+            o.z = ((float)(int)((w >> 16) & 255u) - mean) * scale; o.w = ((float)(int)(w >> 24) - mean) * scale;
+            reinterpret_cast<float4 *>(dst)[z] = o;
+        }
+        for (long z = (n4 << 2) + t0; z < n; z += step) dst[z] = ((float)(int)src[z] - mean) * scale;
+    } else
+        for (long z = t0; z < n; z += step) dst[z] = ((float)(int)src[z] - mean) * scale;
+}
 __global__ void __launch_bounds__(BLK) k_onehot(const uint32_t *__restrict__ label, float *hot, int N, int E) {
     const long total = (long)N * E;
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
@@ -255,6 +274,15 @@ int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t s) {
 int t4k_u8_normalize(const uint8_t *src, float *dst, long n, float mean, float scale, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     hipLaunchKernelGGL(k_u8norm, dim3(grid_for(n)), dim3(BLK), 0, S(s), src, dst, n, mean, scale);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_stage_batch(const uint8_t *src, float *dst, long n, float mean, float scale,
+                    const uint32_t *lab_src, uint32_t *lab_dst, int nlab, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n <= 0 && nlab <= 0) return T4K_OK;
+    if (n < 0 || nlab < 0 || (n > 0 && (!src || !dst)) || (nlab > 0 && (!lab_src || !lab_dst))) return fail(T4K_ERR_ARG, "t4k_stage_batch: bad argument");
+    const int vec = ((uintptr_t)src & 3) == 0 && aligned16(dst);
+    const long lanes = std::max<long>(vec ? (n + 3) >> 2 : n, nlab);
+    hipLaunchKernelGGL(k_stage_batch, dim3(grid_for(lanes)), dim3(BLK), 0, S(s), src, dst, n, mean, scale, lab_src, lab_dst, nlab, vec);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_onehot(const uint32_t *label, float *hot, int N, int E, t4k_stream_t s) {

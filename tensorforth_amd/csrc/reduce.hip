@@ -125,23 +125,29 @@ __global__ void __launch_bounds__(BLK) k_softmax(const float *__restrict__ I, fl
     for (int c = lane; c < C; c += 64) d[c] = d[c] / sm;
 }
 
-// hit count: per-sample first arg-max, then sum of hot[n, argmax]; single block, exact
+// hit count: per-sample FIRST arg-max, then sum of hot[n, argmax]; single block, exact.  G lanes share a sample (G = 1 for class-count
+// sized rows: 256 samples per pass, every thread scans its own row; wider rows take 8 or 64 lanes) - the one-wave-per-sample form this
+// replaces walked a 128 x 10 batch in 32 dependent passes (31 us, the longest kernel of a dataset-fed LeNet step).
+template <int G>
 __global__ void __launch_bounds__(BLK) k_hit(const float *__restrict__ out, const float *__restrict__ hot, int N, int E, int *cnt) {
     __shared__ int sm[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int l = threadIdx.x % G, g = threadIdx.x / G;
     int local = 0;
-    for (int n = w; n < N; n += 4) {
-        const float *o = out + (long)n * E;
+    for (int n0 = 0; n0 < N; n0 += BLK / G) {            // uniform trip count: the shuffles below need every lane of the wave
+        const int n = n0 + g; const bool live = n < N;
+        const float *o = out + (long)(live ? n : 0) * E;
         float m = -FLT_MAX; int idx = 0x7fffffff;
-        for (int e = lane; e < E; e += 64) { float v = o[e]; if (v > m) { m = v; idx = e; } }   // first max within lane
+        if (live) for (int e = l; e < E; e += G) { float v = o[e]; if (v > m) { m = v; idx = e; } }   // first max within lane
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = G >> 1; off > 0; off >>= 1) {
             float m2 = __shfl_xor(m, off, 64); int i2 = __shfl_xor(idx, off, 64);
             if (m2 > m || (m2 == m && i2 < idx)) { m = m2; idx = i2; }
         }
-        if (lane == 0) { if (idx >= E) idx = 0; local += (int)hot[(long)n * E + idx]; }
+        if (live && l == 0) { if (idx >= E) idx = 0; local += (int)hot[(long)n * E + idx]; }
     }
-    if (lane == 0) sm[w] = local;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = local;
     __syncthreads();
     if (threadIdx.x == 0) *cnt = sm[0] + sm[1] + sm[2] + sm[3];
 }
@@ -337,7 +343,9 @@ int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t s) {
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!out || !hot || !cnt || N < 0 || E < 1) return fail(T4K_ERR_ARG, "t4k_hit: bad argument");
-    hipLaunchKernelGGL(k_hit, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
+    if (E <= 32)       hipLaunchKernelGGL(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
+    else if (E <= 256) hipLaunchKernelGGL(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
+    else               hipLaunchKernelGGL(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t s) {

@@ -148,8 +148,7 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     const long NX = (long)n * HWC();
     // The kernels read the pinned staging slot directly over the fabric (hipHostMalloc memory is device visible): no
     // DMA-engine copy, so no cross-engine synchronisation bubble in front of `forward` (measured: 2 H2D copies ~ 40 us/step)
-    chk(t4k_u8_normalize(cp->cur_pix(), data, NX, mean, scale, stream()), "dataset#load");   // (x - mean) * scale on the GPU
-    chk(t4k_copy((const float *)cp->cur_lab(), (float *)label, n, stream()), "dataset#label");   // 4-byte words, bit copy
+    chk(t4k_stage_batch(cp->cur_pix(), data, NX, mean, scale, cp->cur_lab(), label, n, stream()), "dataset#load");   // (x - mean) * scale and the labels, one launch
     t4k_event_record(cp->copied[cp->cur_slot], stream());    // the staging slot may be refilled once these kernels are done
     batch_id++;
     return 0;

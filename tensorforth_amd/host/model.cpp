@@ -374,8 +374,8 @@ Tensor &Model::onehot(Dataset &d) {                     // loss.cpp:47-72
 void Model::hit_lazy() {                                 // count on the GPU now, read it back only if somebody asks (`nn.hit`)
     if (!hot) { hit_ = 0; hit_pending_ = false; return; }
     Tensor &out = at(-1);
-    if (!hit_dev) { void *p; t4k_malloc(&p, 64); hit_dev = (int *)p; }
-    chk(t4k_hit(out.data, hot->data, out.N(), (int)out.HWC(), hit_dev, stream()), "nn#hit");
+    if (!hit_pin) { void *p; chk(t4k_host_alloc(&p, 64), "nn#hit"); hit_pin = (int *)p; }   // device-visible host word: the kernel's store IS the read-back
+    chk(t4k_hit(out.data, hot->data, out.N(), (int)out.HWC(), hit_pin, stream()), "nn#hit");
     hit_pending_ = true;
 }
 // data parallel: `nn.hit` and the loss words report the WHOLE batch when the library owns a communicator - one small
@@ -392,7 +392,8 @@ DU Model::dp_sum(DU v) {
 int Model::hit(bool recalc) {                           // loss.cpp:75-107
     if (recalc) hit_lazy();
     if (hit_pending_) {
-        int c = 0; t4k_memcpy_d2h(&c, hit_dev, sizeof(int), stream()); t4k_sync(stream());
+        t4k_sync(stream());                                // kernel completion makes its store to the pinned word visible (no copy command)
+        const int c = *(volatile int *)hit_pin;
         hit_ = (int)dp_sum((DU)c); hit_pending_ = false;
     }
     return hit_;
@@ -751,6 +752,7 @@ void Model::free_all() {
     if (loss_t) { Store::get().free(*loss_t); loss_t = nullptr; }
     if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }
     if (hit_dev) { t4k_free(hit_dev); hit_dev = nullptr; }
+    if (hit_pin) { t4k_sync(stream()); t4k_host_free(hit_pin); hit_pin = nullptr; }
 }
 
 Model &Store::model(int *trace) { Model *m = new Model(); m->type = T_MODEL; m->trace = trace; put(m); return *m; }

@@ -207,7 +207,7 @@ struct Model : Obj {
     DU   max_norm = 0;
     int *trace = nullptr;
     Tensor *hot = nullptr, *loss_t = nullptr;
-    int  *hit_dev = nullptr;
+    int  *hit_dev = nullptr, *hit_pin = nullptr;          // scalar all-reduce scratch (HBM); hit counter (pinned host, written by k_hit)
 
     Tensor &at(int i) { return *layer[i < 0 ? (int)layer.size() + i : i]; }
     int  batch_size() { return layer.empty() ? 1 : (int)layer[0]->N(); }

@@ -393,6 +393,26 @@ def test_onehot_hit_u8(t4k, dev, oracle):
     o.t4o_u8_normalize(P(u8), P(ref), u8.size, 128.0, 1 / 128.0)
     d = dev.zeros(u8.size); t4k.call("t4k_u8_normalize", p(dev.up(u8)), p(d), u8.size, 128.0, 1 / 128.0, None)
     assert np.array_equal(dev.down(d), ref)
+    for n, nlab in ((128 * 784, 128), (1003, 5), (3, 700), (0, 9)):  # pixels + labels in one launch; ragged tail; more labels than pixel lanes
+        d = dev.zeros(max(n, 1)); dl = dev.zeros(nlab, dev.torch.int32); lab2 = rng.integers(0, 1 << 31, nlab).astype(np.int32)
+        t4k.call("t4k_stage_batch", p(dev.up(u8[:max(n, 1)])), p(d), n, 128.0, 1 / 128.0, p(dev.up(lab2)), p(dl), nlab, None)
+        assert np.array_equal(dev.down(d)[:n], ref[:n]) and np.array_equal(dev.down(dl), lab2), (n, nlab)
+
+
+@pytest.mark.parametrize("N,E", [(128, 10), (77, 10), (300, 7), (1, 1), (513, 32), (64, 100), (301, 256), (37, 1000), (260, 257)])
+def test_hit_count_shapes(t4k, dev, oracle, N, E):
+    """every lanes-per-sample variant of k_hit (1 / 8 / 64), ragged batch counts, ties resolved towards the first maximum"""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N * 1000 + E)
+    out = rng.integers(-3, 4, (N, E)).astype(np.float32)             # small integers: many ties in every row
+    hot = np.zeros((N, E), np.float32); hot[np.arange(N), rng.integers(0, E, N)] = 1.0
+    hot[::3] = 0; hot[::3, 0] = 1.0                                  # a third of the rows point at class 0 (the common first-max)
+    c = ctypes.c_int(0); o.t4o_hit(P(out), P(hot), N, E, ctypes.byref(c))
+    dc = dev.zeros(1, dev.torch.int32)
+    t4k.call("t4k_hit", p(dev.up(out)), p(dev.up(hot)), N, E, p(dc), None)
+    assert int(dev.down(dc)[0]) == c.value
+    want = int(hot[np.arange(N), out.argmax(1)].sum())               # numpy's argmax is the first maximum too
+    assert c.value == want
 
 
 def test_rand_matches_oracle_stream(t4k, dev, oracle):

@@ -1,0 +1,17 @@
+\ PCIe-inclusive rate: LeNet-style CNN trained from the dataset words (IDX file -> host -> HBM u8 -> on-GPU normalise),
+\ one epoch of mini-batches of 128, NO per-batch read-back (the hit kernel still runs inside forward); needs ./data/MNIST/raw (tools/make_synth_mnist.py)
+0 trace
+128 28 28 1 nn.model
+0.5 10 conv2d 2 maxpool relu
+0.5 20 conv2d 0.5 dropout 2 maxpool relu
+flatten 100 linear 0.5 dropout 10 linear softmax
+constant net
+128 dataset mnist_train constant ds0
+variable hits 0 hits !
+: epoch ( N D -- N ) for forward backprop 0.01 0.0 nn.sgd next ;
+net ds0 epoch ds0 rewind drop        \ warm-up epoch
+variable t0 clock t0 !
+0 hits !
+ds0 epoch ds0 rewind drop ds0 epoch ds0 rewind drop ds0 epoch
+clock t0 @ - ." ms_for_3_epochs " . ." hits " hits @ .
+bye
