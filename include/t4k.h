@@ -297,6 +297,12 @@ int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *blk, int N
  * Y as above, ACT_O / ACT_F = activation output / derivative mask of Y; dropout draws the Philox slice t4k_rand would */
 int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y, int layer, float alpha,
                        float *ACT_F, float *ACT_O, int N, int E0, int E1, t4k_stream_t s);
+/* linear layer + the element-wise run behind it (Model::forward's loop over _flinear, _factivate / dropout, forward.cu:82-209) and,
+ * when XCOPY != NULL, the model's copy of the batch into its layer 0 (forward.cu:39: XCOPY[N,E1] = X).  blk (may be NULL) holds the
+ * run: pre and/or post stage (any t4k_layer activation or dropout, at most one dropout), no pool, no flatten copy, KS = 1.  Tensors
+ * written: Y, each stage's mask and output, XCOPY - the same values as t4k_copy + t4k_linear_fwd + t4k_poolblock_fwd. */
+int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const float *B, float *Y, const t4k_poolblock *blk,
+                         int N, int E0, int E1, t4k_stream_t s);
 /* classifier head in one call: [linear E1 -> H + element-wise layer] + [linear H -> E2 (+ softmax when P2 != NULL)] =
  * t4k_linear_act_fwd(X, W1, B1, Y1, layer, alpha, F1, A1) then t4k_linear_softmax_fwd / t4k_linear_fwd on A1, with every
  * tensor written; when the first GEMM is split along K the second layer's launch folds the slabs itself (one launch fewer) */

@@ -155,6 +155,14 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
     if (layer == T4K_L_DROPOUT) t4o_dropout_mask(F, (long)N * E0);
     return rc(t4o_activate(layer, Y, A, F, alpha, (long)N * E0), "k_activate");
 }
+int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t);
+int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const float *B, float *Y, const t4k_poolblock *blk, int N, int E0, int E1, t4k_stream_t st) {
+    if (blk && (blk->pool_layer || blk->copy_out || blk->KS != 1)) return rc(T4K_ERR_UNSUPPORTED, "t4k_linear_block_fwd: the run behind a linear layer has no pool / flatten stage");
+    if (XCOPY && XCOPY != X) t4o_copy(X, XCOPY, (long)N * E1);
+    int r = t4k_linear_fwd(X, W, B, Y, N, E0, E1, st); if (r) return r;
+    if (blk && (blk->pre_layer || blk->post_layer)) return t4k_poolblock_fwd(Y, blk, N, 1, 1, 1, 1, E0, st);
+    return T4K_OK;
+}
 int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, const float *MASK, float *DXM, float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t st) {
     int r = t4k_linear_bwd(X, W, DY, DX, DW, DB, N, E0, E1, tr, st); if (r) return r;
     if (DXM) return rc(t4o_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1), "k_tt_op");

@@ -917,12 +917,28 @@ void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
 // Optional activation epilogue (the layer that follows a linear layer: relu / tanh / ... / dropout): O keeps the linear
 // output, ACT_O / ACT_F receive the activation output and derivative mask (k_activate nmath.cu:37-70); dropout draws its
 // Philox slice here, exactly the values t4k_rand would have stored in the mask tensor.
+// Riders of the fold launch: a second element-wise layer behind the first (the run `leakyrelu dropout` of the GAN nets), and a plain
+// copy done by cp_blocks extra workgroups (the model's copy of the batch into its layer 0, forward.cu:39, rides with the first
+// linear layer's fold instead of taking a launch of its own).
+struct FoldRider { ActEpi ep2; const float *cp_src; float *cp_dst; long cp_n; int cp_blocks, cp_vec; };
 __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ part, float *O, long mn, int nsplit,
-                                                     float alpha, float beta, const float *__restrict__ bias, int N, ActEpi ep) {
+                                                     float alpha, float beta, const float *__restrict__ bias, int N, ActEpi ep, FoldRider fr) {
     uint64_t base = 0, seed = 0;
-    const bool draw = ep.layer == T4K_L_DROPOUT;
-    if (draw) rng_begin(ep.rng, base, seed);
-    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < mn; z += (long)gridDim.x * BLK) {
+    const ActEpi &ep2 = fr.ep2;
+    const bool draw1 = ep.layer == T4K_L_DROPOUT, draw2 = ep2.layer == T4K_L_DROPOUT;      // at most one of the two (one dropout per run)
+    const RngArg &rg = draw2 ? ep2.rng : ep.rng;
+    if (draw1 || draw2) rng_begin(rg, base, seed);
+    const int nfold = (int)gridDim.x - fr.cp_blocks;
+    if ((int)blockIdx.x >= nfold) {
+        const long t0 = (long)((int)blockIdx.x - nfold) * BLK + threadIdx.x, step = (long)fr.cp_blocks * BLK;
+        if (fr.cp_vec) {
+            const long n4 = fr.cp_n >> 2;
+            for (long z = t0; z < n4; z += step) reinterpret_cast<float4 *>(fr.cp_dst)[z] = reinterpret_cast<const float4 *>(fr.cp_src)[z];
+            for (long z = (n4 << 2) + t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
+        } else
+            for (long z = t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
+    } else
+    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < mn; z += (long)nfold * BLK) {
         float s = 0.f;
 #pragma unroll 4
         for (int k = 0; k < nsplit; k++) s += part[(long)k * mn + z];
@@ -930,9 +946,12 @@ __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ p
         if (beta != 0.f) o += O[z] * beta;
         if (bias) o += bias[z % N];
         O[z] = o;
-        if (ep.layer) { float a, f; act_rt(ep.layer, o, draw ? philox_u01_at(base, seed, z) : 0.f, ep.alpha, a, f); ep.F[z] = f; ep.A[z] = a; }
+        if (ep.layer) {
+            float a, f; act_rt(ep.layer, o, draw1 ? philox_u01_at(base, seed, z) : 0.f, ep.alpha, a, f); ep.F[z] = f; ep.A[z] = a;
+            if (ep2.layer) { float a2, f2; act_rt(ep2.layer, a, draw2 ? philox_u01_at(base, seed, z) : 0.f, ep2.alpha, a2, f2); ep2.F[z] = f2; ep2.A[z] = a2; }
+        }
     }
-    if (draw && ep.rng.state) rng_advance_last_block(ep.rng.state, base, (uint64_t)((mn + 3) >> 2));
+    if ((draw1 || draw2) && rg.state) rng_advance_last_block(rg.state, base, (uint64_t)((mn + 3) >> 2));
 }
 
 // words gemm1/gemm2 (k_gemm src/t4math.cu:370, k_gemm_claude :411): double accumulator
@@ -1010,7 +1029,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
 }
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,
                 int tA, int tB, int M, int N, int K, int C, t4k_stream_t s, const ActEpi *epi = nullptr, bool *epi_done = nullptr,
-                ColSum *cs = nullptr, XFold *defer = nullptr) {
+                ColSum *cs = nullptr, XFold *defer = nullptr, FoldRider *rider = nullptr) {   // rider: in ep2 / cp_*, out cp_blocks > 0 when the copy went with the fold
     if (epi_done) *epi_done = false;
     if (defer) defer->part = nullptr;
     if (!A || !B || !O || M < 0 || N < 0 || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_gemm: bad argument");
@@ -1098,11 +1117,22 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     } else if (nsplit > 1 && !p.pair) {
         const long mn = (long)M * N;
         ActEpi ep = {0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
+        FoldRider fr = {ep, nullptr, nullptr, 0, 0, 0};
         if (epi && epi->layer) {
             ep = *epi; if (epi_done) *epi_done = true;
             if (ep.layer == T4K_L_DROPOUT) ep.rng = rng_draw(hs, (uint64_t)((mn + 3) >> 2), true);
+            if (rider && rider->ep2.layer) {
+                fr.ep2 = rider->ep2;
+                if (fr.ep2.layer == T4K_L_DROPOUT) fr.ep2.rng = rng_draw(hs, (uint64_t)((mn + 3) >> 2), true);
+            }
         }
-        hipLaunchKernelGGL(k_splitk_fold, dim3(grid_for(mn)), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N, ep);
+        int gfold = grid_for(mn);
+        if (rider && rider->cp_src && rider->cp_dst && rider->cp_n > 0) {
+            fr.cp_src = rider->cp_src; fr.cp_dst = rider->cp_dst; fr.cp_n = rider->cp_n; fr.cp_vec = aligned16(fr.cp_src) && aligned16(fr.cp_dst);
+            fr.cp_blocks = grid_for(rider->cp_n, 4); if (fr.cp_blocks > 1024) fr.cp_blocks = 1024;
+            rider->cp_blocks = fr.cp_blocks;
+        }
+        hipLaunchKernelGGL(k_splitk_fold, dim3(gfold + fr.cp_blocks), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N, ep, fr);
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;
@@ -1152,6 +1182,39 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
         const long n = (long)N * E0;
         if (layer == T4K_L_DROPOUT) { int rc = t4k_dropout_mask(ACT_F, n, s); if (rc) return rc; }
         return t4k_activate(layer, Y, ACT_O, ACT_F, alpha, n, s);
+    }
+    T4K_LAUNCH_CHECK();
+    return T4K_OK;
+}
+// linear layer + the element-wise run behind it (one or two layers, no pool) + optionally the model's copy of its input batch: when the
+// GEMM is split along K all of it rides in the fold launch; otherwise the same tensors come from the separate launches.
+int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const float *B, float *Y, const t4k_poolblock *blk,
+                         int N, int E0, int E1, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X || !W || !Y || N < 0 || E0 < 1 || E1 < 1) return fail(T4K_ERR_ARG, "t4k_linear_block_fwd: bad argument");
+    int n1 = 0, n2 = 0; float a1 = 0.f, a2 = 0.f; float *F1 = nullptr, *A1 = nullptr, *F2 = nullptr, *A2 = nullptr;
+    if (blk) {
+        if (blk->pool_layer || blk->copy_out || blk->KS != 1) return fail(T4K_ERR_UNSUPPORTED, "t4k_linear_block_fwd: the run behind a linear layer has no pool / flatten stage");
+        if (blk->pre_layer)  { n1 = blk->pre_layer; a1 = blk->pre_alpha; F1 = blk->pre_mask; A1 = blk->pre_out; }
+        if (blk->post_layer) { if (n1) { n2 = blk->post_layer; a2 = blk->post_alpha; F2 = blk->post_mask; A2 = blk->post_out; }
+                               else    { n1 = blk->post_layer; a1 = blk->post_alpha; F1 = blk->post_mask; A1 = blk->post_out; } }
+        if ((n1 && (!F1 || !A1)) || (n2 && (!F2 || !A2))) return fail(T4K_ERR_ARG, "t4k_linear_block_fwd: stage tensors missing");
+        if (n1 == T4K_L_DROPOUT && n2 == T4K_L_DROPOUT) return fail(T4K_ERR_UNSUPPORTED, "t4k_linear_block_fwd: one dropout per run");
+    }
+    if (N == 0) return T4K_OK;
+    bool done = false;
+    FoldRider fr = {ActEpi{n2, a2, F2, A2, RngArg{0, 0, nullptr}}, (XCOPY && XCOPY != X) ? X : nullptr, XCOPY, (long)N * E1, 0, 0};
+    if (linear_small_ok(E0, E1)) linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s));
+    else {
+        ActEpi ep = { n1, a1, F1, A1, RngArg{0, 0, nullptr} };
+        int rc = gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s, &ep, &done, nullptr, nullptr, &fr); if (rc) return rc;
+    }
+    if (XCOPY && !fr.cp_blocks && XCOPY != X) { int rc = t4k_copy(X, XCOPY, (long)N * E1, s); if (rc) return rc; }
+    if (!done && n1) {
+        const long n = (long)N * E0;
+        if (n2) return t4k_poolblock_fwd(Y, blk, N, 1, 1, 1, 1, E0, s);
+        if (n1 == T4K_L_DROPOUT) { int rc = t4k_dropout_mask(F1, n, s); if (rc) return rc; }
+        return t4k_activate(n1, Y, A1, F1, a1, n, s);
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;

@@ -242,7 +242,16 @@ void Model::run_forward(Tensor &input) {
     const bool fused = use_fusion && !(trace && *trace) && !concurrent();
     // layer 0 holds a COPY of the batch (forward.cu:39); a first conv layer reads the batch itself and writes the copy from its own launch
     const bool copy_in_conv = fused && L > 1 && n0.grad_fn == T4K_L_CONV && input.data != n0.data;
-    if (!copy_in_conv) lazy_copy(input.data, n0);
+    // what stands behind linear layer i: 0 nothing fusable, 1 classifier head, 2 lone activation / dropout, 3 element-wise run without pool / flatten
+    auto lin_kind = [&](int i) -> int {
+        if (!(i + 2 < L) || at(i).grad_fn != T4K_L_LINEAR) return 0;
+        const int rn = run_of_[i + 1];
+        if (rn >= 0 && runs_[rn].count >= 2) return (!runs_[rn].blk.pool_layer && !runs_[rn].blk.copy_out) ? 3 : 0;
+        if (!is_eltwise(at(i + 1).grad_fn)) return 0;
+        return (at(i + 2).grad_fn == T4K_L_LINEAR && i + 4 < L && at(i + 3).grad_fn == T4K_L_SOFTMAX) ? 1 : 2;
+    };
+    const bool copy_in_lin = fused && input.data != n0.data && lin_kind(0) >= 2;   // a first linear layer's fold launch carries the layer-0 copy
+    if (!copy_in_conv && !copy_in_lin) lazy_copy(input.data, n0);
     bool masks = false;
     if (concurrent())                                   // side stream: draw every dropout mask up front, in layer order
         for (int i = 0; i + 1 < L; i++)
@@ -265,10 +274,16 @@ void Model::run_forward(Tensor &input) {
             x = lastt.data; i += r.count - 1;
             continue;
         }
-        if (fused && in.grad_fn == T4K_L_LINEAR && i + 2 < L && is_eltwise(out.grad_fn) &&
-            (run_of_[i + 1] < 0 || runs_[run_of_[i + 1]].count == 1)) {   // linear + lone activation / dropout: the activation rides in the GEMM's fold launch
+        if (fused && in.grad_fn == T4K_L_LINEAR && lin_kind(i) == 3) {   // linear + an element-wise run of two (`leakyrelu dropout`): everything rides in the GEMM's fold launch
+            const Run &r = runs_[run_of_[i + 1]];
+            chk(t4k_linear_block_fwd(x, (i == 0 && copy_in_lin) ? n0.data : nullptr, in.grad[0]->data, in.grad[1]->data, out.data, &r.blk,
+                                     out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+run");
+            x = at(i + 1 + r.count).data; i += r.count;
+            continue;
+        }
+        if (fused && in.grad_fn == T4K_L_LINEAR && lin_kind(i) >= 1) {   // linear + lone activation / dropout: the activation rides in the GEMM's fold launch
             Tensor &act = at(i + 2);
-            if (act.grad_fn == T4K_L_LINEAR && i + 4 < L && at(i + 3).grad_fn == T4K_L_SOFTMAX) {
+            if (lin_kind(i) == 1) {
                 // classifier head: [linear + activation] + [linear + softmax] - the second launch folds the first GEMM's split-K slabs
                 Tensor &y2 = at(i + 3), &prob = at(i + 4);
                 chk(t4k_mlp_head_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.grad_fn, out.xparm, out.grad[4]->data, act.data,
@@ -277,8 +292,13 @@ void Model::run_forward(Tensor &input) {
                 x = prob.data; i += 3;
                 continue;
             }
-            chk(t4k_linear_act_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.grad_fn, out.xparm, out.grad[4]->data, act.data,
-                                   out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+act");
+            if (i == 0 && copy_in_lin) {                // the copy of the batch into layer 0 goes with the same launch
+                t4k_poolblock b1; memset(&b1, 0, sizeof(b1)); b1.KS = 1;
+                b1.pre_layer = out.grad_fn; b1.pre_alpha = out.xparm; b1.pre_mask = out.grad[4]->data; b1.pre_out = act.data;
+                chk(t4k_linear_block_fwd(x, n0.data, in.grad[0]->data, in.grad[1]->data, out.data, &b1, out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+act");
+            } else
+                chk(t4k_linear_act_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, out.grad_fn, out.xparm, out.grad[4]->data, act.data,
+                                       out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+act");
             x = act.data; i++;
             continue;
         }

@@ -1051,3 +1051,48 @@ def test_gemm_large_plain_products_exact_on_integer_operands(t4k, dev, M, N, K):
     dO = dev.zeros((M, N))
     t4k.call("t4k_gemm", p(dev.up(A)), p(dev.up(B)), p(dO), 1.0, 0.0, 0, 0, M, N, K, 1, None)
     assert np.array_equal(dev.down(dO), want)
+
+
+@pytest.mark.parametrize("N,E1,E0,stages,copy", [
+    (256, 784, 512, ("leaky", "drop"), True),      # GAN discriminator layer 0: split-K, run of two and the layer-0 copy in the fold launch
+    (256, 512, 256, ("leaky", "drop"), False),
+    (256, 128, 256, ("leaky",), True),             # GAN generator layer 0
+    (64, 300, 128, ("drop", "tanh"), True),        # dropout first, ragged K
+    (2048, 256, 1024, ("relu", "drop"), True),     # output fills the chip: unsplit GEMM, separate launches, same tensors
+    (128, 320, 10, ("relu", "drop"), True),        # classifier-head sized: the vector-ALU linear kernel
+    (32, 100, 64, (), True),                       # no run at all: linear + copy
+])
+def test_linear_block_forward(t4k, dev, oracle, N, E1, E0, stages, copy):
+    """t4k_linear_block_fwd == copy + linear + the element-wise layers of the oracle, one after the other (masks bit-exact, stream position equal)"""
+    o = oracle.lib(); P = oracle.P
+    LAY = {"leaky": (oracle.L_LEAKYRL, 0.2), "relu": (oracle.L_RELU, 0.0), "tanh": (oracle.L_TANH, 0.0), "drop": (oracle.L_DROPOUT, 0.3)}
+    rng = np.random.default_rng(N + E1 + E0)
+    X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) / np.sqrt(E1)).astype(np.float32)
+    B = rng.standard_normal(E0).astype(np.float32)
+    seed, off = 5, 1 << 10
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    Y = np.zeros((N, E0), np.float32); o.t4o_linear_fwd(P(X), P(W), P(B), P(Y), N, E0, E1)
+    ref = []; x = Y
+    for st_ in stages:
+        L, a = LAY[st_]; f = np.zeros(N * E0, np.float32); y = np.zeros_like(Y)
+        if st_ == "drop": o.t4o_dropout_mask(P(f), N * E0)
+        o.t4o_activate(L, P(x), P(y), P(f), a, N * E0); ref.append((f.reshape(Y.shape), y)); x = y
+    t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+    dY = dev.zeros((N, E0)); dC = dev.zeros((N, E1)); d = [(dev.zeros((N, E0)), dev.zeros((N, E0))) for _ in stages]
+    blk = PoolBlock(); blk.KS = 1
+    if len(stages) >= 1:
+        if len(stages) == 2 or stages[0] != "drop":
+            blk.pre_layer, blk.pre_alpha = LAY[stages[0]]; blk.pre_mask = p(d[0][0]); blk.pre_out = p(d[0][1])
+        else:                                       # a lone stage may sit in either slot: exercise `post` for the lone dropout
+            blk.post_layer, blk.post_alpha = LAY[stages[0]]; blk.post_mask = p(d[0][0]); blk.post_out = p(d[0][1])
+    if len(stages) == 2:
+        blk.post_layer, blk.post_alpha = LAY[stages[1]]; blk.post_mask = p(d[1][0]); blk.post_out = p(d[1][1])
+    t4k.call("t4k_linear_block_fwd", p(dev.up(X)), p(dC) if copy else None, p(dev.up(W)), p(dev.up(B)), p(dY),
+             ctypes.byref(blk) if stages else None, N, E0, E1, None)
+    assert t4k.lib.t4k_rand_offset() == o.t4o_rand_offset()
+    assert rel(dev.down(dY), Y) < 2e-6
+    if copy: assert np.array_equal(dev.down(dC), X)
+    for (f, y), (df, dy), st_ in zip(ref, d, stages):
+        if st_ == "drop": assert np.array_equal(dev.down(df), f), "mask"
+        else: assert rel(dev.down(df), f) < 1e-5
+        assert rel(dev.down(dy), y) < 2e-6, st_
