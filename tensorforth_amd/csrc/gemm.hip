@@ -994,7 +994,8 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
 struct ColSum { const float *X; float *out; int rows, E; bool done; };
 bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0; }
 // dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
-// shapes belong to the other kernels (interior tiles -> LDS-DMA kernels, deep K -> split-K, large -> 128x128 tiles)
+// shapes belong to the other kernels (deep K -> split-K, large -> 128x128 tiles).  Interior-tile shapes take it too since round 2
+// (T4K_GEMM_DUAL_FULL=0: the LDS-DMA kernels, 5 launches with their folds and the column sum; GAN round 0.272 -> 0.234 ms)
 bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, hipStream_t hs) {
     State &g = st();
     int *gate = gate_for(hs, 1);                             // nullptr: unknown stream, the two GEMMs go out as separate launches
@@ -1008,7 +1009,8 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     // deep-K shapes would go split-K + fold (2 launches per GEMM); up to K = 1024 the single dual launch, unsplit, is faster (GAN round 0.346 -> 0.322 ms)
     const bool sp = splits(E0, E1, N) || splits(N, E1, E0);
     if (big(E0, E1) || big(N, E1) || (sp && (N > deepk || E0 > deepk))) return false;
-    if ((gemm_variant() & 4) && (full(E0, E1, N) || full(N, E1, E0))) return false;
+    static int dfull = -1; if (dfull < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULL"); dfull = e ? atoi(e) : 1; }
+    if (!dfull && (gemm_variant() & 4) && (full(E0, E1, N) || full(N, E1, E0))) return false;
     const long t1 = tiles(E0, E1), t2 = tiles(N, E1), riders = (E0 + 63) / 64;
     if (t1 + riders + t2 > cu || N > 4096) return false;
     GemmP p1, p2;
