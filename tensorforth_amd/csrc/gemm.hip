@@ -50,8 +50,8 @@ struct GemmP {
     const float *cs_X; float *cs_out; int cs_rows, cs_E;
 };
 
-// FULL: every tile is interior (M%BM == N%BN == K-slice%BK == 0, VEC): no predicates, no branches in
-// the K loop, so the compiler can sink the next stage's loads and address math under the MFMAs.
+// FULL: every K slice is whole stages (K-slice%BK == 0, VEC): no predicates, no branches in the K loop, so the compiler can sink the
+// next stage's loads and address math under the MFMAs.  Ragged M / N edges are handled by clamped source rows and predicated stores.
 // gate (dual launches, see k_gemm_dual): mode 1 = this GEMM READS a buffer the other one overwrites: signal once the K loop
 // has consumed every load; mode 2 = this GEMM is the writer: hold the epilogue stores until gate_n readers have signalled.
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool SKEW, bool FULL>
@@ -123,14 +123,16 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmP &p, const int bx, con
 #pragma unroll
         for (int pp = 0; pp < PA; pp++) {
             const int id = pp * 256 + tid;
-            if (AKC) ga[pp] = reinterpret_cast<const v4f *>(A + (long)(m0 + id / CH) * K + kbeg + (id % CH) * 4);
-            else     ga[pp] = reinterpret_cast<const v4f *>(A + (long)(kbeg + id / (BM / 4)) * M + m0 + (id % (BM / 4)) * 4);
+            // rows / 4-column groups beyond the matrix edge are CLAMPED to the last valid one: the loads stay unpredicated (valid memory,
+            // finite or not - those values only reach accumulator rows / columns the epilogue never stores)
+            if (AKC) ga[pp] = reinterpret_cast<const v4f *>(A + (long)min(m0 + id / CH, M - 1) * K + kbeg + (id % CH) * 4);
+            else     ga[pp] = reinterpret_cast<const v4f *>(A + (long)(kbeg + id / (BM / 4)) * M + min(m0 + (id % (BM / 4)) * 4, M - 4));
         }
 #pragma unroll
         for (int pp = 0; pp < PB; pp++) {
             const int id = pp * 256 + tid;
-            if (BKC) gb[pp] = reinterpret_cast<const v4f *>(B + (long)(n0 + id / CH) * K + kbeg + (id % CH) * 4);
-            else     gb[pp] = reinterpret_cast<const v4f *>(B + (long)(kbeg + id / (BN / 4)) * N + n0 + (id % (BN / 4)) * 4);
+            if (BKC) gb[pp] = reinterpret_cast<const v4f *>(B + (long)min(n0 + id / CH, N - 1) * K + kbeg + (id % CH) * 4);
+            else     gb[pp] = reinterpret_cast<const v4f *>(B + (long)(kbeg + id / (BN / 4)) * N + min(n0 + (id % (BN / 4)) * 4, N - 4));
         }
     }
     const long ga_step = AKC ? BK / 4 : (long)BK * M / 4, gb_step = BKC ? BK / 4 : (long)BK * N / 4;   // in float4
@@ -344,7 +346,7 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmP &p, const int bx, con
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int gm = m0 + wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (FULL || (gm < M && gn < N)) {
+                if (gm < M && gn < N) {
                     float v = acc[mt][nt][0][r];
                     if (NACC == 2) v += acc[mt][nt][NACC - 1][r];
                     if (p.nsplit > 1) {
@@ -377,10 +379,11 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 // Two independent 64x64-tiled GEMMs in ONE launch (a linear layer's dW += dY^T X and dX = dY W): workgroups [0, nb1) run the
 // first, the rest the second.  When the second overwrites an operand of the first (dX lands in X's buffer, backprop.cu:240)
 // its stores wait on an arrival counter; every workgroup is resident (grid <= CU count), so the wait cannot deadlock.
-template <bool A1, bool B1, bool A2, bool B2>
+// F1 / F2: that GEMM's K is whole 64-deep stages -> the predicate-free pipeline with loads two stages ahead (unskewed)
+template <bool A1, bool B1, bool A2, bool B2, bool F1 = false, bool F2 = false>
 __global__ void __launch_bounds__(256) k_gemm_dual(GemmP p1, GemmP p2, int nb1, int t1, int t2, int *gate) {
-    if ((int)blockIdx.x < nb1) gemm_mfma_body<64, 64, 64, A1, B1, true, true, false>(p1, blockIdx.x, 0, 0, gate, 1);
-    else                       gemm_mfma_body<64, 64, 64, A2, B2, true, true, false>(p2, (int)blockIdx.x - nb1, 0, 0, gate, 2, t1, t2);
+    if ((int)blockIdx.x < nb1) gemm_mfma_body<64, 64, 64, A1, B1, true, !F1, F1>(p1, blockIdx.x, 0, 0, gate, 1);
+    else                       gemm_mfma_body<64, 64, 64, A2, B2, true, !F2, F2>(p2, (int)blockIdx.x - nb1, 0, 0, gate, 2, t1, t2);
 }
 
 
@@ -1023,10 +1026,14 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     p1.cs_X = DY; p1.cs_out = DB; p1.cs_rows = N; p1.cs_E = E0;
     fill(p2, DY, W, DX, N, E1, E0, 0.0f);                    // A = dY ([M][K]), B = W ([K][N])
     constexpr size_t lds_bytes = (size_t)2 * (64 + 64) * 64 * sizeof(float);
-    auto kern = k_gemm_dual<false, false, true, false>;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(t1 + riders + t2)), dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate);
+    static int dfk = -1; if (dfk < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULLK"); dfk = e ? atoi(e) : 0; }   // measured on the GAN nets: the skewed kernel is 1 % faster for ragged split-K shapes, off
+    const bool f1 = dfk && N % 64 == 0 && E0 >= 4 && E1 >= 4, f2 = dfk && E0 % 64 == 0 && E1 >= 4;
+    const dim3 grid((unsigned)(t1 + riders + t2));
+#define T4K_DUAL(F1_, F2_) do { auto kern = k_gemm_dual<false, false, true, false, F1_, F2_>; static bool attr_done = false; \
+        if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; } \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate); } while (0)
+    if (f1 && f2) T4K_DUAL(true, true); else if (f1) T4K_DUAL(true, false); else if (f2) T4K_DUAL(false, true); else T4K_DUAL(false, false);
+#undef T4K_DUAL
     return true;
 }
 int gemm_launch(const float *A, const float *B, float *O, const float *bias, float alpha, float beta,
@@ -1112,7 +1119,12 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             case 2:  launch_variant<64, 64, 32, true, true, true>(p, grid, tA, tB, hs); break;
             default: launch_variant<64, 64, 64, true, true, true>(p, grid, tA, tB, hs); break;
             }
-        } else launch_variant<64, 64, 64, true, true, false>(p, grid, tA, tB, hs);
+        } else {
+            static int fk = -1; if (fk < 0) { const char *e = getenv("T4K_GEMM_FULLK"); fk = e ? atoi(e) : 0; }   // measured on the GAN nets: the skewed kernel is 1 % faster for ragged split-K shapes, off
+            const int am = tA ? M : K, bn = tB ? K : N;     // the contiguous extents hold at least one 16-byte group (vec) - the clamp needs M, N >= 4 on the non-K-contiguous side
+            if (fk && kchunk % 64 == 0 && K % kchunk == 0 && M >= 4 && N >= 4 && am >= 4 && bn >= 4) launch_variant<64, 64, 64, true, false, true>(p, grid, tA, tB, hs);   // ragged M / N, whole K stages
+            else launch_variant<64, 64, 64, true, true, false>(p, grid, tA, tB, hs);
+        }
     }
     if (nsplit > 1 && !p.pair && defer && alpha == 1.0f && beta == 0.0f) {      // the consumer folds the slabs (fused head)
         defer->part = p.part; defer->nsplit = nsplit; defer->mn = (long)M * N;
