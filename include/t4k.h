@@ -303,6 +303,13 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
  * written: Y, each stage's mask and output, XCOPY - the same values as t4k_copy + t4k_linear_fwd + t4k_poolblock_fwd. */
 int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const float *B, float *Y, const t4k_poolblock *blk,
                          int N, int E0, int E1, t4k_stream_t s);
+/* backward of the same pair, seen from the linear layer behind the run: t4k_linear_bwd(X, W, DY, DX, DW, DB) of a layer whose input X
+ * was produced by the element-wise run blk (pre and/or post mask-multiply stage, no pool, KS = 1) followed by that run's backward
+ * (t4k_poolblock_bwd(DX, XRUN, blk): the post stage's input buffer = DX * post_mask, XRUN = that * pre_mask; _bactivate
+ * backprop.cu:256-263).  TGT != NULL: DY -= TGT first (backprop's start, backprop.cu:43-53), the difference also stored in DY2 when
+ * that is not NULL.  DX may alias X (the reference's in-place convention). */
+int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float *TGT, float *DY2, float *DX, const t4k_poolblock *blk, float *XRUN,
+                         float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
 /* classifier head in one call: [linear E1 -> H + element-wise layer] + [linear H -> E2 (+ softmax when P2 != NULL)] =
  * t4k_linear_act_fwd(X, W1, B1, Y1, layer, alpha, F1, A1) then t4k_linear_softmax_fwd / t4k_linear_fwd on A1, with every
  * tensor written; when the first GEMM is split along K the second layer's launch folds the slabs itself (one launch fewer) */

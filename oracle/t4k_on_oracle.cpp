@@ -168,6 +168,14 @@ int t4k_linear_bwd2(const float *X, const float *W, const float *DY, float *DX, 
     if (DXM) return rc(t4o_tt_op(T4K_MUL, DX, MASK, DXM, (long)N * E1), "k_tt_op");
     return T4K_OK;
 }
+int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t);
+int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float *TGT, float *DY2, float *DX, const t4k_poolblock *blk, float *XRUN,
+                         float *DW, float *DB, int N, int E0, int E1, int tr, t4k_stream_t st) {
+    if (!blk || blk->pool_layer || blk->copy_out || blk->KS != 1) return rc(T4K_ERR_UNSUPPORTED, "t4k_linear_block_bwd: the run in front of a linear layer has no pool / flatten stage");
+    if (TGT) { int r = t4o_tt_op(T4K_SUB, DY, TGT, DY, (long)N * E0); if (r) return rc(r, "k_tt_op"); if (DY2) t4o_copy(DY, DY2, (long)N * E0); }
+    int r = t4k_linear_bwd(X, W, DY, DX, DW, DB, N, E0, E1, tr, st); if (r) return r;
+    return t4k_poolblock_bwd(DX, XRUN, blk, N, 1, 1, 1, 1, E1, st);
+}
 int t4k_mlp_head_fwd(const float *X, const float *W1, const float *B1, float *Y1, int layer, float alpha, float *F1, float *A1,
                      const float *W2, const float *B2, float *Y2, float *P2, int N, int H, int E1, int E2, t4k_stream_t st) {
     int r = t4k_linear_act_fwd(X, W1, B1, Y1, layer, alpha, F1, A1, N, H, E1, st); if (r) return r;

@@ -35,6 +35,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));       // first-class 16-byte value (HIP's float4 is a struct: its
                                                                // copies become memcpy and can pin staging arrays in scratch)
 
+// mask-multiply backward of the element-wise run in front of a linear layer, applied to dX where it is produced:
+// d1 = dX * m1 (the run's last stage), d2 = d1 * m2 (the stage in front of it); absent stages are nullptr
+struct MaskChain { const float *m1; float *d1; const float *m2; float *d2; };
+
 struct GemmP {
     const float *A, *B;
     const float *bias;                 // optional per-column bias fused in the epilogue (k_bias nmath.cu:27)
@@ -56,12 +60,13 @@ struct GemmP {
 // has consumed every load; mode 2 = this GEMM is the writer: hold the epilogue stores until gate_n readers have signalled.
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool SKEW, bool FULL>
 __device__ __forceinline__ void gemm_mfma_body(const GemmP &p, const int bx, const int by, const int bz,
-                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0) {
+                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
+                                               const MaskChain *mc = nullptr) {
     constexpr int MT = BM / 64, NT = BN / 64;      // 32x32 fragments per wave (wave grid is 2x2)
     constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;   // 16-byte loads per thread per stage
     constexpr int NC = BK / 8;                     // 8-deep k chunks per stage
     constexpr int CH = BK / 4;                     // 16-byte chunks per LDS row of a K-contiguous operand
-    constexpr int SW = 64 / BK;                    // rows per 256-byte LDS bank row
+    constexpr int SW = (64 / BK) > 0 ? (64 / BK) : 1;   // rows per 256-byte LDS bank row
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *sA = lds, *sB = lds + 2 * BM * BK;
 
@@ -357,6 +362,7 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmP &p, const int bx, con
                         if (beta != 0.f) o += (PRE ? oprev[r] : p.O[z]) * beta;
                         if (p.bias) o += p.bias[gn];
                         p.O[z] = o;
+                        if (mc && mc->d1) { const float g1 = o * mc->m1[z]; mc->d1[z] = g1; if (mc->d2) mc->d2[z] = g1 * mc->m2[z]; }
                     }
                 }
             }
@@ -381,9 +387,9 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 // its stores wait on an arrival counter; every workgroup is resident (grid <= CU count), so the wait cannot deadlock.
 // F1 / F2: that GEMM's K is whole 64-deep stages -> the predicate-free pipeline with loads two stages ahead (unskewed)
 template <bool A1, bool B1, bool A2, bool B2, bool F1 = false, bool F2 = false>
-__global__ void __launch_bounds__(256) k_gemm_dual(GemmP p1, GemmP p2, int nb1, int t1, int t2, int *gate) {
+__global__ void __launch_bounds__(256) k_gemm_dual(GemmP p1, GemmP p2, int nb1, int t1, int t2, int *gate, MaskChain mc) {
     if ((int)blockIdx.x < nb1) gemm_mfma_body<64, 64, 64, A1, B1, true, !F1, F1>(p1, blockIdx.x, 0, 0, gate, 1);
-    else                       gemm_mfma_body<64, 64, 64, A2, B2, true, !F2, F2>(p2, (int)blockIdx.x - nb1, 0, 0, gate, 2, t1, t2);
+    else                       gemm_mfma_body<64, 64, 64, A2, B2, true, !F2, F2>(p2, (int)blockIdx.x - nb1, 0, 0, gate, 2, t1, t2, &mc);
 }
 
 
@@ -923,7 +929,7 @@ void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
 // Riders of the fold launch: a second element-wise layer behind the first (the run `leakyrelu dropout` of the GAN nets), and a plain
 // copy done by cp_blocks extra workgroups (the model's copy of the batch into its layer 0, forward.cu:39, rides with the first
 // linear layer's fold instead of taking a launch of its own).
-struct FoldRider { ActEpi ep2; const float *cp_src; float *cp_dst; long cp_n; int cp_blocks, cp_vec; };
+struct FoldRider { ActEpi ep2; const float *cp_src; float *cp_dst; long cp_n; int cp_blocks, cp_vec; MaskChain mc; int mc_done; };
 __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ part, float *O, long mn, int nsplit,
                                                      float alpha, float beta, const float *__restrict__ bias, int N, ActEpi ep, FoldRider fr) {
     uint64_t base = 0, seed = 0;
@@ -949,6 +955,7 @@ __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ p
         if (beta != 0.f) o += O[z] * beta;
         if (bias) o += bias[z % N];
         O[z] = o;
+        if (fr.mc.d1) { const float g1 = o * fr.mc.m1[z]; fr.mc.d1[z] = g1; if (fr.mc.d2) fr.mc.d2[z] = g1 * fr.mc.m2[z]; }
         if (ep.layer) {
             float a, f; act_rt(ep.layer, o, draw1 ? philox_u01_at(base, seed, z) : 0.f, ep.alpha, a, f); ep.F[z] = f; ep.A[z] = a;
             if (ep2.layer) { float a2, f2; act_rt(ep2.layer, a, draw2 ? philox_u01_at(base, seed, z) : 0.f, ep2.alpha, a2, f2); ep2.F[z] = f2; ep2.A[z] = a2; }
@@ -999,7 +1006,8 @@ bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEM
 // dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
 // shapes belong to the other kernels (deep K -> split-K, large -> 128x128 tiles).  Interior-tile shapes take it too since round 2
 // (T4K_GEMM_DUAL_FULL=0: the LDS-DMA kernels, 5 launches with their folds and the column sum; GAN round 0.272 -> 0.234 ms)
-bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, hipStream_t hs) {
+bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, hipStream_t hs,
+                     const MaskChain *mcp = nullptr) {
     State &g = st();
     int *gate = gate_for(hs, 1);                             // nullptr: unknown stream, the two GEMMs go out as separate launches
     if (!dual_on() || !g.d_sync || !gate || (E0 & 3) || (E1 & 3) || !aligned16(DY) || !aligned16(X) || !aligned16(W) || N < 1) return false;
@@ -1026,12 +1034,13 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     p1.cs_X = DY; p1.cs_out = DB; p1.cs_rows = N; p1.cs_E = E0;
     fill(p2, DY, W, DX, N, E1, E0, 0.0f);                    // A = dY ([M][K]), B = W ([K][N])
     constexpr size_t lds_bytes = (size_t)2 * (64 + 64) * 64 * sizeof(float);
-    static int dfk = -1; if (dfk < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULLK"); dfk = e ? atoi(e) : 0; }   // measured on the GAN nets: the skewed kernel is 1 % faster for ragged split-K shapes, off
+    static int dfk = -1; if (dfk < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULLK"); dfk = e ? atoi(e) : 1; }
     const bool f1 = dfk && N % 64 == 0 && E0 >= 4 && E1 >= 4, f2 = dfk && E0 % 64 == 0 && E1 >= 4;
     const dim3 grid((unsigned)(t1 + riders + t2));
+    const MaskChain mc = mcp ? *mcp : MaskChain{nullptr, nullptr, nullptr, nullptr};
 #define T4K_DUAL(F1_, F2_) do { auto kern = k_gemm_dual<false, false, true, false, F1_, F2_>; static bool attr_done = false; \
         if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; } \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate); } while (0)
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate, mc); } while (0)
     if (f1 && f2) T4K_DUAL(true, true); else if (f1) T4K_DUAL(true, false); else if (f2) T4K_DUAL(false, true); else T4K_DUAL(false, false);
 #undef T4K_DUAL
     return true;
@@ -1131,7 +1140,8 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     } else if (nsplit > 1 && !p.pair) {
         const long mn = (long)M * N;
         ActEpi ep = {0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
-        FoldRider fr = {ep, nullptr, nullptr, 0, 0, 0};
+        FoldRider fr = {ep, nullptr, nullptr, 0, 0, 0, MaskChain{nullptr, nullptr, nullptr, nullptr}, 0};
+        if (rider && rider->mc.d1) { fr.mc = rider->mc; rider->mc_done = 1; }
         if (epi && epi->layer) {
             ep = *epi; if (epi_done) *epi_done = true;
             if (ep.layer == T4K_L_DROPOUT) ep.rng = rng_draw(hs, (uint64_t)((mn + 3) >> 2), true);
@@ -1160,7 +1170,8 @@ int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
 bool linear_small_ok(int E0, int E1);
 int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xf = nullptr);
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, bool train, hipStream_t hs,
-                      const float *MASK = nullptr, float *DXM = nullptr, const float *TGT = nullptr, float *DY2 = nullptr);
+                      const float *MASK = nullptr, float *DXM = nullptr, const float *TGT = nullptr, float *DY2 = nullptr,
+                      const float *MASKB = nullptr, float *DXMB = nullptr);
 }
 
 extern "C" {
@@ -1217,7 +1228,7 @@ int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const flo
     }
     if (N == 0) return T4K_OK;
     bool done = false;
-    FoldRider fr = {ActEpi{n2, a2, F2, A2, RngArg{0, 0, nullptr}}, (XCOPY && XCOPY != X) ? X : nullptr, XCOPY, (long)N * E1, 0, 0};
+    FoldRider fr = {ActEpi{n2, a2, F2, A2, RngArg{0, 0, nullptr}}, (XCOPY && XCOPY != X) ? X : nullptr, XCOPY, (long)N * E1, 0, 0, MaskChain{nullptr, nullptr, nullptr, nullptr}, 0};
     if (linear_small_ok(E0, E1)) linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s));
     else {
         ActEpi ep = { n1, a1, F1, A1, RngArg{0, 0, nullptr} };
@@ -1308,6 +1319,34 @@ int t4k_loss_linear_bwd(const float *X, const float *W, float *OUT, const float 
     if (linear_small_ok(E0, E1) && linear_small_bwd(X, W, OUT, DX, DW, DB, N, E0, E1, train != 0, S(s), MASK, DXM, TGT, OUT2)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     int rc = t4k_tt_op2(T4K_SUB, OUT, TGT, OUT, OUT2, (long)N * E0, s); if (rc) return rc;
     return t4k_linear_bwd2(X, W, OUT, DX, MASK, DXM, DW, DB, N, E0, E1, train, s);
+}
+
+// linear backward + the backward of the element-wise run IN FRONT of the layer (the run that produced X), + optionally backprop's
+// `out -= target` start: one launch when the shapes allow (vector-ALU head kernel, or the dual dW || dX launch), else layer by layer
+int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float *TGT, float *DY2, float *DX, const t4k_poolblock *blk, float *XRUN,
+                         float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X || !W || !DY || !DX || !blk || !XRUN || N < 0 || E0 < 1 || E1 < 1) return fail(T4K_ERR_ARG, "t4k_linear_block_bwd: bad argument");
+    if ((DW == nullptr) != (DB == nullptr)) return fail(T4K_ERR_ARG, "t4k_linear_block_bwd: DW and DB go together");
+    if (blk->pool_layer || blk->copy_out || blk->KS != 1 || (!blk->pre_layer && !blk->post_layer)) return fail(T4K_ERR_UNSUPPORTED, "t4k_linear_block_bwd: the run in front of a linear layer has no pool / flatten stage");
+    if ((blk->pre_layer && (!blk->pre_mask || (blk->post_layer && !blk->pre_out))) || (blk->post_layer && !blk->post_mask)) return fail(T4K_ERR_ARG, "t4k_linear_block_bwd: stage tensors missing");
+    if (N == 0) return T4K_OK;
+    MaskChain mc = {nullptr, nullptr, nullptr, nullptr};
+    if (blk->post_layer) { mc.m1 = blk->post_mask; mc.d1 = blk->pre_layer ? blk->pre_out : XRUN; if (blk->pre_layer) { mc.m2 = blk->pre_mask; mc.d2 = XRUN; } }
+    else                 { mc.m1 = blk->pre_mask; mc.d1 = XRUN; }
+    hipStream_t hs = S(s);
+    if (linear_small_ok(E0, E1) && (!TGT || (const float *)DX == X) &&
+        linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, hs, mc.m1, mc.d1, TGT, DY2, mc.m2, mc.d2)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
+    if (TGT) { int rc = t4k_tt_op2(T4K_SUB, DY, TGT, DY, DY2, (long)N * E0, s); if (rc) return rc; }
+    if (train && DW && linear_bwd_dual(X, W, DY, DX, DW, DB, N, E0, E1, hs, &mc)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
+    if (!(train && DW) && !linear_small_ok(E0, E1)) {       // dX only (a frozen net in the middle of a chain): the mask chain rides in the GEMM's fold launch
+        FoldRider fr = {ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}}, nullptr, nullptr, 0, 0, 0, mc, 0};
+        int rc = gemm_launch(DY, W, DX, nullptr, 1.0f, 0.0f, 0, 0, N, E1, E0, 1, s, nullptr, nullptr, nullptr, nullptr, &fr); if (rc) return rc;
+        if (fr.mc_done) return T4K_OK;
+        return t4k_poolblock_bwd(DX, XRUN, blk, N, 1, 1, 1, 1, E1, s);
+    }
+    int rc = t4k_linear_bwd2(X, W, DY, DX, nullptr, nullptr, DW, DB, N, E0, E1, train, s); if (rc) return rc;
+    return t4k_poolblock_bwd(DX, XRUN, blk, N, 1, 1, 1, 1, E1, s);
 }
 
 int t4k_gemm_f64acc(const float *A, const float *B, float *O, float alpha, float beta,

@@ -114,7 +114,8 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
                                                       float *DX, float *DW, float *DB, int N, int E0, int E1,
                                                       int nB, int nA, int RA, int *sync, int alias,
                                                       const float *__restrict__ MASK, float *__restrict__ DXM,
-                                                      const float *__restrict__ TGT, float *DYW, float *DY2) {
+                                                      const float *__restrict__ TGT, float *DYW, float *DY2,
+                                                      const float *__restrict__ MASKB, float *__restrict__ DXMB) {
     // TGT != NULL (alias mode only): dY = DY - TGT is formed while staging (the `out -= target` start of backprop); the dX
     // workgroups store it over DY (= DYW) and into DY2 once every workgroup has staged its share (counter sync[2])
     extern __shared__ float sm[];
@@ -204,7 +205,10 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
             if (n < N) {
                 const long o = (long)n * E1 + (z - r * E1);
                 DX[o] = out[q];
-                if (DXM) DXM[o] = out[q] * MASK[o];             // the mask-multiply backward of the layer in front (dropout / relu ...)
+                if (DXM) {                                       // the mask-multiply backward of the layer(s) in front (dropout / relu ...)
+                    const float g1 = out[q] * MASK[o]; DXM[o] = g1;
+                    if (DXMB) DXMB[o] = g1 * MASKB[o];
+                }
             }
         }
     }
@@ -257,7 +261,8 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
 
 // returns false when the shape does not qualify (caller falls back to the GEMM path)
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
-                      int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM, const float *TGT, float *DY2) {
+                      int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM, const float *TGT, float *DY2,
+                      const float *MASKB, float *DXMB) {
     const int nB = (train && DW) ? E0 : 0;
     int RA = 1024 / E1; if (RA > 64) RA = 64; if (RA < 1) RA = 1;        // rows of dX per workgroup (<= 1024 outputs, <= 64 rows of dY in LDS)
     const int nA = DX ? (N + RA - 1) / RA : 0;
@@ -273,7 +278,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate ? gate : g.d_sync, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2);
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate ? gate : g.d_sync, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
     return true;
 }
 

@@ -554,7 +554,8 @@ void Model::run_backward(Tensor &tgt) {
         if (skip_next_) {                               // bstep also ran the backward of op i-1 (a lone mask-multiply layer)
             skip_next_ = false;
             grads_ready(i, in);
-            dy = at(i - 1).data; i--; j++;
+            const int k = skip_cnt_; skip_cnt_ = 1;
+            dy = at(i - k).data; i -= k; j += k;
             continue;
         }
         grads_ready(i, in);
@@ -609,6 +610,15 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
                 chk(t4k_linear_bwd2(in.data, in.grad[0]->data, dy, in.data, prev.grad[4]->data, prev.data, train ? in.grad[2]->data : nullptr,
                                     train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#blinear+act");
                 skip_next_ = true;
+                return in.data;
+            }
+            // a run of two mask-multiply layers (`leakyrelu dropout`) in front: its backward rides along as well
+            if (fused && i > 1 && run_of_[i - 2] >= 0 && runs_[run_of_[i - 2]].count == 2 && !runs_[run_of_[i - 2]].blk.pool_layer &&
+                !runs_[run_of_[i - 2]].blk.copy_out) {
+                const Run &r = runs_[run_of_[i - 2]];
+                chk(t4k_linear_block_bwd(in.data, in.grad[0]->data, (float *)dy, tg, tg ? at(-2).data : nullptr, in.data, &r.blk, at(i - 2).data,
+                                         train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#blinear+run");
+                skip_next_ = true; skip_cnt_ = 2;
                 return in.data;
             }
             if (tg) chk(t4k_loss_linear_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, in.data, nullptr, nullptr,

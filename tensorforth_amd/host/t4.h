@@ -288,6 +288,7 @@ private:
     void dp_begin_backward();
     void dp_finish();
     Tensor *prep_tgt_ = nullptr;               // `out -= target` pending: the last linear layer's backward launch performs it
+    int  skip_cnt_ = 1;                        // ... how many ops in front it covered
     bool skip_next_ = false;                   // set by bstep when it also ran the backward of the op in front
 };
 

@@ -1096,3 +1096,49 @@ def test_linear_block_forward(t4k, dev, oracle, N, E1, E0, stages, copy):
         if st_ == "drop": assert np.array_equal(dev.down(df), f), "mask"
         else: assert rel(dev.down(df), f) < 1e-5
         assert rel(dev.down(dy), y) < 2e-6, st_
+
+
+@pytest.mark.parametrize("N,E1,E0,stages,train,tgt", [
+    (256, 512, 256, ("leaky", "drop"), 1, False),   # interior tiles: the dual dW || dX launch carries the mask chain
+    (256, 784, 512, ("leaky", "drop"), 1, False),   # ragged E1
+    (256, 256, 1, ("leaky", "drop"), 1, True),      # GAN discriminator head: vector-ALU kernel, `out -= target` in the same launch
+    (256, 512, 256, ("leaky", "drop"), 0, False),   # frozen net: dX only, the chain rides in the split-K fold launch
+    (64, 128, 64, ("relu",), 0, False),             # shallow K: unsplit GEMM, separate launches
+    (128, 320, 100, ("drop",), 1, True),            # lone stage in the post slot + target
+    (2048, 1024, 1024, ("tanh", "drop"), 1, False), # large: 128x128 tiles, layer by layer
+])
+def test_linear_block_backward(t4k, dev, oracle, N, E1, E0, stages, train, tgt):
+    """t4k_linear_block_bwd == (out -= target) + linear backward + the mask multiplies of the run in front, oracle layer by layer"""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N + E1 + E0 + train)
+    X = rng.standard_normal((N, E1)).astype(np.float32); W = (rng.standard_normal((E0, E1)) / np.sqrt(E1)).astype(np.float32)
+    DY = rng.standard_normal((N, E0)).astype(np.float32); T = rng.standard_normal((N, E0)).astype(np.float32)
+    DW0 = rng.standard_normal((E0, E1)).astype(np.float32); DB0 = rng.standard_normal(E0).astype(np.float32)
+    masks = [(rng.random((N, E1)) < 0.6).astype(np.float32) * np.float32(1.5) for _ in stages]    # forward order: stage 0 sits in front
+    dy = DY - T if tgt else DY.copy()
+    DX = np.zeros((N, E1), np.float32); DW = DW0.copy(); DB = DB0.copy()
+    Xc = X.copy()                                                  # keep the array alive across the call
+    o.t4o_linear_bwd(P(Xc), P(W), P(dy), P(DX), P(DW), P(DB), N, E0, E1, train)
+    g = [DX]
+    for m in reversed(masks): g.append(g[-1] * m)                  # last stage first
+    dX = dev.up(X); dDY = dev.up(DY); dDY2 = dev.zeros((N, E0)); dDW = dev.up(DW0); dDB = dev.up(DB0)
+    dm = [dev.up(m) for m in masks]; dpre_out = dev.zeros((N, E1)); dxrun = dev.zeros((N, E1))
+    blk = PoolBlock(); blk.KS = 1
+    if len(stages) == 2:
+        blk.pre_layer = oracle.L_LEAKYRL; blk.pre_mask = p(dm[0]); blk.pre_out = p(dpre_out)
+        blk.post_layer = oracle.L_DROPOUT; blk.post_mask = p(dm[1]); blk.post_out = p(dX)
+    elif stages[0] == "drop":
+        blk.post_layer = oracle.L_DROPOUT; blk.post_mask = p(dm[0]); blk.post_out = p(dX)
+    else:
+        blk.pre_layer = oracle.L_RELU; blk.pre_mask = p(dm[0]); blk.pre_out = p(dX)
+    t4k.call("t4k_linear_block_bwd", p(dX), p(dev.up(W)), p(dDY), p(dev.up(T)) if tgt else None, p(dDY2) if tgt else None, p(dX),
+             ctypes.byref(blk), p(dxrun), p(dDW) if train else None, p(dDB) if train else None, N, E0, E1, train, None)
+    tol = 3e-6 * max(1.0, np.sqrt(max(N, E0) / 256.0))
+    assert rel(dev.down(dX), g[0]) < tol, "dX"
+    if len(stages) == 2: assert rel(dev.down(dpre_out), g[1]) < tol, "post stage input gradient"
+    assert rel(dev.down(dxrun), g[-1]) < tol, "run input gradient"
+    if tgt: assert np.array_equal(dev.down(dDY), dy) and np.array_equal(dev.down(dDY2), dy)
+    if train:
+        assert rel(dev.down(dDW), DW) < tol and rel(dev.down(dDB), DB) < tol
+    else:
+        assert np.array_equal(dev.down(dDW), DW0) and np.array_equal(dev.down(dDB), DB0)
