@@ -261,6 +261,9 @@ int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float
 int t4k_onehot(const uint32_t *label_dev, float *hot, int N, int E, t4k_stream_t s);
 /* Model::hit loss.cpp:75-107: *cnt_dev = sum_n (int)hot[n, argmax_e out[n,e]] (first max wins) */
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt_dev, t4k_stream_t s);
+/* both of the above in one launch (Model::forward on a dataset, forward.cu:57-60: onehot(dset) then hit(true)): hot written from the
+   labels, *cnt_dev = number of rows whose first arg-max is the label's class */
+int t4k_onehot_hit(const uint32_t *label_dev, float *hot, const float *out, int N, int E, int *cnt_dev, t4k_stream_t s);
 /* Dataset::_load dataset.cu:123-158: dst[i] = ((float)src_u8[i] - mean) * scale */
 int t4k_u8_normalize(const uint8_t *src_dev, float *dst, long n, float mean, float scale, t4k_stream_t s);
 /* Dataset::fetch dataset.cu:64-121 (two host-to-device copies + the _load pass) as ONE launch off device-visible staging memory:

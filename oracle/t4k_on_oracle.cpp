@@ -141,6 +141,7 @@ int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float 
 int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd, long n, t4k_stream_t) { return t4o_adamw(G, DG, M, V, lr, b1, b2, wd, n); }
 int t4k_onehot(const uint32_t *l, float *hot, int N, int E, t4k_stream_t) { return t4o_onehot(l, hot, N, E); }
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t) { return t4o_hit(out, hot, N, E, cnt); }
+int t4k_onehot_hit(const uint32_t *l, float *hot, const float *out, int N, int E, int *cnt, t4k_stream_t) { int r = t4o_onehot(l, hot, N, E); return r ? r : t4o_hit(out, hot, N, E, cnt); }
 int t4k_u8_normalize(const uint8_t *s, float *d, long n, float mean, float scale, t4k_stream_t) { return t4o_u8_normalize(s, d, n, mean, scale); }
 int t4k_stage_batch(const uint8_t *src, float *dst, long n, float mean, float scale, const uint32_t *ls, uint32_t *ld, int nlab, t4k_stream_t) {
     if (nlab > 0) memcpy(ld, ls, sizeof(uint32_t) * (size_t)nlab);

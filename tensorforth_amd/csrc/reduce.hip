@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(BLK) k_softmax(const float *__restrict__ I, fl
 // sized rows: 256 samples per pass, every thread scans its own row; wider rows take 8 or 64 lanes) - the one-wave-per-sample form this
 // replaces walked a 128 x 10 batch in 32 dependent passes (31 us, the longest kernel of a dataset-fed LeNet step).
 template <int G>
-__global__ void __launch_bounds__(BLK) k_hit(const float *__restrict__ out, const float *__restrict__ hot, int N, int E, int *cnt) {
+__global__ void __launch_bounds__(BLK) k_hit(const float *__restrict__ out, const float *__restrict__ hot, int N, int E, int *cnt,
+                                             const uint32_t *__restrict__ label = nullptr, float *hot_w = nullptr) {   // label != NULL: also WRITE the one-hot rows (Model::onehot(Dataset&)) and count against the label
     __shared__ int sm[4];
     const int l = threadIdx.x % G, g = threadIdx.x / G;
     int local = 0;
@@ -143,6 +144,11 @@ __global__ void __launch_bounds__(BLK) k_hit(const float *__restrict__ out, cons
             float m2 = __shfl_xor(m, off, 64); int i2 = __shfl_xor(idx, off, 64);
             if (m2 > m || (m2 == m && i2 < idx)) { m = m2; idx = i2; }
         }
+        if (label) {
+            uint32_t m = live ? label[n] : 0u; if (m >= (uint32_t)E) m = 0;
+            if (live) for (int e = l; e < E; e += G) hot_w[(long)n * E + e] = (e == (int)m) ? 1.0f : 0.0f;
+            if (live && l == 0) { if (idx >= E) idx = 0; local += (idx == (int)m) ? 1 : 0; }
+        } else
         if (live && l == 0) { if (idx >= E) idx = 0; local += (int)hot[(long)n * E + idx]; }
     }
 #pragma unroll
@@ -343,9 +349,17 @@ int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t s) {
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!out || !hot || !cnt || N < 0 || E < 1) return fail(T4K_ERR_ARG, "t4k_hit: bad argument");
-    if (E <= 32)       hipLaunchKernelGGL(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
-    else if (E <= 256) hipLaunchKernelGGL(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
-    else               hipLaunchKernelGGL(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt);
+    if (E <= 32)       hipLaunchKernelGGL(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
+    else if (E <= 256) hipLaunchKernelGGL(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
+    else               hipLaunchKernelGGL(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_onehot_hit(const uint32_t *label, float *hot, const float *out, int N, int E, int *cnt, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!label || !out || !hot || !cnt || N < 0 || E < 1) return fail(T4K_ERR_ARG, "t4k_onehot_hit: bad argument");
+    if (E <= 32)       hipLaunchKernelGGL(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
+    else if (E <= 256) hipLaunchKernelGGL(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
+    else               hipLaunchKernelGGL(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t s) {

@@ -225,7 +225,7 @@ Model &Model::forward(Tensor &input) {
         run_forward(input);
         end_capture(g_fwd_, cap);
     }
-    if (input.type == T_DATASET) { onehot((Dataset &)input); hit_lazy(); }
+    if (input.type == T_DATASET) onehot_hit((Dataset &)input);   // labels -> one-hot rows and the hit count, one launch
     NLOG("\n} Model::forward\n");
     return *this;
 }
@@ -390,6 +390,16 @@ Tensor &Model::onehot(Dataset &d) {                     // loss.cpp:47-72
     if ((uint32_t)d.batch_sz < out.N()) hot->zeros();
     chk(t4k_onehot(d.label, hot->data, d.batch_sz, E, stream()), "nn#onehot");
     return *hot;
+}
+void Model::onehot_hit(Dataset &d) {                    // Model::onehot(Dataset&) + hit_lazy() (forward.cu:57-60) in one launch
+    Tensor &out = at(-1);
+    const uint32_t E = (uint32_t)out.HWC();
+    if (!d.label || d.batch_sz < 1 || (uint32_t)d.batch_sz > out.N()) { onehot(d); hit_lazy(); return; }
+    if (!hot) hot = &T4(out.N(), 1, E, 1);
+    if ((uint32_t)d.batch_sz < out.N()) hot->zeros();     // short last batch: the rows past it stay zero and count nothing
+    if (!hit_pin) { void *p; chk(t4k_host_alloc(&p, 64), "nn#hit"); hit_pin = (int *)p; }
+    chk(t4k_onehot_hit(d.label, hot->data, out.data, d.batch_sz, (int)E, hit_pin, stream()), "nn#onehot+hit");
+    hit_pending_ = true;
 }
 void Model::hit_lazy() {                                 // count on the GPU now, read it back only if somebody asks (`nn.hit`)
     if (!hot) { hit_ = 0; hit_pending_ = false; return; }

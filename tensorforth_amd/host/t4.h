@@ -223,6 +223,7 @@ struct Model : Obj {
     Tensor &onehot(Dataset &d);
     int  hit(bool recalc = true);
     DU   dp_sum(DU v);                         // SUM over the data-parallel ranks (identity without a communicator)
+    void onehot_hit(Dataset &d);               // forward(dataset): one-hot rows + hit count in one launch
     void hit_lazy();                           // forward(dataset): enqueue the count, defer the read-back
     bool hit_pending_ = false;
     DU   loss(Loss op);

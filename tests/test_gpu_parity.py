@@ -413,6 +413,12 @@ def test_hit_count_shapes(t4k, dev, oracle, N, E):
     assert int(dev.down(dc)[0]) == c.value
     want = int(hot[np.arange(N), out.argmax(1)].sum())               # numpy's argmax is the first maximum too
     assert c.value == want
+    # labels -> one-hot rows and the count in one launch (labels >= E fall on class 0, as t4k_onehot)
+    lab = rng.integers(0, E + 2, N).astype(np.uint32)
+    hot2 = np.zeros((N, E), np.float32); o.t4o_onehot(P(lab), P(hot2), N, E); c2 = ctypes.c_int(0); o.t4o_hit(P(out), P(hot2), N, E, ctypes.byref(c2))
+    dh = dev.up(np.full((N, E), 7.0, np.float32)); dc.zero_()
+    t4k.call("t4k_onehot_hit", p(dev.up(lab.view(np.int32))), p(dh), p(dev.up(out)), N, E, p(dc), None)
+    assert np.array_equal(dev.down(dh), hot2) and int(dev.down(dc)[0]) == c2.value
 
 
 def test_rand_matches_oracle_stream(t4k, dev, oracle):
