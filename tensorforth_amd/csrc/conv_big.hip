@@ -274,7 +274,8 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
     CbP p = { X, F, B, Y, Y2, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, 0 };
     const long npix = (long)N * Hy * Wy;
     const int tiles_m = (int)((npix + 127) / 128);
-    const bool wide = Cout > 64;
+    static int wmul = -1; if (wmul < 0) { const char *e = getenv("T4K_CONVBIG_WIDE_MUL"); wmul = e ? atoi(e) : 1; }
+    const bool wide = Cout > 64 && (long)tiles_m * ((Cout + 127) / 128) >= (long)st().cu_count * wmul;   // 128-wide tiles only when they still give every CU a workgroup (CIFAR conv3 dX: 128 -> 256 workgroups)
     const int BN = wide ? 128 : 64;
     p.tiles_n = (Cout + BN - 1) / BN;
     const dim3 g((unsigned)(tiles_m * p.tiles_n)), b(256);
