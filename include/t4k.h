@@ -196,6 +196,8 @@ int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t s);
 int t4k_activate(int layer, const float *I, float *O, float *F, float alpha, long n, t4k_stream_t s);
 /* k_softmax_small / k_softmax nmath.cu:74-169: row softmax over C per sample */
 int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t s);
+/* Model::_flogsoftmax forward.cu:245-259 as written there: O[n,c] = exp(I[n,c]) - log10(max(sum_c exp(I[n,c]), 1e-6)) */
+int t4k_logsoftmax(const float *I, float *O, int N, int C, t4k_stream_t s);
 /* k_batchnorm_1/2/3 nmath.cu:177-264 (Model::_fbatchnorm forward.cu:263-309).
  * stat_dev[3C]: [0,C) rvar = 1/(sqrt(max(var,0))+1e-6), [C,2C) mean, [2C,3C) scratch */
 int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B,

@@ -8,6 +8,7 @@
  * expected values in examples/t4_30a/b/c, t4_20a, t4_22a, and (b) as the checker that the GPU
  * `ten4` output is compared with.  The product binary never links or loads this file.
  */
+#include <cmath>
 #include "../include/t4k.h"
 #include "t4_oracle.h"
 #include <stdio.h>
@@ -93,6 +94,15 @@ int t4k_dropout_mask(float *m, long n, t4k_stream_t) { return t4o_dropout_mask(m
 int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t) { return t4o_bias(B, O, N, E0); }
 int t4k_activate(int l, const float *I, float *O, float *F, float a, long n, t4k_stream_t) { return rc(t4o_activate(l, I, O, F, a, n), "k_activate"); }
 int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t) { return t4o_softmax(I, O, N, C); }
+int t4k_logsoftmax(const float *I, float *O, int N, int C, t4k_stream_t) {      // forward.cu:245-259 as written (exp(x) - log10 of the row sum)
+    for (int n = 0; n < N; n++) {
+        const float *x = I + (size_t)n * C; float *o = O + (size_t)n * C; float sum = 0.f;
+        for (int c = 0; c < C; c++) { o[c] = expf(x[c]); sum += o[c]; }
+        const float ls = log10f(fmaxf(sum, 1.0e-6f));
+        for (int c = 0; c < C; c++) o[c] -= ls;
+    }
+    return T4K_OK;
+}
 int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B, float *st, int N, int HW, int C, t4k_stream_t) {
     return t4o_batchnorm_fwd(I, O, XH, W, B, st, N, HW, C);
 }

@@ -125,6 +125,18 @@ __global__ void __launch_bounds__(BLK) k_softmax(const float *__restrict__ I, fl
     for (int c = lane; c < C; c += 64) d[c] = d[c] / sm;
 }
 
+// log-softmax layer as the reference computes it (_flogsoftmax forward.cu:245-259, quirk a-16 kept): O = exp(I) - log10(max(sum_c exp(I), 1e-6)).
+// One thread per row, the sum in index order (the reference sums each row sequentially on one thread as well).
+__global__ void __launch_bounds__(BLK) k_logsoftmax(const float *__restrict__ I, float *O, int N, int C) {
+    const int n = blockIdx.x * BLK + threadIdx.x;
+    if (n >= N) return;
+    const float *x = I + (long)n * C; float *o = O + (long)n * C;
+    float sum = 0.f;
+    for (int c = 0; c < C; c++) { const float e = __expf(x[c]); o[c] = e; sum += e; }
+    const float ls = log10f(fmaxf(sum, 1.0e-6f));
+    for (int c = 0; c < C; c++) o[c] -= ls;
+}
+
 // hit count: per-sample FIRST arg-max, then sum of hot[n, argmax]; single block, exact.  G lanes share a sample (G = 1 for class-count
 // sized rows: 256 samples per pass, every thread scans its own row; wider rows take 8 or 64 lanes) - the one-wave-per-sample form this
 // replaces walked a 128 x 10 batch in 32 dependent passes (31 us, the longest kernel of a dataset-fed LeNet step).
@@ -344,6 +356,12 @@ int t4k_dot(const float *A, const float *B, float *O, float alpha, float beta, i
 int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || C <= 0) return T4K_OK;
     hipLaunchKernelGGL(k_softmax, dim3((N + 3) / 4), dim3(BLK), 0, S(s), I, O, N, C);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_logsoftmax(const float *I, float *O, int N, int C, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (N <= 0 || C <= 0) return T4K_OK;
+    if (!I || !O) return fail(T4K_ERR_ARG, "t4k_logsoftmax: null tensor");
+    hipLaunchKernelGGL(k_logsoftmax, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, S(s), I, O, N, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t s) {

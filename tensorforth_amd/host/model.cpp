@@ -117,7 +117,6 @@ void Model::finalize() {                                // gradient slab: SURVEY
     gx_.assign(layer.size(), nullptr);
     for (int i = 0; i + 1 < (int)layer.size(); i++) {
         Tensor &in = at(i);
-        if (in.grad_fn == T4K_L_LOGSMAX) capturable_ = false;               // host round trip inside the layer
         for (int k = 2; k < 4; k++) if (in.grad[k]) total += pad(in.grad[k]->numel);
         if (use_side && in.grad_fn == T4K_L_LINEAR && i + 2 < (int)layer.size()) gx_[i] = &T4(in.N(), in.H(), in.W(), in.C());
     }
@@ -348,15 +347,8 @@ const float *Model::fstep(Tensor &in, Tensor &out, const float *x) {
     case T4K_L_RELU: case T4K_L_TANH: case T4K_L_SIGMOID: case T4K_L_SELU: case T4K_L_LEAKYRL: case T4K_L_ELU:
         chk(t4k_activate(fn, x, out.data, in.grad[4]->data, in.xparm, (long)in.numel, s), "nn#factivate"); break;
     case T4K_L_SOFTMAX: chk(t4k_softmax(x, out.data, in.N(), (int)in.HWC(), s), "nn#fsoftmax"); break;
-    case T4K_L_LOGSMAX: {                               // _flogsoftmax forward.cu:245-259 (log10 and exp(x) kept: reference bug a-16)
-        chk(t4k_copy(x, out.data, (long)out.numel, s), "copy"); out.map(T4K_EXP);
-        std::vector<float> h; out.to_host(h);
-        for (uint32_t n = 0; n < out.N(); n++) {
-            DU sum = 0; for (uint64_t i = 0; i < out.HWC(); i++) sum += h[n * out.HWC() + i];
-            DU ls = log10f(fmaxf(sum, DU_EPS));
-            t4k_ts_op(T4K_SUB, out.slice(n), ls, out.slice(n), (long)out.HWC(), s);
-        }
-    } break;
+    case T4K_L_LOGSMAX:                                 // _flogsoftmax forward.cu:245-259 (log10 and exp(x) kept: reference bug a-16)
+        chk(t4k_logsoftmax(x, out.data, out.N(), (int)out.HWC(), s), "nn#flogsoftmax"); break;
     case T4K_L_AVGPOOL: case T4K_L_MAXPOOL: case T4K_L_MINPOOL:
         chk(t4k_pool(fn, x, out.data, out.N(), in.H(), in.W(), out.H(), out.W(), out.C(), in.stride[0], s), "nn#fpool"); break;
     case T4K_L_BATCHNM:

@@ -1148,3 +1148,17 @@ def test_linear_block_backward(t4k, dev, oracle, N, E1, E0, stages, train, tgt):
         assert rel(dev.down(dDW), DW) < tol and rel(dev.down(dDB), DB) < tol
     else:
         assert np.array_equal(dev.down(dDW), DW0) and np.array_equal(dev.down(dDB), DB0)
+
+
+@pytest.mark.parametrize("N,C", [(128, 10), (5, 1), (300, 1000), (1, 37)])
+def test_logsoftmax_layer_as_the_reference_writes_it(t4k, dev, N, C):
+    """O = exp(I) - log10(max(sum exp(I), 1e-6)), the row sum taken in index order (_flogsoftmax forward.cu:245-259, quirk a-16)"""
+    rng = np.random.default_rng(N + C)
+    X = (rng.standard_normal((N, C)) * 2).astype(np.float32); X[0, :] = -40.0      # one row whose sum falls below the epsilon floor
+    e = np.exp(X.astype(np.float64)).astype(np.float32)
+    s = np.zeros(N, np.float32)
+    for c in range(C): s = (s + e[:, c]).astype(np.float32)                         # sequential fp32 row sums
+    want = e - np.log10(np.maximum(s, np.float32(1e-6)))[:, None].astype(np.float32)
+    d = dev.zeros((N, C))
+    t4k.call("t4k_logsoftmax", p(dev.up(X)), p(d), N, C, None)
+    np.testing.assert_allclose(dev.down(d), want, rtol=2e-6, atol=2e-6)
