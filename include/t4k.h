@@ -259,6 +259,8 @@ int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float 
 /* k_adamw nmath.cu:456 */
 int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd,
               long n, t4k_stream_t s);
+/* Model::broadcast backprop.cu:17-29: O[N,E] with O[n,e] = T[n] (a per-sample target spread over the output width) */
+int t4k_broadcast_rows(const float *T, float *O, int N, int E, t4k_stream_t s);
 /* Model::onehot(Dataset&) loss.cpp:47-72: hot[N,E] = 0; hot[n, label<E ? label : 0] = 1 */
 int t4k_onehot(const uint32_t *label_dev, float *hot, int N, int E, t4k_stream_t s);
 /* Model::hit loss.cpp:75-107: *cnt_dev = sum_n (int)hot[n, argmax_e out[n,e]] (first max wins) */

@@ -185,6 +185,11 @@ __global__ void __launch_bounds__(BLK) k_stage_batch(const uint8_t *__restrict__
     } else
         for (long z = t0; z < n; z += step) dst[z] = ((float)(int)src[z] - mean) * scale;
 }
+// Model::broadcast backprop.cu:17-29: a [N,1] target spread over the output width, O[n,e] = T[n]
+__global__ void __launch_bounds__(BLK) k_broadcast_rows(const float *__restrict__ T, float *O, int N, int E) {
+    const long total = (long)N * E;
+    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) O[z] = T[z / E];
+}
 __global__ void __launch_bounds__(BLK) k_onehot(const uint32_t *__restrict__ label, float *hot, int N, int E) {
     const long total = (long)N * E;
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
@@ -283,6 +288,12 @@ int t4k_stage_batch(const uint8_t *src, float *dst, long n, float mean, float sc
     const int vec = ((uintptr_t)src & 3) == 0 && aligned16(dst);
     const long lanes = std::max<long>(vec ? (n + 3) >> 2 : n, nlab);
     hipLaunchKernelGGL(k_stage_batch, dim3(grid_for(lanes)), dim3(BLK), 0, S(s), src, dst, n, mean, scale, lab_src, lab_dst, nlab, vec);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_broadcast_rows(const float *T, float *O, int N, int E, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (N <= 0 || E <= 0) return T4K_OK;
+    if (!T || !O) return fail(T4K_ERR_ARG, "t4k_broadcast_rows: null tensor");
+    hipLaunchKernelGGL(k_broadcast_rows, dim3(grid_for((long)N * E)), dim3(BLK), 0, S(s), T, O, N, E);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_onehot(const uint32_t *label, float *hot, int N, int E, t4k_stream_t s) {

@@ -438,9 +438,8 @@ Model &Model::broadcast(Tensor &tgt) {                  // backprop.cu:17-29: [N
     Tensor &out = at(-1);
     const uint64_t HWC = out.HWC(); const uint32_t N = out.N();
     if (!hot) hot = &T4(N, 1, (uint32_t)HWC, 1);
-    std::vector<float> t, h(N * HWC); tgt.to_host(t);
-    for (uint32_t n = 0; n < N && n < t.size(); n++) for (uint64_t i = 0; i < HWC; i++) h[n * HWC + i] = t[n];
-    hot->from_host(h.data(), h.size());
+    if (tgt.numel < N) hot->zeros();                    // a short target fills its rows only
+    chk(t4k_broadcast_rows(tgt.data, hot->data, (int)std::min<uint64_t>(N, tgt.numel), (int)HWC, stream()), "nn#broadcast");
     return *this;
 }
 Model &Model::backprop() {

@@ -198,9 +198,8 @@ Tensor &Tensor::operator=(Tensor &t) { chk(t4k_copy(t.data, data, (long)std::min
 static DU read_scalar() { DU v = 0; t4k_memcpy_d2h(&v, g_scalar, sizeof(DU), stream()); t4k_sync(stream()); return v; }
 
 DU Tensor::sum() {                                      // tensor.cu:224-236
-    DU v = 0;
-    if (numel < 16) { std::vector<float> h; to_host(h); for (float x : h) v += x; }
-    else { chk(t4k_reduce(T4K_RED_SUM, data, (long)numel, 0, g_scalar, stream()), "sum"); v = read_scalar(); }
+    chk(t4k_reduce(T4K_RED_SUM, data, (long)numel, 0, g_scalar, stream()), "sum");    // every size on the device (the reference sums short tensors on the host)
+    DU v = read_scalar();
     return SCALAR(v);
 }
 DU Tensor::avg() { DU v = sum() / numel; return SCALAR(v); }
@@ -275,16 +274,8 @@ Tensor &Tensor::mm(Tensor &A, Tensor &B, Tensor &O, bool inc, bool tA, bool tB) 
 Tensor &Tensor::gemm(int variant, Tensor &A, Tensor &B, Tensor &O, DU alpha, DU beta) {   // words gemm, gemm1..4 (tensor.cu:97-201)
     const uint32_t H = A.H(), W = B.W(), Ka = A.W(), Kb = B.H();
     const uint32_t Na = A.N(), Nb = B.N(), C = B.C(), N = std::max(Na, Nb);
-    if (variant == 0) {                                  // the reference's own host loop: the CPU comparator
-        std::vector<float> a, b, o; A.to_host(a); B.to_host(b); O.to_host(o);
-        const int BLOCK = 32;
-        for (uint32_t i = 0; i < H * W; ++i) o[i] *= beta;
-        for (uint32_t kk = 0; kk < Ka; kk += BLOCK) for (uint32_t mm = 0; mm < H; mm += BLOCK) for (uint32_t nn = 0; nn < W; nn += BLOCK)
-            for (uint32_t k = kk; k < std::min(kk + BLOCK, Ka); ++k) for (uint32_t i = mm; i < std::min(mm + BLOCK, H); ++i) {
-                float av = alpha * a[i * Ka + k];
-                for (uint32_t j = nn; j < std::min(nn + BLOCK, W); ++j) o[i * W + j] += av * b[k * W + j];
-            }
-        O.from_host(o.data(), o.size());
+    if (variant == 0) {                                  // word `gemm` (tensor.cu:97-123: a blocked loop on the HOST in the reference): the MFMA kernel, same alpha / beta
+        chk(t4k_gemm(A.data, B.data, O.data, alpha, beta, 0, 0, H, W, Ka, 1, stream()), "gemm");
         return O;
     }
     if (Ka != Kb || N != O.N() || C != O.C()) { hprintf("  tensor#gemm%d ka(%d)!=kb(%d) or N, C diff\n", variant, Ka, Kb); return O; }
