@@ -382,14 +382,168 @@ template <int BM, int BN, int BK, bool AKC, bool BKC, bool VEC, bool SKEW, bool 
 __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
     gemm_mfma_body<BM, BN, BK, AKC, BKC, VEC, SKEW, FULL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
+// ------------------------------------------------------------------------------------------
+// Latency-shaped GEMM for the slivers of small-batch training (a 256-row batch gives 8..100 tiles of 64x64: most CUs idle, every
+// workgroup a serial chain of memory round trips).  One workgroup = one 32x32 output tile; its four waves split K (k-groups) and
+// fetch their operand fragments STRAIGHT INTO REGISTERS in the MFMA operand layout - no LDS staging, no barriers in the K loop,
+// 64 k of loads in flight per wave before the first MFMA and the next 64 issued under it.  The four partial accumulators meet in
+// LDS once; each wave then finishes a quarter of the tile (alpha / beta / bias, mask chain).  4x the workgroups of the 64x64
+// kernels, each with 1/16 of the matrix work per wave.
+// Operand layout of v_mfma_f32_32x32x2_f32: lane (l31, h) supplies A[row = l31][k] and B[k][col = l31] for one k per instruction;
+// chunk c covers k = 8c + 4h + {0..3}, as in the LDS kernels above.
+template <bool AKC, bool BKC, int CB>
+__device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const float *__restrict__ B, int M, int N, int K, int arow, int bcol,
+                                          int cbeg, int cend, int h, float (&fa)[CB][4], float (&fb)[CB][4]) {
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+        const int ch = cbeg + c, k0 = ch * 8 + 4 * h;
+        const bool ok = ch < cend && k0 < K;
+        if (AKC) {                                                  // A stored [M][K], K % 4 == 0: one 16-byte load
+            const v4f z = {0.f, 0.f, 0.f, 0.f};
+            const v4f t = ok ? *reinterpret_cast<const v4f *>(A + (long)arow * K + k0) : z;
+            fa[c][0] = t[0]; fa[c][1] = t[1]; fa[c][2] = t[2]; fa[c][3] = t[3];
+        } else {                                                    // A stored [K][M]: the 32 lanes of a half wave read one 128-byte run per k
+#pragma unroll
+            for (int j = 0; j < 4; j++) fa[c][j] = (ok && k0 + j < K) ? A[(long)(k0 + j) * M + arow] : 0.f;
+        }
+        if (BKC) {                                                  // B stored [N][K]
+            const v4f z = {0.f, 0.f, 0.f, 0.f};
+            const v4f t = ok ? *reinterpret_cast<const v4f *>(B + (long)bcol * K + k0) : z;
+            fb[c][0] = t[0]; fb[c][1] = t[1]; fb[c][2] = t[2]; fb[c][3] = t[3];
+        } else {                                                    // B stored [K][N]
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[c][j] = (ok && k0 + j < K) ? B[(long)(k0 + j) * N + bcol] : 0.f;
+        }
+    }
+}
+template <bool AKC, bool BKC, int CB>
+__device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, float *red,
+                                              int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
+                                              const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int M = p.M, N = p.N, K = p.K;
+    const int T = p.tiles_m * p.tiles_n;
+    if (bx >= T) {                                 // rider workgroups: cs_out[e] += sum_r cs_X[r, e] (k_dlinear_db nmath.cu:274-280)
+        const int ex = tid & 63, ry = tid >> 6, e = (bx - T) * 64 + ex;
+        float a = 0.f;
+        if (e < p.cs_E) {
+#pragma unroll 8
+            for (int r = ry; r < p.cs_rows; r += 4) a += p.cs_X[(long)r * p.cs_E + e];
+        }
+        red[ry * 64 + ex] = a;
+        __syncthreads();
+        if (ry == 0 && e < p.cs_E) p.cs_out[e] += (red[ex] + red[64 + ex]) + (red[128 + ex] + red[192 + ex]);
+        return;
+    }
+    const int tm = bx / p.tiles_n, tn = bx - tm * p.tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int arow = min(m0 + l31, M - 1), bcol = min(n0 + l31, N - 1);      // clamped: rows / columns past the edge are never stored
+    // this wave's share of the 8-deep k chunks
+    const int nch = (K + 7) >> 3, cpw = (nch + 3) >> 2;
+    const int c0 = w * cpw, c1 = min(nch, c0 + cpw);
+    // the quarter of the tile this wave finishes: accumulator registers 4w .. 4w+3 -> rows (r & 3) + 8 (r >> 2) + 4 h = 8w + 4h + {0..3}
+    const int gn = n0 + l31;
+    float oprev[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.beta != 0.f) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int gm = m0 + 8 * w + 4 * h + q; if (gm < M && gn < N) oprev[q] = p.O[(long)gm * N + gn]; }
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float fa0[CB][4], fb0[CB][4], fa1[CB][4], fb1[CB][4];
+    auto mma = [&](float (&fa)[CB][4], float (&fb)[CB][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][2], fb[c][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][3], fb[c][3], acc1, 0, 0, 0);
+        }
+    };
+    // gate_mode 1 with per-wave slots (gate_n <= 128 reader workgroups): a wave reports as soon as its LAST operand fragments sit in
+    // registers, in front of its last MFMA batch - the writers' wait then overlaps that batch, the LDS reduction and the epilogue
+    const bool early = gate_mode == 1 && gate_n <= 128;
+    auto arrive = [&]() __attribute__((always_inline)) {
+        if (!early) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(slots + 4 * bx + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (c0 < c1) {
+        s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, arow, bcol, c0, c1, h, fa0, fb0);
+        for (int cb = c0; cb < c1; cb += 2 * CB) {
+            if (cb + CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, arow, bcol, cb + CB, c1, h, fa1, fb1);
+            else arrive();
+            mma(fa0, fb0);
+            if (cb + CB < c1) {
+                if (cb + 2 * CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, arow, bcol, cb + 2 * CB, c1, h, fa0, fb0);
+                else arrive();
+                mma(fa1, fb1);
+            }
+        }
+    } else arrive();
+    // the four k-groups meet in LDS: red[w][r][lane]
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[(w * 16 + r) * 64 + lane] = acc0[r] + acc1[r];
+    // In-place dX: a writer waits until the reader workgroups of ITS columns have consumed their loads of the shared buffer.  No
+    // counters: a reader stores this launch's epoch into its slot (fire and forget), the writer's first wave polls those slots with
+    // agent-scope loads until all of them carry the epoch - one store and one load round trip on the critical path, nothing to re-arm.
+    if (gate_mode == 1) {
+        __syncthreads();
+        if (!early && tid == 0) __hip_atomic_store(slots + bx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (gate_mode == 2) {
+        if (w == 0) {
+            // only the readers of the columns this tile overwrites matter: dW tiles (e0t, tn), e0t = 0 .. gate_n / tiles_n - 1 (both GEMMs
+            // have the same column tiling), each with 4 per-wave slots when those fit the 512-int block (gate_n <= 128)
+            const int per = gate_n <= 128 ? 4 : 1, rows = gate_n / p.tiles_n, nslot = rows * per;
+            for (;;) {
+                bool ok = true;
+                unsigned bad = 0;                                  // no short-circuit: the loads of one pass are independent and go out together
+#pragma unroll 4
+                for (int i = lane; i < nslot; i += 64) {
+                    const int e0t = i / per, ww = i - e0t * per;
+                    bad |= __hip_atomic_load(slots + per * (e0t * p.tiles_n + tn) + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ epoch;
+                }
+                ok = bad == 0;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+    } else __syncthreads();
+    const float alpha = p.alpha, beta = p.beta;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = 4 * w + q, gm = m0 + 8 * w + 4 * h + q;
+        const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+        if (gm < M && gn < N) {
+            const long z = (long)gm * N + gn;
+            float o = v * alpha;
+            if (beta != 0.f) o += oprev[q] * beta;
+            if (p.bias) o += p.bias[gn];
+            p.O[z] = o;
+            if (mc && mc->d1) { const float g1 = o * mc->m1[z]; mc->d1[z] = g1; if (mc->d2) mc->d2[z] = g1 * mc->m2[z]; }
+        }
+    }
+}
+// dW += dY^T X (+ dB rider) and dX = dY W of one linear layer on 32x32 tiles (see k_gemm_dual for the gate)
+// CB = k chunks (of 8) per register batch: 8 = 64 k in flight twice over (216 VGPRs, 2 workgroups per CU), 4 = half of that (4 per CU)
+template <int CB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 4 ? 3 : 2))) k_gemm_dual32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, MaskChain mc) {
+    __shared__ float red[4 * 16 * 64];
+    if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, CB>(p1, blockIdx.x, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
+    else                       gemm_s32_body<true, false, CB>(p2, (int)blockIdx.x - nb1, red, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
+}
+
 // Two independent 64x64-tiled GEMMs in ONE launch (a linear layer's dW += dY^T X and dX = dY W): workgroups [0, nb1) run the
 // first, the rest the second.  When the second overwrites an operand of the first (dX lands in X's buffer, backprop.cu:240)
 // its stores wait on an arrival counter; every workgroup is resident (grid <= CU count), so the wait cannot deadlock.
 // F1 / F2: that GEMM's K is whole 64-deep stages -> the predicate-free pipeline with loads two stages ahead (unskewed)
 template <bool A1, bool B1, bool A2, bool B2, bool F1 = false, bool F2 = false>
 __global__ void __launch_bounds__(256) k_gemm_dual(GemmP p1, GemmP p2, int nb1, int t1, int t2, int *gate, MaskChain mc) {
-    if ((int)blockIdx.x < nb1) gemm_mfma_body<64, 64, 64, A1, B1, true, !F1, F1>(p1, blockIdx.x, 0, 0, gate, 1);
-    else                       gemm_mfma_body<64, 64, 64, A2, B2, true, !F2, F2>(p2, (int)blockIdx.x - nb1, 0, 0, gate, 2, t1, t2, &mc);
+    // gate == nullptr: dX does not land in a buffer the dW half reads (no aliasing) - nothing to wait for
+    if ((int)blockIdx.x < nb1) gemm_mfma_body<64, 64, 64, A1, B1, true, !F1, F1>(p1, blockIdx.x, 0, 0, gate, gate ? 1 : 0);
+    else                       gemm_mfma_body<64, 64, 64, A2, B2, true, !F2, F2>(p2, (int)blockIdx.x - nb1, 0, 0, gate, gate ? 2 : 0, t1, t2, &mc);
 }
 
 
@@ -1002,6 +1156,7 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
 }
 
 struct ColSum { const float *X; float *out; int rows, E; bool done; };
+bool capturing(hipStream_t hs) { hipStreamCaptureStatus st_ = hipStreamCaptureStatusNone; return hipStreamIsCapturing(hs, &st_) == hipSuccess && st_ != hipStreamCaptureStatusNone; }   // a replayed graph would repeat the epoch argument
 bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0; }
 // dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
 // shapes belong to the other kernels (deep K -> split-K, large -> 128x128 tiles).  Interior-tile shapes take it too since round 2
@@ -1024,6 +1179,37 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     if (!dfull && (gemm_variant() & 4) && (full(E0, E1, N) || full(N, E1, E0))) return false;
     const long t1 = tiles(E0, E1), t2 = tiles(N, E1), riders = (E0 + 63) / 64;
     if (t1 + riders + t2 > cu || N > 4096) return false;
+    {   // small layers: 32x32 tiles, operands fetched straight into registers (k_gemm_dual32)
+        static int s32 = -1; if (s32 < 0) { const char *e = getenv("T4K_GEMM_DUAL32"); s32 = e ? atoi(e) : 1; }
+        static int cap = -1, cap4 = -1;
+        if (cap < 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gemm_dual32<8>, 256, 0) != hipSuccess) nb = 1; cap = nb * cu;
+                       nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gemm_dual32<4>, 256, 0) != hipSuccess) nb = 1; cap4 = nb * cu; }
+        auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
+        const long a1 = t32(E0, E1), a2 = t32(N, E1), ar = (E0 + 63) / 64;
+        static int maxk = -1; if (maxk < 0) { const char *e = getenv("T4K_GEMM_DUAL32_MAXK"); maxk = e ? atoi(e) : 1024; }
+        if (s32 && a1 + ar + a2 <= cap4 && a1 <= 512 && N <= maxk && E0 <= maxk && N <= 4096 && !capturing(hs)) {      // every workgroup resident (the gate spins); deep K stays with the staged kernels
+            GemmP q1, q2;
+            auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
+                p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
+                p.tiles_m = (M + 31) / 32; p.tiles_n = (Nn + 31) / 32; p.kchunk = K; p.nsplit = 1;
+                p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+            };
+            fill32(q1, DY, X, DW, E0, E1, N, 1.0f);
+            q1.cs_X = DY; q1.cs_out = DB; q1.cs_rows = N; q1.cs_E = E0;
+            fill32(q2, DY, W, DX, N, E1, E0, 0.0f);
+            const bool alias32 = (const float *)DX == X || (const float *)DX == DY || (const float *)DX == W;
+            const MaskChain mc32 = mcp ? *mcp : MaskChain{nullptr, nullptr, nullptr, nullptr};
+            // arrival slots: ints [512, 1024) of the stream's gate block; the epoch is this stream's launch count (never 0, slots cleared when it wraps)
+            unsigned *slots = reinterpret_cast<unsigned *>(gate_for(hs, 0)) + 512;
+            static unsigned epochs[64];
+            const int li = lane_of(hs);
+            unsigned epoch = ++epochs[li < 63 ? li : 63];
+            if (alias32 && epoch == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); epoch = ++epochs[li < 63 ? li : 63]; }
+            if (a1 + ar + a2 <= cap) hipLaunchKernelGGL(k_gemm_dual32<8>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
+            else                     hipLaunchKernelGGL(k_gemm_dual32<4>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
+            return true;
+        }
+    }
     GemmP p1, p2;
     auto fill = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
         p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
@@ -1037,10 +1223,11 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     static int dfk = -1; if (dfk < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULLK"); dfk = e ? atoi(e) : 1; }
     const bool f1 = dfk && N % 64 == 0 && E0 >= 4 && E1 >= 4, f2 = dfk && E0 % 64 == 0 && E1 >= 4;
     const dim3 grid((unsigned)(t1 + riders + t2));
+    const bool alias = (const float *)DX == X || (const float *)DX == DY || (const float *)DX == W;   // only an in-place dX needs the arrival gate
     const MaskChain mc = mcp ? *mcp : MaskChain{nullptr, nullptr, nullptr, nullptr};
 #define T4K_DUAL(F1_, F2_) do { auto kern = k_gemm_dual<false, false, true, false, F1_, F2_>; static bool attr_done = false; \
         if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; } \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, gate, mc); } while (0)
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, alias ? gate : nullptr, mc); } while (0)
     if (f1 && f2) T4K_DUAL(true, true); else if (f1) T4K_DUAL(true, false); else if (f2) T4K_DUAL(false, true); else T4K_DUAL(false, false);
 #undef T4K_DUAL
     return true;

@@ -21,5 +21,7 @@ for (N, E0, E1) in shapes:
     X = torch.rand(N, E1, device="cuda"); W = torch.rand(E0, E1, device="cuda"); G = torch.rand(N, E0, device="cuda") * 1e-3
     DW = torch.zeros(E0, E1, device="cuda"); DB = torch.zeros(E0, device="cuda")
     tb = timeit(lambda: k.call("t4k_linear_bwd", p(X), p(W), p(G), p(X), p(DW), p(DB), N, E0, E1, 1, None))
+    DX = torch.zeros(N, E1, device="cuda")
+    tn = timeit(lambda: k.call("t4k_linear_bwd", p(X), p(W), p(G), p(DX), p(DW), p(DB), N, E0, E1, 1, None))
     fl = 2.0 * N * E0 * E1 * 2
-    print("N=%4d %3d<-%3d: bwd %6.2f us  (%5.1f TFLOP/s)" % (N, E0, E1, tb, fl / tb / 1e6), flush=True)
+    print("N=%4d %3d<-%3d: bwd in place %6.2f us  (%5.1f TFLOP/s)   dX to its own buffer %6.2f us" % (N, E0, E1, tb, fl / tb / 1e6, tn), flush=True)
