@@ -810,6 +810,14 @@ def test_linear_random_shapes(t4k, dev, oracle):
         DW = rng.standard_normal((E0, E1)).astype(np.float32); DB = rng.standard_normal(E0).astype(np.float32); DX = np.zeros_like(X)
         dDW, dDB = dev.up(DW), dev.up(DB)
         o.t4o_linear_bwd(P(X), P(W), P(G), P(DX), P(DW), P(DB), N, E0, E1, 1)
+        dX2, dXk = dev.zeros((N, E1)), dev.up(X)
+        DW0 = rng.standard_normal((E0, E1)).astype(np.float32)      # dX to its own buffer first (no arrival gate in the dual launches), fresh accumulators
+        DWb, DBb, DXb = DW0.copy(), np.zeros(E0, np.float32), np.zeros_like(X)
+        o.t4o_linear_bwd(P(X), P(W), P(G), P(DXb), P(DWb), P(DBb), N, E0, E1, 1)
+        dDWb, dDBb = dev.up(DW0), dev.zeros(E0)
+        t4k.call("t4k_linear_bwd", p(dXk), p(dW), p(dev.up(G)), p(dX2), p(dDWb), p(dDBb), N, E0, E1, 1, None)
+        assert rel(dev.down(dX2), DXb) < RTOL and rel(dev.down(dDWb), DWb) < RTOL and rel(dev.down(dDBb), DBb) < RTOL, tag + " (dX apart)"
+        assert np.array_equal(dev.down(dXk), X), tag + " (X untouched)"
         t4k.call("t4k_linear_bwd", p(dX), p(dW), p(dev.up(G)), p(dX), p(dDW), p(dDB), N, E0, E1, 1, None)      # dX over X
         assert rel(dev.down(dX), DX) < RTOL and rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL, tag
 
