@@ -38,6 +38,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));       // first-class 16-b
 // mask-multiply backward of the element-wise run in front of a linear layer, applied to dX where it is produced:
 // d1 = dX * m1 (the run's last stage), d2 = d1 * m2 (the stage in front of it); absent stages are nullptr
 struct MaskChain { const float *m1; float *d1; const float *m2; float *d2; };
+// riders of a GEMM's last launch (its split-K fold, or the epilogue of the small-tile kernel): see k_splitk_fold
+struct FoldRider { ActEpi ep2; const float *cp_src; float *cp_dst; long cp_n; int cp_blocks, cp_vec; MaskChain mc; int mc_done; };
 
 struct GemmP {
     const float *A, *B;
@@ -392,15 +394,15 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 // Operand layout of v_mfma_f32_32x32x2_f32: lane (l31, h) supplies A[row = l31][k] and B[k][col = l31] for one k per instruction;
 // chunk c covers k = 8c + 4h + {0..3}, as in the LDS kernels above.
 template <bool AKC, bool BKC, int CB>
-__device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const float *__restrict__ B, int M, int N, int K, int arow, int bcol,
-                                          int cbeg, int cend, int h, float (&fa)[CB][4], float (&fb)[CB][4]) {
+__device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const float *__restrict__ B, int M, int N, int ldk, int K, int arow, int bcol,
+                                          int cbeg, int cend, int h, float (&fa)[CB][4], float (&fb)[CB][4], int kbeg) {
 #pragma unroll
     for (int c = 0; c < CB; c++) {
-        const int ch = cbeg + c, k0 = ch * 8 + 4 * h;
+        const int ch = cbeg + c, k0 = kbeg + ch * 8 + 4 * h;       // K here is the END of this workgroup's k range, kbeg its start
         const bool ok = ch < cend && k0 < K;
         if (AKC) {                                                  // A stored [M][K], K % 4 == 0: one 16-byte load
             const v4f z = {0.f, 0.f, 0.f, 0.f};
-            const v4f t = ok ? *reinterpret_cast<const v4f *>(A + (long)arow * K + k0) : z;
+            const v4f t = ok ? *reinterpret_cast<const v4f *>(A + (long)arow * ldk + k0) : z;
             fa[c][0] = t[0]; fa[c][1] = t[1]; fa[c][2] = t[2]; fa[c][3] = t[3];
         } else {                                                    // A stored [K][M]: the 32 lanes of a half wave read one 128-byte run per k
 #pragma unroll
@@ -408,7 +410,7 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
         }
         if (BKC) {                                                  // B stored [N][K]
             const v4f z = {0.f, 0.f, 0.f, 0.f};
-            const v4f t = ok ? *reinterpret_cast<const v4f *>(B + (long)bcol * K + k0) : z;
+            const v4f t = ok ? *reinterpret_cast<const v4f *>(B + (long)bcol * ldk + k0) : z;
             fb[c][0] = t[0]; fb[c][1] = t[1]; fb[c][2] = t[2]; fb[c][3] = t[3];
         } else {                                                    // B stored [K][N]
 #pragma unroll
@@ -419,9 +421,11 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
 template <bool AKC, bool BKC, int CB>
 __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, float *red,
                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
-                                              const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0) {
+                                              const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0,
+                                              const int by = 0, const FoldRider *fe = nullptr, const ActEpi *ep1 = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int M = p.M, N = p.N, K = p.K;
+    const int kbeg = by * p.kchunk, kend = min(K, kbeg + p.kchunk);      // this workgroup's k range (split-K: slab `by`)
     const int T = p.tiles_m * p.tiles_n;
     if (bx >= T) {                                 // rider workgroups: cs_out[e] += sum_r cs_X[r, e] (k_dlinear_db nmath.cu:274-280)
         const int ex = tid & 63, ry = tid >> 6, e = (bx - T) * 64 + ex;
@@ -439,12 +443,12 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     const int m0 = tm * 32, n0 = tn * 32;
     const int arow = min(m0 + l31, M - 1), bcol = min(n0 + l31, N - 1);      // clamped: rows / columns past the edge are never stored
     // this wave's share of the 8-deep k chunks
-    const int nch = (K + 7) >> 3, cpw = (nch + 3) >> 2;
+    const int nch = (kend - kbeg + 7) >> 3, cpw = (nch + 3) >> 2;
     const int c0 = w * cpw, c1 = min(nch, c0 + cpw);
     // the quarter of the tile this wave finishes: accumulator registers 4w .. 4w+3 -> rows (r & 3) + 8 (r >> 2) + 4 h = 8w + 4h + {0..3}
     const int gn = n0 + l31;
     float oprev[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.beta != 0.f) {
+    if (p.beta != 0.f && p.nsplit == 1) {
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int gm = m0 + 8 * w + 4 * h + q; if (gm < M && gn < N) oprev[q] = p.O[(long)gm * N + gn]; }
     }
@@ -470,13 +474,13 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         if (lane == 0) __hip_atomic_store(slots + 4 * bx + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (c0 < c1) {
-        s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, arow, bcol, c0, c1, h, fa0, fb0);
+        s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg);
         for (int cb = c0; cb < c1; cb += 2 * CB) {
-            if (cb + CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, arow, bcol, cb + CB, c1, h, fa1, fb1);
+            if (cb + CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, kend, arow, bcol, cb + CB, c1, h, fa1, fb1, kbeg);
             else arrive();
             mma(fa0, fb0);
             if (cb + CB < c1) {
-                if (cb + 2 * CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, arow, bcol, cb + 2 * CB, c1, h, fa0, fb0);
+                if (cb + 2 * CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, kend, arow, bcol, cb + 2 * CB, c1, h, fa0, fb0, kbeg);
                 else arrive();
                 mma(fa1, fb1);
             }
@@ -518,13 +522,40 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
         if (gm < M && gn < N) {
             const long z = (long)gm * N + gn;
+            if (p.nsplit > 1) { p.part[(long)by * M * N + z] = v; continue; }       // split-K slab: the consumer folds (XFold / k_splitk_fold)
             float o = v * alpha;
             if (beta != 0.f) o += oprev[q] * beta;
             if (p.bias) o += p.bias[gn];
             p.O[z] = o;
             if (mc && mc->d1) { const float g1 = o * mc->m1[z]; mc->d1[z] = g1; if (mc->d2) mc->d2[z] = g1 * mc->m2[z]; }
+            if (ep1 && ep1->layer) {                                              // element-wise layer(s) behind a linear layer: as k_splitk_fold
+                const bool d1 = ep1->layer == T4K_L_DROPOUT, d2 = fe && fe->ep2.layer == T4K_L_DROPOUT;
+                float u = 0.f;
+                if (d1 || d2) { uint64_t base, seed; rng_begin(d2 ? fe->ep2.rng : ep1->rng, base, seed); u = philox_u01_at(base, seed, z); }
+                float a, f; act_rt(ep1->layer, o, d1 ? u : 0.f, ep1->alpha, a, f); ep1->F[z] = f; ep1->A[z] = a;
+                if (fe && fe->ep2.layer) { float a2, f2; act_rt(fe->ep2.layer, a, d2 ? u : 0.f, fe->ep2.alpha, a2, f2); fe->ep2.F[z] = f2; fe->ep2.A[z] = a2; }
+            }
         }
     }
+}
+// one GEMM on 32x32 tiles (see gemm_s32_body): grid = (tiles + column-sum riders + copy riders, k slabs); epilogue riders as the fold launch's
+template <bool AKC, bool BKC, int CB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 4 ? 3 : 2))) k_gemm_s32(GemmP p, ActEpi ep, FoldRider fr) {
+    __shared__ float red[4 * 16 * 64];
+    const int nwork = (int)gridDim.x - fr.cp_blocks;
+    if ((int)blockIdx.x >= nwork) {                              // the model's copy of the batch into its layer 0 rides along (forward.cu:39)
+        if (blockIdx.y) return;
+        const long t0 = (long)((int)blockIdx.x - nwork) * 256 + threadIdx.x, step = (long)fr.cp_blocks * 256;
+        if (fr.cp_vec) {
+            const long n4 = fr.cp_n >> 2;
+            for (long z = t0; z < n4; z += step) reinterpret_cast<float4 *>(fr.cp_dst)[z] = reinterpret_cast<const float4 *>(fr.cp_src)[z];
+            for (long z = (n4 << 2) + t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
+        } else
+            for (long z = t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
+        return;
+    }
+    if ((int)blockIdx.x >= p.tiles_m * p.tiles_n && blockIdx.y) return;   // column-sum riders run once
+    gemm_s32_body<AKC, BKC, CB>(p, blockIdx.x, red, nullptr, 0, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
 }
 // dW += dY^T X (+ dB rider) and dX = dY W of one linear layer on 32x32 tiles (see k_gemm_dual for the gate)
 // CB = k chunks (of 8) per register batch: 8 = 64 k in flight twice over (216 VGPRs, 2 workgroups per CU), 4 = half of that (4 per CU)
@@ -1083,7 +1114,6 @@ void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
 // Riders of the fold launch: a second element-wise layer behind the first (the run `leakyrelu dropout` of the GAN nets), and a plain
 // copy done by cp_blocks extra workgroups (the model's copy of the batch into its layer 0, forward.cu:39, rides with the first
 // linear layer's fold instead of taking a launch of its own).
-struct FoldRider { ActEpi ep2; const float *cp_src; float *cp_dst; long cp_n; int cp_blocks, cp_vec; MaskChain mc; int mc_done; };
 __global__ void __launch_bounds__(BLK) k_splitk_fold(const float *__restrict__ part, float *O, long mn, int nsplit,
                                                      float alpha, float beta, const float *__restrict__ bias, int N, ActEpi ep, FoldRider fr) {
     uint64_t base = 0, seed = 0;
@@ -1253,6 +1283,57 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     p.tiles_m = (M + BMv - 1) / BMv; p.tiles_n = (N + BMv - 1) / BMv;
     const long tiles = (long)p.tiles_m * p.tiles_n;
 
+    // Slivers (the output gives at most half the CUs a 64x64 tile, K moderate): 32x32 tiles with operands fetched straight into
+    // registers, the whole epilogue (bias, activation riders, mask chain, layer-0 copy, column sums) in the same launch - no fold
+    {
+        static int s32 = -1; if (s32 < 0) { const char *e = getenv("T4K_GEMM_S32"); s32 = e ? atoi(e) : 1; }
+        static int maxk = -1; if (maxk < 0) { const char *e = getenv("T4K_GEMM_S32_MAXK"); maxk = e ? atoi(e) : 1024; }
+        const bool akc = !tA, bkc = tB != 0;
+        const bool al = (!akc || (K % 4 == 0 && aligned16(A))) && (!bkc || (K % 4 == 0 && aligned16(B)));
+        if (s32 && C == 1 && !big && tiles * 2 <= st().cu_count && K >= 1 && K <= maxk && al && !capturing(S(s))) {
+            hipStream_t hs2 = S(s);
+            p.tiles_m = (M + 31) / 32; p.tiles_n = (N + 31) / 32;
+            const long t32 = (long)p.tiles_m * p.tiles_n;
+            int ns = 1, kc = ((K + 7) / 8) * 8;
+            if (defer && alpha == 1.0f && beta == 0.0f && K >= 256) {           // a consumer folds the slabs anyway: spread K over idle CUs
+                int want = (int)((st().cu_count + t32 - 1) / t32); if (want > K / 128) want = K / 128; if (want > 16) want = 16;
+                if (want > 1) { kc = (((K + want - 1) / want) + 7) / 8 * 8; ns = (K + kc - 1) / kc; }
+                if ((size_t)ns * M * N * sizeof(float) > st().ws_bytes / 2) { ns = 1; kc = ((K + 7) / 8) * 8; }
+            }
+            p.kchunk = kc; p.nsplit = ns; p.pair = 0; p.sync = st().d_sync;
+            p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+            unsigned gx = (unsigned)t32;
+            if (cs && ns == 1 && cs->rows > 0 && cs->rows <= 4096 && cs->E > 0) {
+                p.cs_X = cs->X; p.cs_out = cs->out; p.cs_rows = cs->rows; p.cs_E = cs->E; cs->done = true; gx += (unsigned)((cs->E + 63) / 64);
+            }
+            const long mn = (long)M * N;
+            ActEpi ep = {0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
+            FoldRider fr = {ep, nullptr, nullptr, 0, 0, 0, MaskChain{nullptr, nullptr, nullptr, nullptr}, 0};
+            if (ns == 1) {
+                if (epi && epi->layer) {
+                    ep = *epi; if (epi_done) *epi_done = true;
+                    if (ep.layer == T4K_L_DROPOUT) ep.rng = rng_draw(hs2, (uint64_t)((mn + 3) >> 2), true);
+                    if (rider && rider->ep2.layer) {
+                        fr.ep2 = rider->ep2;
+                        if (fr.ep2.layer == T4K_L_DROPOUT) fr.ep2.rng = rng_draw(hs2, (uint64_t)((mn + 3) >> 2), true);
+                    }
+                }
+                if (rider && rider->mc.d1) { fr.mc = rider->mc; rider->mc_done = 1; }
+                if (rider && rider->cp_src && rider->cp_dst && rider->cp_n > 0) {
+                    fr.cp_src = rider->cp_src; fr.cp_dst = rider->cp_dst; fr.cp_n = rider->cp_n; fr.cp_vec = aligned16(fr.cp_src) && aligned16(fr.cp_dst);
+                    fr.cp_blocks = grid_for(rider->cp_n, 16); if (fr.cp_blocks > 128) fr.cp_blocks = 128;
+                    rider->cp_blocks = fr.cp_blocks; gx += (unsigned)fr.cp_blocks;
+                }
+            } else { defer->part = p.part; defer->nsplit = ns; defer->mn = mn; }
+            const dim3 g32(gx, (unsigned)ns);
+#define T4K_S32(A_, B_) do { if (t32 * ns > 2L * st().cu_count) hipLaunchKernelGGL((k_gemm_s32<A_, B_, 4>), g32, dim3(256), 0, hs2, p, ep, fr); \
+                             else                                hipLaunchKernelGGL((k_gemm_s32<A_, B_, 8>), g32, dim3(256), 0, hs2, p, ep, fr); } while (0)
+            if (akc && !bkc) T4K_S32(true, false); else if (akc) T4K_S32(true, true); else if (!bkc) T4K_S32(false, false); else T4K_S32(false, true);
+#undef T4K_S32
+            T4K_LAUNCH_CHECK();
+            return T4K_OK;
+        }
+    }
     // split K when the output alone cannot fill the chip (granularity = the deepest stage, 64)
     constexpr int KG = 64;
     int nsplit = 1, kchunk = ((K + KG - 1) / KG) * KG; if (kchunk == 0) kchunk = KG;
