@@ -418,7 +418,7 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
         }
     }
 }
-template <bool AKC, bool BKC, int CB>
+template <bool AKC, bool BKC, int CB, int NW = 4>   // NW waves = NW k-groups per 32x32 tile
 __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, float *red,
                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
                                               const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0,
@@ -430,11 +430,11 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     if (bx >= T) {                                 // rider workgroups: cs_out[e] += sum_r cs_X[r, e] (k_dlinear_db nmath.cu:274-280)
         const int ex = tid & 63, ry = tid >> 6, e = (bx - T) * 64 + ex;
         float a = 0.f;
-        if (e < p.cs_E) {
+        if (e < p.cs_E && ry < 4) {
 #pragma unroll 8
             for (int r = ry; r < p.cs_rows; r += 4) a += p.cs_X[(long)r * p.cs_E + e];
         }
-        red[ry * 64 + ex] = a;
+        if (ry < 4) red[ry * 64 + ex] = a;
         __syncthreads();
         if (ry == 0 && e < p.cs_E) p.cs_out[e] += (red[ex] + red[64 + ex]) + (red[128 + ex] + red[192 + ex]);
         return;
@@ -443,14 +443,17 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     const int m0 = tm * 32, n0 = tn * 32;
     const int arow = min(m0 + l31, M - 1), bcol = min(n0 + l31, N - 1);      // clamped: rows / columns past the edge are never stored
     // this wave's share of the 8-deep k chunks
-    const int nch = (kend - kbeg + 7) >> 3, cpw = (nch + 3) >> 2;
+    const int nch = (kend - kbeg + 7) >> 3, cpw = (nch + NW - 1) / NW;
     const int c0 = w * cpw, c1 = min(nch, c0 + cpw);
-    // the quarter of the tile this wave finishes: accumulator registers 4w .. 4w+3 -> rows (r & 3) + 8 (r >> 2) + 4 h = 8w + 4h + {0..3}
+    // the share of the tile this wave finishes: accumulator registers QN w .. QN w + QN - 1 (QN = 16 / NW), row of register r = (r & 3) + 8 (r >> 2) + 4 h
+    constexpr int QN = 16 / NW;
     const int gn = n0 + l31;
-    float oprev[4] = {0.f, 0.f, 0.f, 0.f};
+    float oprev[QN];
+#pragma unroll
+    for (int q = 0; q < QN; q++) oprev[q] = 0.f;
     if (p.beta != 0.f && p.nsplit == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int gm = m0 + 8 * w + 4 * h + q; if (gm < M && gn < N) oprev[q] = p.O[(long)gm * N + gn]; }
+        for (int q = 0; q < QN; q++) { const int r = QN * w + q, gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h; if (gm < M && gn < N) oprev[q] = p.O[(long)gm * N + gn]; }
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -517,9 +520,11 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     } else __syncthreads();
     const float alpha = p.alpha, beta = p.beta;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int r = 4 * w + q, gm = m0 + 8 * w + 4 * h + q;
-        const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+    for (int q = 0; q < QN; q++) {
+        const int r = QN * w + q, gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = red[r * 64 + lane];
+#pragma unroll
+        for (int g = 1; g < NW; g++) v += red[(g * 16 + r) * 64 + lane];         // k-groups in order
         if (gm < M && gn < N) {
             const long z = (long)gm * N + gn;
             if (p.nsplit > 1) { p.part[(long)by * M * N + z] = v; continue; }       // split-K slab: the consumer folds (XFold / k_splitk_fold)
@@ -539,13 +544,13 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     }
 }
 // one GEMM on 32x32 tiles (see gemm_s32_body): grid = (tiles + column-sum riders + copy riders, k slabs); epilogue riders as the fold launch's
-template <bool AKC, bool BKC, int CB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 4 ? 3 : 2))) k_gemm_s32(GemmP p, ActEpi ep, FoldRider fr) {
-    __shared__ float red[4 * 16 * 64];
+template <bool AKC, bool BKC, int CB, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CB == 4 ? 3 : 2))) k_gemm_s32(GemmP p, ActEpi ep, FoldRider fr) {
+    __shared__ float red[NW * 16 * 64];
     const int nwork = (int)gridDim.x - fr.cp_blocks;
     if ((int)blockIdx.x >= nwork) {                              // the model's copy of the batch into its layer 0 rides along (forward.cu:39)
         if (blockIdx.y) return;
-        const long t0 = (long)((int)blockIdx.x - nwork) * 256 + threadIdx.x, step = (long)fr.cp_blocks * 256;
+        const long t0 = (long)((int)blockIdx.x - nwork) * (64 * NW) + threadIdx.x, step = (long)fr.cp_blocks * (64 * NW);
         if (fr.cp_vec) {
             const long n4 = fr.cp_n >> 2;
             for (long z = t0; z < n4; z += step) reinterpret_cast<float4 *>(fr.cp_dst)[z] = reinterpret_cast<const float4 *>(fr.cp_src)[z];
@@ -555,7 +560,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 
         return;
     }
     if ((int)blockIdx.x >= p.tiles_m * p.tiles_n && blockIdx.y) return;   // column-sum riders run once
-    gemm_s32_body<AKC, BKC, CB>(p, blockIdx.x, red, nullptr, 0, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
+    gemm_s32_body<AKC, BKC, CB, NW>(p, blockIdx.x, red, nullptr, 0, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
 }
 // dW += dY^T X (+ dB rider) and dX = dY W of one linear layer on 32x32 tiles (see k_gemm_dual for the gate)
 // CB = k chunks (of 8) per register batch: 8 = 64 k in flight twice over (216 VGPRs, 2 workgroups per CU), 4 = half of that (4 per CU)
@@ -1326,7 +1331,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
                 }
             } else { defer->part = p.part; defer->nsplit = ns; defer->mn = mn; }
             const dim3 g32(gx, (unsigned)ns);
+            static int nw8 = -1; if (nw8 < 0) { const char *e = getenv("T4K_GEMM_S32_NW8"); nw8 = e ? atoi(e) : 1; }
 #define T4K_S32(A_, B_) do { if (t32 * ns > 2L * st().cu_count) hipLaunchKernelGGL((k_gemm_s32<A_, B_, 4>), g32, dim3(256), 0, hs2, p, ep, fr); \
+                             else if (nw8 && kc >= 384)          hipLaunchKernelGGL((k_gemm_s32<A_, B_, 8, 8>), g32, dim3(512), 0, hs2, p, ep, fr);   /* deep k per slab: 8 k-groups */ \
                              else                                hipLaunchKernelGGL((k_gemm_s32<A_, B_, 8>), g32, dim3(256), 0, hs2, p, ep, fr); } while (0)
             if (akc && !bkc) T4K_S32(true, false); else if (akc) T4K_S32(true, true); else if (!bkc) T4K_S32(false, false); else T4K_S32(false, true);
 #undef T4K_S32
