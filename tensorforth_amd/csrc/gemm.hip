@@ -1443,7 +1443,8 @@ namespace t4k {
 int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
 // linear_small.hip: classifier-head sized layers on the vector ALUs, one launch each way
 bool linear_small_ok(int E0, int E1);
-int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xf = nullptr);
+int  linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xf = nullptr,
+                      const ActEpi *oep = nullptr);   // oep: element-wise layer behind the linear layer, applied in the same launch
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, bool train, hipStream_t hs,
                       const float *MASK = nullptr, float *DXM = nullptr, const float *TGT = nullptr, float *DY2 = nullptr,
                       const float *MASKB = nullptr, float *DXMB = nullptr);
@@ -1472,8 +1473,13 @@ int t4k_linear_act_fwd(const float *X, const float *W, const float *B, float *Y,
     if (!X || !W || !Y || !ACT_F || !ACT_O || N < 0) return fail(T4K_ERR_ARG, "t4k_linear_act_fwd: bad argument");
     if (N == 0) return T4K_OK;
     bool done = false;
-    if (linear_small_ok(E0, E1)) linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s));
-    else {
+    if (linear_small_ok(E0, E1)) {
+        ActEpi ep = { layer, alpha, ACT_F, ACT_O, RngArg{0, 0, nullptr} };
+        const bool fuse = !(layer == T4K_L_DROPOUT && st().capturing);   // a captured mask draw advances a device-resident counter: the separate launches below do that
+        if (fuse && layer == T4K_L_DROPOUT) ep.rng = rng_draw(S(s), (uint64_t)(((long)N * E0 + 3) >> 2), true);
+        linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s), nullptr, fuse ? &ep : nullptr);
+        done = fuse;
+    } else {
         // the mask's Philox slice is reserved only if the fold launch will really apply the epilogue (decided inside gemm_launch)
         ActEpi ep = { layer, alpha, ACT_F, ACT_O, RngArg{0, 0, nullptr} };
         int rc = gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s, &ep, &done); if (rc) return rc;
@@ -1504,8 +1510,13 @@ int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const flo
     if (N == 0) return T4K_OK;
     bool done = false;
     FoldRider fr = {ActEpi{n2, a2, F2, A2, RngArg{0, 0, nullptr}}, (XCOPY && XCOPY != X) ? X : nullptr, XCOPY, (long)N * E1, 0, 0, MaskChain{nullptr, nullptr, nullptr, nullptr}, 0};
-    if (linear_small_ok(E0, E1)) linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s));
-    else {
+    if (linear_small_ok(E0, E1)) {
+        ActEpi ep = { n1, a1, F1, A1, RngArg{0, 0, nullptr} };
+        const bool fuse = n1 && !n2 && !(n1 == T4K_L_DROPOUT && st().capturing);     // one stage rides in the head kernel
+        if (fuse && n1 == T4K_L_DROPOUT) ep.rng = rng_draw(S(s), (uint64_t)(((long)N * E0 + 3) >> 2), true);
+        linear_small_fwd(X, W, B, Y, nullptr, N, E0, E1, S(s), nullptr, fuse ? &ep : nullptr);
+        done = fuse;
+    } else {
         ActEpi ep = { n1, a1, F1, A1, RngArg{0, 0, nullptr} };
         int rc = gemm_launch(X, W, Y, B, 1.0f, 0.0f, 0, 1, N, E0, E1, 1, s, &ep, &done, nullptr, nullptr, &fr); if (rc) return rc;
     }

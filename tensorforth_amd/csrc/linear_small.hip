@@ -22,7 +22,7 @@ constexpr int LS_MAX_FLOATS = 12288;          // 48 KiB of dynamic LDS
 // all 256 threads fold / stage them (4x the workgroups and threads on the slab reads), wave 0 alone computes the few dot products
 template <int LG, bool NARROW = false>
 __global__ void __launch_bounds__(256) k_linsmall_fwd(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ B,
-                                                      float *__restrict__ Y, float *__restrict__ P, int N, int E0, int E1, XFold xf) {
+                                                      float *__restrict__ Y, float *__restrict__ P, int N, int E0, int E1, XFold xf, ActEpi oep) {   // oep: the element-wise layer BEHIND this one (sigmoid of a discriminator head, ...)
     extern __shared__ float sm[];
     constexpr int RPW = 64 / LG, RPB = NARROW ? RPW : 4 * RPW;
     const int ldw = E1 + 1;                                      // odd-ish stride: lanes (= rows of W) hit different banks
@@ -73,7 +73,13 @@ __global__ void __launch_bounds__(256) k_linsmall_fwd(const float *__restrict__ 
         const float *xs = Xs + rloc * E1, *ws = Ws + e0 * ldw;
         for (int k = 0; k < E1; k++) acc = fmaf(xs[k], ws[k], acc);
         acc += B ? B[e0] : 0.f;
-        Y[(long)n * E0 + e0] = acc;
+        const long z = (long)n * E0 + e0;
+        Y[z] = acc;
+        if (oep.layer) {
+            float u = 0.f;
+            if (oep.layer == T4K_L_DROPOUT) { uint64_t ob, os; rng_begin(oep.rng, ob, os); u = philox_u01_at(ob, os, z); }
+            float a, f; act_rt(oep.layer, acc, u, oep.alpha, a, f); oep.F[z] = f; oep.A[z] = a;
+        }
     }
     if (P) {                                                     // softmax over the LG lanes of this row
         float mx = live ? acc : -FLT_MAX;
@@ -233,7 +239,8 @@ bool linear_small_ok(int E0, int E1) {
     return E0 >= 1 && E0 <= 64 && E1 >= 1 && E1 <= 512 && E0 * (E1 + 1) + 16 * E1 <= LS_MAX_FLOATS && E0 * E1 + 64 * E0 <= LS_MAX_FLOATS;
 }
 
-int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xfp) {
+int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xfp, const ActEpi *oepp) {
+    const ActEpi oep = oepp ? *oepp : ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
     XFold xf; if (xfp) xf = *xfp; else { xf.part = nullptr; xf.nsplit = 0; xf.mn = 0; xf.bias = nullptr; xf.Y = nullptr; xf.ep = ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}}; }
     const int LG = E0 <= 16 ? 16 : (E0 <= 32 ? 32 : 64);
     const int RPB = (xfp ? 1 : 4) * (64 / LG);
@@ -248,14 +255,14 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
         attr = true;
     }
     if (xfp) {
-        if (LG == 16)      hipLaunchKernelGGL((k_linsmall_fwd<16, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
-        else if (LG == 32) hipLaunchKernelGGL((k_linsmall_fwd<32, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
-        else               hipLaunchKernelGGL((k_linsmall_fwd<64, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
+        if (LG == 16)      hipLaunchKernelGGL((k_linsmall_fwd<16, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+        else if (LG == 32) hipLaunchKernelGGL((k_linsmall_fwd<32, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+        else               hipLaunchKernelGGL((k_linsmall_fwd<64, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
         return T4K_OK;
     }
-    if (LG == 16)      hipLaunchKernelGGL(k_linsmall_fwd<16>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
-    else if (LG == 32) hipLaunchKernelGGL(k_linsmall_fwd<32>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
-    else               hipLaunchKernelGGL(k_linsmall_fwd<64>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf);
+    if (LG == 16)      hipLaunchKernelGGL(k_linsmall_fwd<16>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+    else if (LG == 32) hipLaunchKernelGGL(k_linsmall_fwd<32>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+    else               hipLaunchKernelGGL(k_linsmall_fwd<64>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
     return T4K_OK;
 }
 
