@@ -613,6 +613,21 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
                 skip_next_ = true;
                 return in.data;
             }
+            // a lone activation that multiplies by its derivative mask (relu, tanh, leakyrelu, ... - not a fused run, not the
+            // pass-through sigmoid) in front of a layer too large for the head kernel: the multiply rides in the dX epilogue
+            auto in_run = [&](int op) { for (int k = op; k >= 0 && k > op - 5; k--) if (run_of_[k] >= 0 && k + runs_[run_of_[k]].count - 1 >= op) return true; return false; };
+            if (fused && i > 0 && !tg && !in_run(i - 1)) {
+                const int pf = at(i - 1).grad_fn;
+                if (pf == T4K_L_RELU || pf == T4K_L_TANH || pf == T4K_L_SELU || pf == T4K_L_LEAKYRL || pf == T4K_L_ELU) {
+                    Tensor &prev = at(i - 1);
+                    t4k_poolblock b1; memset(&b1, 0, sizeof(b1)); b1.KS = 1;
+                    b1.pre_layer = pf; b1.pre_alpha = prev.xparm; b1.pre_mask = prev.grad[4]->data; b1.pre_out = in.data;
+                    chk(t4k_linear_block_bwd(in.data, in.grad[0]->data, (float *)dy, nullptr, nullptr, in.data, &b1, prev.data,
+                                             train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#blinear+act");
+                    skip_next_ = true; skip_cnt_ = 1;
+                    return in.data;
+                }
+            }
             // a run of two mask-multiply layers (`leakyrelu dropout`) in front: its backward rides along as well
             if (fused && i > 1 && run_of_[i - 2] >= 0 && runs_[run_of_[i - 2]].count == 2 && !runs_[run_of_[i - 2]].blk.pool_layer &&
                 !runs_[run_of_[i - 2]].blk.copy_out) {
