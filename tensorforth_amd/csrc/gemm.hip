@@ -1621,9 +1621,11 @@ int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float 
     if (blk->post_layer) { mc.m1 = blk->post_mask; mc.d1 = blk->pre_layer ? blk->pre_out : XRUN; if (blk->pre_layer) { mc.m2 = blk->pre_mask; mc.d2 = XRUN; } }
     else                 { mc.m1 = blk->pre_mask; mc.d1 = XRUN; }
     hipStream_t hs = S(s);
-    if (linear_small_ok(E0, E1) && (!TGT || (const float *)DX == X) &&
+    if (linear_small_ok(E0, E1) &&
         linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, hs, mc.m1, mc.d1, TGT, DY2, mc.m2, mc.d2)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (TGT) { int rc = t4k_tt_op2(T4K_SUB, DY, TGT, DY, DY2, (long)N * E0, s); if (rc) return rc; }
+    if (linear_small_ok(E0, E1) &&                              // the head kernel could not take the target (dX apart from X): masks still ride
+        linear_small_bwd(X, W, DY, DX, DW, DB, N, E0, E1, train != 0, hs, mc.m1, mc.d1, nullptr, nullptr, mc.m2, mc.d2)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (train && DW && linear_bwd_dual(X, W, DY, DX, DW, DB, N, E0, E1, hs, &mc)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (!(train && DW) && !linear_small_ok(E0, E1)) {       // dX only (a frozen net in the middle of a chain): the mask chain rides in the GEMM's fold launch
         FoldRider fr = {ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}}, nullptr, nullptr, 0, 0, 0, mc, 0};

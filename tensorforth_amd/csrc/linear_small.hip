@@ -202,6 +202,11 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
                 const int n = row0 + e / E0;
                 if (n < N) { const long o = (long)n * E0 + e % E0; DYW[o] = Ds[e]; if (DY2) DY2[o] = Ds[e]; }
             }
+    } else if (TGT) {                                            // no dW workgroups in this launch (frozen layer): these rows of DY are read by nobody else
+        for (int e = tid; e < RA * E0; e += 256) {
+            const int n = row0 + e / E0;
+            if (n < N) { const long o = (long)n * E0 + e % E0; DYW[o] = Ds[e]; if (DY2) DY2[o] = Ds[e]; }
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -275,7 +280,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     const int nA = DX ? (N + RA - 1) / RA : 0;
     if (nA + nB == 0) return true;
     const bool alias = DX && nB > 0 && (const float *)DX == X;
-    if (TGT && !alias) return false;                                       // the in-place `out -= target` needs the arrival counters
+    if (TGT && !alias && nB > 0) return false;                             // the in-place `out -= target` needs the arrival counters (unless no dW workgroup reads dY: frozen layer)
     State &g = st();
     static int gate_on = -1; if (gate_on < 0) { const char *e = getenv("T4K_LINSMALL_GATE"); gate_on = e ? atoi(e) : 1; }
     int *gate = gate_for(hs, 0);                                           // nullptr: a stream the library does not know -> no private counters

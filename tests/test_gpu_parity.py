@@ -1116,7 +1116,8 @@ def test_linear_block_forward(t4k, dev, oracle, N, E1, E0, stages, copy):
     (256, 512, 256, ("leaky", "drop"), 1, False),   # interior tiles: the dual dW || dX launch carries the mask chain
     (256, 784, 512, ("leaky", "drop"), 1, False),   # ragged E1
     (256, 256, 1, ("leaky", "drop"), 1, True),      # GAN discriminator head: vector-ALU kernel, `out -= target` in the same launch
-    (256, 512, 256, ("leaky", "drop"), 0, False),   # frozen net: dX only, the chain rides in the split-K fold launch
+    (256, 256, 1, ("leaky", "drop"), 0, True),      # frozen discriminator head (train_g): target, dX and both masks in the head kernel, no dW workgroups
+    (256, 512, 256, ("leaky", "drop"), 0, False),   # frozen net: dX only, the chain rides in the GEMM launch
     (64, 128, 64, ("relu",), 0, False),             # shallow K: unsplit GEMM, separate launches
     (128, 320, 100, ("drop",), 1, True),            # lone stage in the post slot + target
     (2048, 1024, 1024, ("tanh", "drop"), 1, False), # large: 128x128 tiles, layer by layer
