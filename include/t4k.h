@@ -259,6 +259,9 @@ int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float 
 /* k_adamw nmath.cu:456 */
 int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd,
               long n, t4k_stream_t s);
+/* Model::backprop's start for an output layer with a derivative mask (tanh / relu / ... as the last op: backprop.cu:43-53 copies
+   the target into the output tensor, _bactivate :256-263 multiplies by the mask): OUT[i] = T[i], IN[i] = T[i] * MASK[i] */
+int t4k_copy_mask(const float *T, const float *MASK, float *OUT, float *IN, long n, t4k_stream_t s);
 /* Model::broadcast backprop.cu:17-29: O[N,E] with O[n,e] = T[n] (a per-sample target spread over the output width) */
 int t4k_broadcast_rows(const float *T, float *O, int N, int E, t4k_stream_t s);
 /* Model::onehot(Dataset&) loss.cpp:47-72: hot[N,E] = 0; hot[n, label<E ? label : 0] = 1 */

@@ -149,6 +149,7 @@ int t4k_dpool(int l, float *I, const float *DY, int N, int H1, int W1, int H0, i
 int t4k_sgd(float *G, float *DG, float *M, int Nw, float lr, float b, long n, t4k_stream_t) { return t4o_sgd(G, DG, M, Nw, lr, b, n); }
 int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, long n, t4k_stream_t) { return t4o_adam(G, DG, M, V, lr, b1, b2, n); }
 int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd, long n, t4k_stream_t) { return t4o_adamw(G, DG, M, V, lr, b1, b2, wd, n); }
+int t4k_copy_mask(const float *T, const float *M, float *OUT, float *IN, long n, t4k_stream_t) { for (long i = 0; i < n; i++) { const float t = T[i]; OUT[i] = t; IN[i] = t * M[i]; } return T4K_OK; }
 int t4k_broadcast_rows(const float *T, float *O, int N, int E, t4k_stream_t) { for (int n = 0; n < N; n++) for (int e = 0; e < E; e++) O[(size_t)n * E + e] = T[n]; return T4K_OK; }
 int t4k_onehot(const uint32_t *l, float *hot, int N, int E, t4k_stream_t) { return t4o_onehot(l, hot, N, E); }
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t) { return t4o_hit(out, hot, N, E, cnt); }

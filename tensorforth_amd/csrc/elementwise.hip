@@ -190,6 +190,11 @@ __global__ void __launch_bounds__(BLK) k_broadcast_rows(const float *__restrict_
     const long total = (long)N * E;
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) O[z] = T[z / E];
 }
+// backprop's start when the output layer is an activation with a derivative mask (Model::backprop: `out = target` copy, then
+// _bactivate `in = out * mask`, backprop.cu:43-53,256-263): both tensors from one pass over the target
+__global__ void __launch_bounds__(BLK) k_copy_mask(const float *__restrict__ T, const float *__restrict__ M, float *OUT, float *IN, long n) {
+    for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < n; z += (long)gridDim.x * BLK) { const float t = T[z]; OUT[z] = t; IN[z] = t * M[z]; }
+}
 __global__ void __launch_bounds__(BLK) k_onehot(const uint32_t *__restrict__ label, float *hot, int N, int E) {
     const long total = (long)N * E;
     for (long z = (long)blockIdx.x * BLK + threadIdx.x; z < total; z += (long)gridDim.x * BLK) {
@@ -294,6 +299,12 @@ int t4k_broadcast_rows(const float *T, float *O, int N, int E, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || E <= 0) return T4K_OK;
     if (!T || !O) return fail(T4K_ERR_ARG, "t4k_broadcast_rows: null tensor");
     hipLaunchKernelGGL(k_broadcast_rows, dim3(grid_for((long)N * E)), dim3(BLK), 0, S(s), T, O, N, E);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_copy_mask(const float *T, const float *MASK, float *OUT, float *IN, long n, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
+    if (!T || !MASK || !OUT || !IN) return fail(T4K_ERR_ARG, "t4k_copy_mask: null tensor");
+    hipLaunchKernelGGL(k_copy_mask, dim3(grid_for(n)), dim3(BLK), 0, S(s), T, MASK, OUT, IN, n);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_onehot(const uint32_t *label, float *hot, int N, int E, t4k_stream_t s) {

@@ -522,6 +522,7 @@ void Model::run_backward(Tensor &tgt) {
     t4k_stream_t s = stream();
     const bool fused = use_fusion && !(trace && *trace) && !concurrent();
     int skip = 0;                                       // layers already handled by the prep launch
+    const float *dy0 = nullptr;                         // ... and where they left the gradient (default: the output tensor)
     switch (at(-2).grad_fn) {
     case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
         if (fused && layer.size() > 3 && at(-3).grad_fn == T4K_L_LINEAR) { prep_tgt_ = &tgt; skip = 1; break; }   // rides in the linear backward launch
@@ -531,9 +532,16 @@ void Model::run_backward(Tensor &tgt) {
         /* fall through */
     case T4K_L_LINEAR:
         chk(t4k_tt_op(T4K_SUB, out.data, tgt.data, out.data, (long)out.numel, s), "bprep"); break;
-    default: chk(t4k_copy(tgt.data, out.data, (long)out.numel, s), "bprep"); break;
+    default: {
+        const int lf = at(-2).grad_fn;                  // last op
+        const bool mact = lf == T4K_L_RELU || lf == T4K_L_TANH || lf == T4K_L_SELU || lf == T4K_L_LEAKYRL || lf == T4K_L_ELU;
+        if (fused && mact && layer.size() > 2 && run_of_[(int)layer.size() - 2] < 0 && at(-2).numel == out.numel) {   // copy + the activation's mask multiply, one launch
+            chk(t4k_copy_mask(tgt.data, at(-2).grad[4]->data, out.data, at(-2).data, (long)out.numel, s), "bprep+bactivate"); skip = 1; dy0 = at(-2).data; break;
+        }
+        chk(t4k_copy(tgt.data, out.data, (long)out.numel, s), "bprep"); break;
     }
-    const float *dy = out.data;                         // where the gradient w.r.t. the current layer's output lives
+    }
+    const float *dy = dy0 ? dy0 : out.data;             // where the gradient w.r.t. the current layer's output lives
     for (int i = (int)layer.size() - 2 - skip, j = skip; i >= 0; i--, j++) {
         Tensor &in = at(i), &o = at(i + 1);
         if (trace && *trace)
