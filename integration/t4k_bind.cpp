@@ -227,14 +227,8 @@ int Model::_fpool(Tensor &in, Tensor &out, t4_layer fn) {       // :211-227
     return t4k_pool((int)fn, in.data, out.data, (int)out.N(), (int)in.H(), (int)in.W(), (int)out.H(), (int)out.W(), (int)out.C(), in.stride[0], nullptr);
 }
 int Model::_fsoftmax(Tensor &in, Tensor &out) { return t4k_softmax(in.data, out.data, (int)in.N(), (int)in.HWC(), nullptr); }   // :229-243
-int Model::_flogsoftmax(Tensor &in, Tensor &out) {       // :245-259: exp(x) - log10(sum exp(x)) per sample, quirk kept (SURVEY a-16)
-    Tensor::copy(in, out); out.map(EXP);
-    for (U32 n = 0; n < out.N(); n++) {
-        warn(t4k_reduce(T4K_RED_SUM, out.slice(n), (long)out.HWC(), 0.0f, scratch(), nullptr), "nn#flogsoftmax");
-        const DU ls = log10f(std::max(read_scalar(), DU_EPS));
-        warn(t4k_ts_op(T4K_SUB, out.slice(n), ls, out.slice(n), (long)out.HWC(), nullptr), "nn#flogsoftmax");
-    }
-    return 0;
+int Model::_flogsoftmax(Tensor &in, Tensor &out) {       // :245-259: exp(x) - log10(sum exp(x)) per sample, quirk kept (SURVEY a-16); one launch
+    return t4k_logsoftmax(in.data, out.data, (int)in.N(), (int)in.HWC(), nullptr);
 }
 int Model::_fbatchnorm(Tensor &in, Tensor &out) {        // :263-309
     return t4k_batchnorm_fwd(in.data, out.data, in.grad[4]->data, in.grad[0]->data, in.grad[1]->data, in.mtum[4]->data,
