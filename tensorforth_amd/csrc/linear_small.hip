@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
                                                       int nB, int nA, int RA, int *sync, int alias,
                                                       const float *__restrict__ MASK, float *__restrict__ DXM,
                                                       const float *__restrict__ TGT, float *DYW, float *DY2,
-                                                      const float *__restrict__ MASKB, float *__restrict__ DXMB) {
+                                                      const float *__restrict__ MASKB, float *__restrict__ DXMB, int CBK) {
     // TGT != NULL (alias mode only): dY = DY - TGT is formed while staging (the `out -= target` start of backprop); the dX
     // workgroups store it over DY (= DYW) and into DY2 once every workgroup has staged its share (counter sync[2])
     extern __shared__ float sm[];
@@ -130,15 +130,18 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
         // one output row e0 per workgroup: CL lanes cover the E1 columns, the 256 / CL lane groups split the batch; all loads of a
         // trip are independent (U rows in flight per thread - the loop is pure latency, one memory round trip per trip), partial
         // sums meet in LDS.  The bias gradient is the plain sum of the staged dY column (no pass over X needed).
-        const int e0 = blockIdx.x;
+        // CBK > 1 (one or a few output rows, e.g. a discriminator's 256 -> 1 head): a row's E1 columns are spread over CBK workgroups of
+        // 64 columns x 4 batch groups, so the batch is walked in ONE trip instead of one workgroup taking four dependent trips
+        const int e0 = blockIdx.x / CBK, cb = blockIdx.x - e0 * CBK;
         int CL = 32; while (CL < E1 && CL < 256) CL <<= 1;
-        const int NG = 256 / CL, c0 = tid % CL, ng = tid / CL;
+        if (CBK > 1) CL = 64;
+        const int NG = 256 / CL, lc = tid % CL, c0 = cb * 64 + lc, ng = tid / CL;
         float *dys = sm;                                         // dY[:, e0] for the whole batch
         for (int n = tid; n < N; n += 256) dys[n] = DY[(long)n * E0 + e0] - (TGT ? TGT[(long)n * E0 + e0] : 0.f);
         __syncthreads();
         if (TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // dY column staged
         float acc[2] = {0.f, 0.f};                               // columns c0 and c0 + 256 (E1 > 256)
-        if (E1 <= 256) dw_rows<1, 64>(X, dys, acc, N, E1, NG, ng, c0);
+        if (E1 <= 256 || CBK > 1) dw_rows<1, 64>(X, dys, acc, N, E1, NG, ng, c0);
         else           dw_rows<2, 32>(X, dys, acc, N, E1, NG, ng, c0);
         float bsum = 0.f;                                        // dB: fixed-order sum of the column (thread t: rows t, t+256, ...)
         for (int n = tid; n < N; n += 256) bsum += dys[n];
@@ -147,12 +150,12 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
         float *red = sm + N;                                     // [NG][CL][2], then [256] for the bias sum
         if (NG > 1) {
 #pragma unroll
-            for (int q = 0; q < 2; q++) red[(ng * CL + c0) * 2 + q] = acc[q];
+            for (int q = 0; q < 2; q++) red[(ng * CL + lc) * 2 + q] = acc[q];
             __syncthreads();
             if (ng == 0)
                 for (int g2 = 1; g2 < NG; g2++)
 #pragma unroll
-                    for (int q = 0; q < 2; q++) acc[q] += red[(g2 * CL + c0) * 2 + q];
+                    for (int q = 0; q < 2; q++) acc[q] += red[(g2 * CL + lc) * 2 + q];
             __syncthreads();
         }
         red[tid] = bsum;
@@ -161,11 +164,11 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
             float b = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) b += __shfl_xor(b, off, 64);
-            if (tid == 0) DB[e0] += b;
+            if (tid == 0 && cb == 0) DB[e0] += b;
         }
         if (ng == 0) {
             if (c0 < E1) DW[(long)e0 * E1 + c0] += acc[0];
-            if (c0 + 256 < E1) DW[(long)e0 * E1 + c0 + 256] += acc[1];
+            if (CBK == 1 && c0 + 256 < E1) DW[(long)e0 * E1 + c0 + 256] += acc[1];
         }
         return;
     }
@@ -275,7 +278,12 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
                       int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM, const float *TGT, float *DY2,
                       const float *MASKB, float *DXMB) {
-    const int nB = (train && DW) ? E0 : 0;
+    // dW: one workgroup per output row walks the batch in trips of (256 / CL) x 64 rows; when that takes more than one trip, the row's
+    // columns are split over workgroups of 64 columns x 4 batch groups instead (a 256 -> 1 head: 1 workgroup x 4 trips -> 4 x 1)
+    int CLh = 32; while (CLh < E1 && CLh < 256) CLh <<= 1;
+    const int trips = (N + (256 / CLh) * 64 - 1) / ((256 / CLh) * 64);
+    const int CBK = (E1 > 64 && trips > 1 && E0 * ((E1 + 63) / 64) <= 128) ? (E1 + 63) / 64 : 1;
+    const int nB = (train && DW) ? E0 * CBK : 0;
     int RA = 1024 / E1; if (RA > 64) RA = 64; if (RA < 1) RA = 1;        // rows of dX per workgroup (<= 1024 outputs, <= 64 rows of dY in LDS)
     const int nA = DX ? (N + RA - 1) / RA : 0;
     if (nA + nB == 0) return true;
@@ -290,7 +298,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate ? gate : g.d_sync, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate ? gate : g.d_sync, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB, CBK);
     return true;
 }
 
