@@ -1538,7 +1538,8 @@ int t4k_mlp_head_fwd(const float *X, const float *W1, const float *B1, float *Y1
     T4K_REQUIRE_INIT();
     if (!X || !W1 || !Y1 || !F1 || !A1 || !W2 || !Y2 || N < 0) return fail(T4K_ERR_ARG, "t4k_mlp_head_fwd: bad argument");
     if (N == 0) return T4K_OK;
-    if (!linear_small_ok(H, E1) && linear_small_ok(E2, H)) {
+    static int head_fold = -1; if (head_fold < 0) { const char *e = getenv("T4K_HEAD_FOLD"); head_fold = e ? atoi(e) : 1; }
+    if (head_fold && !linear_small_ok(H, E1) && linear_small_ok(E2, H)) {
         XFold xf; xf.part = nullptr;
         int rc = gemm_launch(X, W1, Y1, B1, 1.0f, 0.0f, 0, 1, N, H, E1, 1, s, nullptr, nullptr, nullptr, &xf); if (rc) return rc;
         if (xf.part) {
