@@ -1222,7 +1222,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
         auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
         const long a1 = t32(E0, E1), a2 = t32(N, E1), ar = (E0 + 63) / 64;
         static int maxk = -1; if (maxk < 0) { const char *e = getenv("T4K_GEMM_DUAL32_MAXK"); maxk = e ? atoi(e) : 1024; }
-        if (s32 && a1 + ar + a2 <= cap4 && a1 <= 512 && N <= maxk && E0 <= maxk && N <= 4096 && !capturing(hs)) {      // every workgroup resident (the gate spins); deep K stays with the staged kernels
+        if (s32 && a1 + ar + a2 <= cap4 - 32 && a1 <= 512 && N <= maxk && E0 <= maxk && N <= 4096 && !capturing(hs)) {      // every workgroup resident (the gate spins); deep K stays with the staged kernels
             GemmP q1, q2;
             auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
                 p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
@@ -1240,7 +1240,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             const int li = lane_of(hs);
             unsigned epoch = ++epochs[li < 63 ? li : 63];
             if (alias32 && epoch == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); epoch = ++epochs[li < 63 ? li : 63]; }
-            if (a1 + ar + a2 <= cap) hipLaunchKernelGGL(k_gemm_dual32<8>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
+            if (a1 + ar + a2 <= cap - 32) hipLaunchKernelGGL(k_gemm_dual32<8>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
             else                     hipLaunchKernelGGL(k_gemm_dual32<4>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
             return true;
         }
