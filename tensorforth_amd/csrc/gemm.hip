@@ -1292,19 +1292,19 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     // registers, the whole epilogue (bias, activation riders, mask chain, layer-0 copy, column sums) in the same launch - no fold
     {
         static int s32 = -1; if (s32 < 0) { const char *e = getenv("T4K_GEMM_S32"); s32 = e ? atoi(e) : 1; }
-        static int maxk = -1; if (maxk < 0) { const char *e = getenv("T4K_GEMM_S32_MAXK"); maxk = e ? atoi(e) : 1024; }
+        static int maxk = -1; if (maxk < 0) { const char *e = getenv("T4K_GEMM_S32_MAXK"); maxk = e ? atoi(e) : 832; }   // measured: 256 x 512 x K wins up to K = 784 (7.6 vs 10.6 us at 512), loses at 1024 (12.8 vs 10.7 us split-K + fold)
         const bool akc = !tA, bkc = tB != 0;
         const bool al = (!akc || (K % 4 == 0 && aligned16(A))) && (!bkc || (K % 4 == 0 && aligned16(B)));
-        if (s32 && C == 1 && !big && tiles * 2 <= st().cu_count && K >= 1 && K <= maxk && al && !capturing(S(s))) {
+        const long t32 = (long)((M + 31) / 32) * ((N + 31) / 32);
+        int ns = 1, kc = ((K + 7) / 8) * 8;
+        if (defer && alpha == 1.0f && beta == 0.0f && K >= 256) {               // a consumer folds the slabs anyway: spread K over idle CUs
+            int want = (int)((st().cu_count + t32 - 1) / t32); if (want > K / 128) want = K / 128; if (want > 16) want = 16;
+            if (want > 1) { kc = (((K + want - 1) / want) + 7) / 8 * 8; ns = (K + kc - 1) / kc; }
+            if ((size_t)ns * M * N * sizeof(float) > st().ws_bytes / 2) { ns = 1; kc = ((K + 7) / 8) * 8; }
+        }
+        if (s32 && C == 1 && !big && tiles * 2 <= st().cu_count && K >= 1 && kc <= maxk && al && !capturing(S(s))) {   // kc: depth one workgroup walks
             hipStream_t hs2 = S(s);
             p.tiles_m = (M + 31) / 32; p.tiles_n = (N + 31) / 32;
-            const long t32 = (long)p.tiles_m * p.tiles_n;
-            int ns = 1, kc = ((K + 7) / 8) * 8;
-            if (defer && alpha == 1.0f && beta == 0.0f && K >= 256) {           // a consumer folds the slabs anyway: spread K over idle CUs
-                int want = (int)((st().cu_count + t32 - 1) / t32); if (want > K / 128) want = K / 128; if (want > 16) want = 16;
-                if (want > 1) { kc = (((K + want - 1) / want) + 7) / 8 * 8; ns = (K + kc - 1) / kc; }
-                if ((size_t)ns * M * N * sizeof(float) > st().ws_bytes / 2) { ns = 1; kc = ((K + 7) / 8) * 8; }
-            }
             p.kchunk = kc; p.nsplit = ns; p.pair = 0; p.sync = st().d_sync;
             p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
             unsigned gx = (unsigned)t32;
