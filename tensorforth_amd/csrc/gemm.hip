@@ -810,14 +810,16 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int i = w * NJ + j;
+        // rows / 4-column groups past a ragged edge are clamped to the last valid one (valid memory; they only feed accumulator rows /
+        // columns the epilogue never stores), so N = 1000 classes or a 784-wide image row run this kernel like interior tiles
         if (AKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
-                   voffA[j] = (unsigned)(((long)(m0 + r) * K + kbeg + q * 4) * 4); }
+                   voffA[j] = (unsigned)(((long)min(m0 + r, M - 1) * K + kbeg + q * 4) * 4); }
         else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
-                   voffA[j] = (unsigned)(((long)(kbeg + kk) * M + m0 + ch * 4) * 4); }
+                   voffA[j] = (unsigned)(((long)(kbeg + kk) * M + min(m0 + ch * 4, M - 4)) * 4); }
         if (BKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
-                   voffB[j] = (unsigned)(((long)(n0 + r) * K + kbeg + q * 4) * 4); }
+                   voffB[j] = (unsigned)(((long)min(n0 + r, N - 1) * K + kbeg + q * 4) * 4); }
         else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
-                   voffB[j] = (unsigned)(((long)(kbeg + kk) * N + n0 + ch * 4) * 4); }
+                   voffB[j] = (unsigned)(((long)(kbeg + kk) * N + min(n0 + ch * 4, N - 4)) * 4); }
     }
     const long stepA = AKC ? BK : (long)BK * M, stepB = BKC ? BK : (long)BK * N;
 
@@ -930,6 +932,7 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     for (int r = 0; r < 16; r++) {
         const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = (acc0[r] + acc1[r]) + add[r];
+        if (gm >= M || gn >= N) continue;                   // ragged edge tile
         if (p.nsplit > 1) p.part[((long)blockIdx.y * M + gm) * N + gn] = v;
         else {
             const long z = (long)gm * N + gn;
@@ -1366,10 +1369,16 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
 
     dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)C);
     hipStream_t hs = S(s);
+    // ragged M / N with whole K stages on the 8-wave LDS-DMA kernel (clamped source rows, predicated stores) when the K loop is long enough
+    // to matter: unsplit products (N = 1000 classes: 1024 x 1000 x 4096 122 -> measured below) - split slivers stay with the skewed kernel
+    static int rag = -1; if (rag < 0) { const char *e = getenv("T4K_GEMM_RAGGED_DMA"); rag = e ? atoi(e) : 1; }
+    const bool ragged8 = rag && !big && vec && C == 1 && nsplit == 1 && !p.pair && (var & 4) && (var & 16) && (M % 64 != 0 || N % 64 != 0) &&
+                         kchunk % 64 == 0 && K % kchunk == 0 && M >= 4 && N >= 4 &&
+                         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);
     p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
     {   // column-sum rider: only the generic kernel carries it, and only when one workgroup per tile writes the output
         const bool full64 = !big && vec && M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
-        const bool generic = big || !vec || !(full64 && (var & 4));
+        const bool generic = big || !vec || !((full64 || ragged8) && (var & 4));
         if (cs && generic && nsplit == 1 && C == 1 && cs->rows > 0 && cs->rows <= 4096 && cs->E > 0) {
             p.cs_X = cs->X; p.cs_out = cs->out; p.cs_rows = cs->rows; p.cs_E = cs->E; cs->done = true;
             grid.x += (unsigned)((cs->E + 63) / 64);
@@ -1380,7 +1389,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
         launch_nn_plain(p, dim3((unsigned)((M / 64) * (N / 64))), hs);      // large plain products on the 64x64 LDS-DMA kernel, several tiles per CU
     } else if (big) {
-        const bool full = vec && M % 128 == 0 && N % 128 == 0 && kchunk % 32 == 0 && K % kchunk == 0;
+        static int bigfk = -1; if (bigfk < 0) { const char *e = getenv("T4K_GEMM_BIG_FULLK"); bigfk = e ? atoi(e) : 1; }
+        // whole K stages are enough for the predicate-free pipeline: ragged M / N edges are clamped source rows + predicated stores
+        const bool full = vec && kchunk % 32 == 0 && K % kchunk == 0 && M >= 4 && N >= 4 && (bigfk || (M % 128 == 0 && N % 128 == 0));
         if (full)     launch_variant<128, 128, 32, true, true, true>(p, grid, tA, tB, hs);
         else if (vec) launch_variant<128, 128, 32, true, true, false>(p, grid, tA, tB, hs);
         else          launch_variant<128, 128, 32, false, false, false>(p, grid, tA, tB, hs);
@@ -1388,7 +1399,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
         launch_variant<64, 64, 32, false, false, false>(p, grid, tA, tB, hs);
     } else {
         const bool full = M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
-        if (full && (var & 4)) {
+        if (ragged8) {
+            if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs); else launch_glds8<64>(p, grid, tA, tB, hs);
+        } else if (full && (var & 4)) {
             const bool span32 = (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);   // 32-bit DMA lane offsets
             if ((var & 16) && !p.pair && span32) {
                 if ((var & 32) && kchunk % 128 == 0 && !tA && !tB && nsplit == 1 && alpha == 1.0f && beta == 0.0f && !bias && !(var & 64)) launch_nn_plain(p, grid, hs);   // `matmul`

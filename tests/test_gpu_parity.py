@@ -1067,6 +1067,22 @@ def test_gemm_large_plain_products_exact_on_integer_operands(t4k, dev, M, N, K):
     assert np.array_equal(dev.down(dO), want)
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB", [(1024, 1000, 512, 0, 0), (1000, 1028, 256, 0, 1), (996, 1000, 384, 1, 0), (516, 2044, 128, 1, 1),
+                                         (40, 72, 64, 0, 1), (200, 100, 832, 0, 1), (36, 28, 96, 1, 0)])
+def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N, K, tA, tB):
+    """Ragged M / N (not multiples of the tile) on the LDS-DMA kernel with clamped source rows, and sliver shapes on the 32x32
+    register-fetch kernel, every operand layout: entries in {-2..2} keep fp32 sums exact, so the product must equal numpy's bit for bit
+    (a clamped row or column leaking into a stored element, or a k group counted twice, would show)."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K + tA * 2 + tB)
+    A = rng.integers(-2, 3, (M, K)).astype(np.float32); B = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    want = (A.astype(np.int64) @ B.astype(np.int64)).astype(np.float32)
+    O0 = rng.integers(-3, 4, (M, N)).astype(np.float32); bias = None
+    dA = dev.up(np.ascontiguousarray(A.T) if tA else A); dB = dev.up(np.ascontiguousarray(B.T) if tB else B)
+    dO = dev.up(O0)
+    t4k.call("t4k_gemm", p(dA), p(dB), p(dO), 2.0, -1.0, tA, tB, M, N, K, 1, None)        # alpha, beta exact in fp32 too
+    assert np.array_equal(dev.down(dO), 2.0 * want - O0)
+
+
 @pytest.mark.parametrize("N,E1,E0,stages,copy", [
     (256, 784, 512, ("leaky", "drop"), True),      # GAN discriminator layer 0: split-K, run of two and the layer-0 copy in the fold launch
     (256, 512, 256, ("leaky", "drop"), False),
