@@ -1194,6 +1194,7 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
 }
 
 struct ColSum { const float *X; float *out; int rows, E; bool done; };
+bool big_dma() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_BIG_DMA"); v = e ? atoi(e) : 1; } return v != 0; }
 bool capturing(hipStream_t hs) { hipStreamCaptureStatus st_ = hipStreamCaptureStatusNone; return hipStreamIsCapturing(hs, &st_) == hipSuccess && st_ != hipStreamCaptureStatusNone; }   // a replayed graph would repeat the epoch argument
 bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0; }
 // dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
@@ -1388,6 +1389,13 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     if (big && plain_big && vec && C == 1 && !tA && !tB && alpha == 1.0f && beta == 0.0f && !bias && !p.cs_X && M % 64 == 0 && N % 64 == 0 && K % 128 == 0 &&
         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
         launch_nn_plain(p, dim3((unsigned)((M / 64) * (N / 64))), hs);      // large plain products on the 64x64 LDS-DMA kernel, several tiles per CU
+    } else if (big && big_dma() && vec && C == 1 && !p.cs_X && K % 64 == 0 && K >= 2048 && M >= 4 && N >= 4 && nsplit == 1 &&   // deep K only: at K = 1024 the 128x128 kernel's fewer, fatter tiles win (292 vs 318 us at 4096 x 4096 x 1024)
+               (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
+        // every other large product (transposed operands, alpha / beta / bias: the linear layers of an MLP) on the 8-wave LDS-DMA kernel too,
+        // 64x64 tiles, several per CU, ragged edges clamped (the 128x128 register-staged kernel: 69-78 % of peak)
+        p.tiles_m = (M + 63) / 64; p.tiles_n = (N + 63) / 64; p.kchunk = K; p.nsplit = 1;
+        const dim3 g64((unsigned)(p.tiles_m * p.tiles_n), 1, 1);
+        if (K % 128 == 0) launch_glds8<128>(p, g64, tA, tB, hs); else launch_glds8<64>(p, g64, tA, tB, hs);
     } else if (big) {
         static int bigfk = -1; if (bigfk < 0) { const char *e = getenv("T4K_GEMM_BIG_FULLK"); bigfk = e ? atoi(e) : 1; }
         // whole K stages are enough for the predicate-free pipeline: ragged M / N edges are clamped source rows + predicated stores

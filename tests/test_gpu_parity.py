@@ -1083,6 +1083,19 @@ def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N,
     assert np.array_equal(dev.down(dO), 2.0 * want - O0)
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB", [(2048, 2048, 2048, 0, 1), (1024, 4096, 2048, 1, 0), (2040, 2048, 2112, 1, 1)])
+def test_gemm_large_transposed_products_exact_on_integer_operands(t4k, dev, M, N, K, tA, tB):
+    """Large products with transposed operands and alpha / beta (the linear layers of an MLP) on the 8-wave LDS-DMA kernel, several 64x64
+    tiles per CU, one shape with a ragged M: small-integer entries keep every fp32 sum exact, so the result equals the float64 product."""
+    rng = np.random.default_rng(M + N + K + tA + 2 * tB)
+    A = rng.integers(-2, 3, (M, K)).astype(np.float32); B = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    O0 = rng.integers(-3, 4, (M, N)).astype(np.float32)
+    dA = dev.up(np.ascontiguousarray(A.T) if tA else A); dB = dev.up(np.ascontiguousarray(B.T) if tB else B); dO = dev.up(O0)
+    t4k.call("t4k_gemm", p(dA), p(dB), p(dO), 2.0, -1.0, tA, tB, M, N, K, 1, None)
+    assert np.array_equal(dev.down(dO).astype(np.float64), 2.0 * want - O0)
+
+
 @pytest.mark.parametrize("N,E1,E0,stages,copy", [
     (256, 784, 512, ("leaky", "drop"), True),      # GAN discriminator layer 0: split-K, run of two and the layer-0 copy in the fold launch
     (256, 512, 256, ("leaky", "drop"), False),
