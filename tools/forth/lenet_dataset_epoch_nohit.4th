@@ -12,6 +12,6 @@ variable hits 0 hits !
 net ds0 epoch ds0 rewind drop        \ warm-up epoch
 variable t0 clock t0 !
 0 hits !
-ds0 epoch ds0 rewind drop ds0 epoch ds0 rewind drop ds0 epoch
+ds0 epoch ds0 rewind drop ds0 epoch ds0 rewind drop ds0 epoch nn.hit hits !   \ ONE read-back at the end: the device sync in front of the clock
 clock t0 @ - ." ms_for_3_epochs " . ." hits " hits @ .
 bye
