@@ -1199,7 +1199,7 @@ bool capturing(hipStream_t hs) { hipStreamCaptureStatus st_ = hipStreamCaptureSt
 bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0; }
 // dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
 // shapes belong to the other kernels (deep K -> split-K, large -> 128x128 tiles).  Interior-tile shapes take it too since round 2
-// (T4K_GEMM_DUAL_FULL=0: the LDS-DMA kernels, 5 launches with their folds and the column sum; GAN round 0.272 -> 0.234 ms)
+// (T4K_GEMM_DUAL_FULL=0: the LDS-DMA kernels, 5 launches with their folds and the column sum: GAN round 0.356 instead of 0.318 ms of GPU time)
 bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB, int N, int E0, int E1, hipStream_t hs,
                      const MaskChain *mcp = nullptr) {
     State &g = st();
@@ -1211,7 +1211,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     auto splits = [&](int m, int n, int k) { return tiles(m, n) * 2 <= cu && k >= 256; };
     auto full = [](int m, int n, int k) { return m % 64 == 0 && n % 64 == 0 && k % 64 == 0; };
     static int deepk = -1; if (deepk < 0) { const char *e = getenv("T4K_GEMM_DUAL_MAXK"); deepk = e ? atoi(e) : 1024; }
-    // deep-K shapes would go split-K + fold (2 launches per GEMM); up to K = 1024 the single dual launch, unsplit, is faster (GAN round 0.346 -> 0.322 ms)
+    // deep-K shapes would go split-K + fold (2 launches per GEMM); up to K = 1024 the single dual launch, unsplit, is faster (GAN round 0.318 ms of GPU time; with T4K_GEMM_DUAL_MAXK=256: 0.341)
     const bool sp = splits(E0, E1, N) || splits(N, E1, E0);
     if (big(E0, E1) || big(N, E1) || (sp && (N > deepk || E0 > deepk))) return false;
     static int dfull = -1; if (dfull < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULL"); dfull = e ? atoi(e) : 1; }
