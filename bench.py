@@ -118,10 +118,10 @@ def main():
     # (stream slice [rank*n, (rank+1)*n) of a world*n-element draw), like the dropout masks later (t4k_rand_set_shard):
     # N ranks x 128 images see exactly the data and masks of 1 rank x 128N images
     n_img = N * 28 * 28
-    off0 = k.lib.t4k_rand_offset()
-    k.call("t4k_rand_set_offset", off0 + rank * n_img)
+    off0 = vm.rand_tell()
+    vm.rand_seek(off0 + rank * n_img)
     vm.eval("%d 28 28 1 tensor rand constant img\n" % N)
-    k.call("t4k_rand_set_offset", off0 + world * n_img)
+    vm.rand_seek(off0 + world * n_img)
     out_txt = vm.eval(
         ": hot ( T -- T ) %d 0 do 1 i 10 * i 7 * %d + 10 mod + t! loop ;\n"
         "%d vector zeros hot %d 1 10 1 reshape4 constant lbl\n"

@@ -179,12 +179,14 @@ int t4k_rand_init(uint64_t seed);
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s);
 uint64_t t4k_rand_offset(void);                    /* current stream offset (for checkpoint/tests) */
 int t4k_rand_set_offset(uint64_t off);
+uint64_t t4k_rand_seed(void);                      /* the seed of the stream (a host that embeds several VMs saves / restores (seed, offset) per VM) */
 /* Data-parallel shard of the stream (SURVEY 8e "dropout: per-rank Philox offset = global sample index").  With a shard (rank, world)
  * set, a dropout-mask draw of n elements takes elements [rank*n, (rank+1)*n) of the n*world-element draw the whole batch would make
  * and moves the stream by n*world, so `world` ranks x batch B draw exactly the masks of one rank x batch B*world (n % 4 == 0; every
  * rank must make the same draws in the same order).  Every other draw (weight init, `rand` words) stays replicated.  t4k_comm_init
  * sets the shard to the communicator's (rank, world), t4k_comm_destroy resets it to (0, 1). */
 int t4k_rand_set_shard(int rank, int world);
+int t4k_rand_shard_world(void);                    /* 1 = no shard.  Sharded draws are keyed on the host per launch: a host must not replay captured graphs while world > 1 */
 /* the mask of a dropout layer (Model::_fstep L_DROPOUT forward.cu:100-103 + t4_rand): uniform (0,1], keyed by sample as above */
 int t4k_dropout_mask(float *mask, long n, t4k_stream_t s);
 

@@ -25,6 +25,15 @@ const char *ten4_output(ten4_vm *vm);
 int ten4_grad_slab(ten4_vm *vm, float **dev_ptr, long *n_floats);
 /* the stream every kernel of the VM is issued on (a hipStream_t) */
 void *ten4_stream(ten4_vm *vm);
+/* Each VM owns a Philox stream (seed given to ten4_new, position 0): ten4_eval swaps it into the backend and saves it back, so
+ * VMs created with the same seed are identical replicas whatever the interleaving of their ten4_eval calls.  tell / seek read and
+ * move the position (in elements) between evals - a data-parallel launcher that draws only its shard of a replicated tensor. */
+unsigned long long ten4_rand_tell(ten4_vm *vm);
+void ten4_rand_seek(ten4_vm *vm, unsigned long long element_offset);
+/* Copy the tensor on top of the data stack to host memory as fp32 (synchronises the VM stream).  Returns its element count (-1
+ * when the top of stack is not a tensor); nothing is copied when cap < count or dst is NULL; shape = {H, W, C, N} if non-NULL.
+ * Full-precision read-back for hosts and tests - the printer rounds to 4 decimals, `bin save` to 8 bits (aio_tensor.cpp:240-255). */
+long ten4_fetch(ten4_vm *vm, float *dst, long cap, int shape[4]);
 /* Called during `backprop`, on the calling thread, right after the kernels that complete one layer's dW|dB have been
  * enqueued on the VM stream: `off`/`n` locate that layer's segment in the gradient slab (floats).  Layers finish in
  * reverse order, so [off, slab end) is complete (stream-ordered) at each call - a data-parallel launcher can start

@@ -391,6 +391,8 @@ int t4o_rand_set_shard(int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) return ERR_ARG;
     g_shard_rank = rank; g_shard_world = world; return OK;
 }
+uint64_t t4o_rand_seed(void) { return g_seed; }
+int t4o_rand_shard_world(void) { return g_shard_world; }
 int t4o_dropout_mask(float *mask, long n) {
     const uint64_t nq = (uint64_t)((n + 3) / 4), off0 = g_off;
     g_off = off0 + (uint64_t)g_shard_rank * nq * 4;

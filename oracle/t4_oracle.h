@@ -50,6 +50,8 @@ int      t4o_rand(float *d, long n, int opt, float bias, float scale);
 uint64_t t4o_rand_offset(void);
 int      t4o_rand_set_offset(uint64_t off);
 int      t4o_rand_set_shard(int rank, int world);   /* include/t4k.h t4k_rand_set_shard */
+uint64_t t4o_rand_seed(void);
+int      t4o_rand_shard_world(void);
 int      t4o_dropout_mask(float *mask, long n);      /* include/t4k.h t4k_dropout_mask   */
 
 int t4o_bias(const float *B, float *O, int N, int E0);

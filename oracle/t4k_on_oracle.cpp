@@ -90,6 +90,8 @@ int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t) {
 uint64_t t4k_rand_offset(void) { return t4o_rand_offset(); }
 int t4k_rand_set_offset(uint64_t o) { return t4o_rand_set_offset(o); }
 int t4k_rand_set_shard(int r, int w) { return t4o_rand_set_shard(r, w); }
+uint64_t t4k_rand_seed(void) { return t4o_rand_seed(); }
+int t4k_rand_shard_world(void) { return t4o_rand_shard_world(); }
 int t4k_dropout_mask(float *m, long n, t4k_stream_t) { return t4o_dropout_mask(m, n); }
 int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t) { return t4o_bias(B, O, N, E0); }
 int t4k_activate(int l, const float *I, float *O, float *F, float a, long n, t4k_stream_t) { return rc(t4o_activate(l, I, O, F, a, n), "k_activate"); }

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
         float *dys = sm;                                         // dY[:, e0] for the whole batch
         for (int n = tid; n < N; n += 256) dys[n] = DY[(long)n * E0 + e0] - (TGT ? TGT[(long)n * E0 + e0] : 0.f);
         __syncthreads();
-        if (TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // dY column staged
+        if (alias && TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // dY column staged
         float acc[2] = {0.f, 0.f};                               // columns c0 and c0 + 256 (E1 > 256)
         if (E1 <= 256 || CBK > 1) dw_rows<1, 64>(X, dys, acc, N, E1, NG, ng, c0);
         else           dw_rows<2, 32>(X, dys, acc, N, E1, NG, ng, c0);
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
         Ds[e] = n < N ? DY[o] - (TGT ? TGT[o] : 0.f) : 0.f;
     }
     __syncthreads();
-    if (TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // dY rows staged
+    if (alias && TGT && tid == 0) __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // dY rows staged (counted only where the re-arm below runs: the gate stays zero between launches)
     const int total = RA * E1;
     float out[4];                                                // RA * E1 <= 1024 outputs per block
 #pragma unroll
@@ -298,7 +298,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate ? gate : g.d_sync, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB, CBK);
+    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB, CBK);
     return true;
 }
 

@@ -190,6 +190,8 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n
 
 int t4k_rand_init(uint64_t seed) { T4K_REQUIRE_INIT(); State &g = st(); g.seed = seed; g.rng_ctr = 0; g.d_rng_ctr = ~0ull; return T4K_OK; }
 uint64_t t4k_rand_offset(void) { return st().rng_ctr * 4; }
+uint64_t t4k_rand_seed(void) { return st().seed; }
+int t4k_rand_shard_world(void) { return st().shard_world; }
 int t4k_rand_set_offset(uint64_t off) { T4K_REQUIRE_INIT(); State &g = st(); g.rng_ctr = off / 4; g.d_rng_ctr = ~0ull; return T4K_OK; }
 int t4k_rand_set_shard(int rank, int world) {
     T4K_REQUIRE_INIT();

@@ -191,7 +191,7 @@ void Model::lazy_copy(const float *src, Tensor &dst) {   // bookkeeping copy, of
 }
 bool Model::replay(GraphSlot &slot, const void *key, int flags, const float *p) {
     capturing_ = false;
-    if (!use_graphs || !capturable_ || (trace && *trace) || t4k_comm_world() > 1) return false;   // data parallel: mask draws are keyed on the host per launch, a replay would repeat them
+    if (!use_graphs || !capturable_ || (trace && *trace) || t4k_comm_world() > 1 || t4k_rand_shard_world() > 1) return false;   // data parallel (a communicator, or a shard set for another transport): mask draws are keyed on the host per launch, a replay would repeat them
     const bool same = slot.key == key && slot.flags == flags && (!p || memcmp(slot.p, p, sizeof(slot.p)) == 0);
     if (same && slot.g) { chk(t4k_graph_launch(slot.g, stream()), "graph launch"); return true; }
     if (!same) {                                        // new operands: run eagerly once, capture next time
@@ -401,9 +401,11 @@ void Model::hit_lazy() {                                 // count on the GPU now
     hit_pending_ = true;
 }
 // data parallel: `nn.hit` and the loss words report the WHOLE batch when the library owns a communicator - one small
-// all-reduce(SUM) of the rank-local value on the VM stream (hit counts are exact in fp32 below 2^24; every rank must run the word)
+// all-reduce(SUM) of the rank-local value on the VM stream (hit counts are exact in fp32 below 2^24; every rank must run the word).
+// Training-mode models only: after `0 trainable` the words report the rank-local value and issue NO collective, so an evaluation
+// pass may run on one rank alone (the same rule dp_bn_mode applies to the batch-norm statistics).
 DU Model::dp_sum(DU v) {
-    if (t4k_comm_world() < 2) return v;
+    if (t4k_comm_world() < 2 || !train) return v;
     if (!hit_dev) { void *p; t4k_malloc(&p, 64); hit_dev = (int *)p; }
     float *d = (float *)hit_dev + 8, r = v;               // second half of the 64-byte scratch
     t4k_memcpy_h2d(d, &r, sizeof(float), stream());
@@ -430,7 +432,7 @@ DU Model::loss(Loss op, Tensor &tgt) {                  // loss.cpp:119-136: non
     if (loss_t) *loss_t = out; else loss_t = &Store::get().copy(out);
     const DU z = loss_t->loss(op, tgt);                  // = sum over the local rows / N_local
     const int world = t4k_comm_world();
-    return world < 2 ? z : SCALAR(dp_sum(z) / (DU)world);   // equal shards: mean of the rank means = whole-batch mean
+    return (world < 2 || !train) ? z : SCALAR(dp_sum(z) / (DU)world);   // equal shards (the batch size is fixed by nn.model): mean of the rank means = whole-batch mean
 }
 
 // ---------------------------------------------------------------- backprop

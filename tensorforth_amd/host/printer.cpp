@@ -6,7 +6,8 @@
 
 namespace t4 {
 
-static const int THRES = 10, EDGE = 3, PREC = 4;         // src/io/aio.h:80-82
+static const int EDGE = 3, PREC = 4;                     // src/io/aio.h:80-82
+static int THRES = 10;                                   // _thres: 10 for the printer, 1024 while a tensor is saved as text (aio_tensor.cpp:232-235)
 
 std::string fmt_scalar(DU v, int base) {
     char buf[40];
@@ -71,8 +72,9 @@ static std::string mat_s(const float *td, const uint32_t *shape) {
     for (uint32_t y = ym, y1 = y + 1; y < H; y++, y1++, d += WC) row(y1, d);
     return o.str();
 }
-std::string fmt_tensor(Tensor &t) {
+std::string fmt_tensor(Tensor &t, int thres) {
     std::vector<float> h; t.to_host(h);
+    struct Thres { int old; explicit Thres(int v) : old(THRES) { if (v > 0) THRES = v; } ~Thres() { THRES = old; } } scope(thres);
     std::ostringstream o;
     switch (t.rank) {
     case 1: o << "vector" << shape_s(t) << " = " << vec_s(h.data(), (uint32_t)t.numel, 1); break;

@@ -42,6 +42,7 @@ int  chk(int rc, const char *what);  // prints t4k_last_error() on failure (prin
 // embedded users (ten4_eval / ten4_output, vm.py) see them and they stay in order with the text the words print; stdout otherwise.
 void hprintf(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void set_host_sink(void (*fn)(const char *text, void *user), void *user);
+void get_host_sink(void (**fn)(const char *text, void *user), void **user);
 // TensorBoard sink (host/tboard.cpp): inactive - the words only print the reference's hint - until a log directory is given
 struct Tensor;
 bool tb_configure(const char *logdir, const char *run_id);
@@ -296,7 +297,7 @@ private:
 // ---------------------------------------------------------------- printing
 std::string fmt_scalar(DU v, int base);                 // src/io/aio.cpp:38-57
 std::string fmt_objname(Obj &o, bool view);             // "T2[2,3]" etc, src/io/aio_tensor.cpp:16-58
-std::string fmt_tensor(Tensor &t);                      // src/io/aio_tensor.cpp:141-226
+std::string fmt_tensor(Tensor &t, int thres = 0);                      // src/io/aio_tensor.cpp:141-226
 std::string fmt_model(Model &m);                        // src/io/aio_model.cpp:65-141
 std::string fmt_parm(Tensor &in, Tensor &out);          // src/io/aio_model.cpp:103-141 (layer parameter text)
 int model_save(Model &m, const char *fname);            // src/io/aio_model.cpp:16-35,143-181 (.t4 model file)

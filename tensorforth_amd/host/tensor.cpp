@@ -35,6 +35,7 @@ void die_if_no_backend() {
 static void (*g_sink)(const char *, void *) = nullptr;
 static void *g_sink_user = nullptr;
 void set_host_sink(void (*fn)(const char *, void *), void *user) { g_sink = fn; g_sink_user = user; }
+void get_host_sink(void (**fn)(const char *, void *), void **user) { *fn = g_sink; *user = g_sink_user; }
 void hprintf(const char *fmt, ...) {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);

@@ -15,6 +15,19 @@ static double now_ms() {
 }
 
 VM::VM() : pmem_(PMEM_SZ, 0) { base() = 10; }
+static void vm_sink(const char *t, void *u) { ((VM *)u)->host_msg(t); }
+VM::~VM() {
+    void (*fn)(const char *, void *); void *user; get_host_sink(&fn, &user);
+    if (user == this) set_host_sink(nullptr, nullptr);
+}
+namespace {
+// host-layer messages (hprintf / chk) reach the VM that is EXECUTING: the sink is process-global, several VMs may be embedded
+struct SinkScope {
+    void (*fn)(const char *, void *); void *user;
+    explicit SinkScope(VM *vm) { get_host_sink(&fn, &user); set_host_sink(vm_sink, vm); }
+    ~SinkScope() { if (user) set_host_sink(fn, user); }      // an attached VM keeps the sink between lines; never restore "no sink" over a live VM
+};
+}
 
 // ---------------------------------------------------------------- input
 const char *VM::fetch() {
@@ -154,6 +167,7 @@ int VM::process(const char *idiom) {                     // TensorVM::process te
     return 1;
 }
 bool VM::eval(const std::string &line) {
+    SinkScope sink(this);
     line_ = line; pos_ = 0;
     const char *idiom;
     while (!stop_ && (idiom = fetch()) != nullptr) {
@@ -482,7 +496,7 @@ void VM::init_core() {
 }
 
 void VM::init() {
-    set_host_sink([](const char *t, void *u) { ((VM *)u)->pstr(t); }, this);     // host-layer messages join this VM's output, in order
+    set_host_sink(vm_sink, this);                        // host-layer messages join this VM's output, in order (re-pointed at every eval)
     dict_.clear();
     init_core();
     init_tensor();

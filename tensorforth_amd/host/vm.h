@@ -19,11 +19,14 @@ struct Word {
 class VM {
 public:
     VM();
+    ~VM();                                    // detaches the host-message sink if it still points here
     void init();
     // feed one line of Forth source; returns false after `bye`
     bool eval(const std::string &line);
     std::string take_output() { std::string s; s.swap(out_); return s; }
     bool done() const { return stop_; }
+    Tensor *tos_tensor() { return TOS1T() ? &TTOS() : nullptr; }   // embedding API: the tensor on top of the data stack (ten4_fetch)
+    void host_msg(const char *t) { out_ += t; }   // host-layer diagnostics (hprintf) routed here by the sink
     int  trace_lvl = 1;                       // T4_VERBOSE default, `trace` word
 
 private:

@@ -192,16 +192,45 @@ void VM::init_tensor() {
     CODE("gemm2", [this] { gemm(2); });
     CODE("gemm3", [this] { gemm(3); });
     CODE("gemm4", [this] { gemm(4); });
-    CODE("bin", [this] { PUSH(1.0f); });
-    CODE("w/o", [this] { PUSH(2.0f); });
-    CODE("r/w", [this] { PUSH(4.0f); });
-    auto tsave = [this](bool load) {                     // ( T adr len [mode] -- T ): text form of the tensor
-        if (SP() > 2 && IS_OBJ(SS(-3))) POPi();
+    // file access modes, io/ostream.h:43-47 (FAM_WO = 0, FAM_RO = 1, FAM_RW = 2, FAM_RAW = 3)
+    CODE("bin", [this] { PUSH(3.0f); });
+    CODE("w/o", [this] { PUSH(0.0f); });
+    CODE("r/w", [this] { PUSH(2.0f); });
+    // ( T adr len [mode] -- T ) tenvm.cpp:389-410 -> sys.cpp:153-163 -> AIO::tsave aio_tensor.cpp:75-93.
+    // text (default): the printed form with the 1024-cell threshold (:232-238).  raw (`bin`): 'T','4', shape[4] as U32 {H,W,C,N}, then
+    // one byte per element, (U8)(v * 256) slice by slice (:240-255) - the byte layout is the reference's.  Reference hazard decided:
+    // tsave tests mode bits (FAM_RW = 2 is a bit of FAM_RAW = 3), so its `bin save` opens the file read-only and writes nothing; here
+    // `bin` writes the raw format it defines.  `load` of a tensor has no handler in the reference (OP_TLOAD falls through the switch at
+    // sys.cpp:145-215); here it fills the tensor on the stack from a raw file of the same element count (v = byte / 256).
+    auto tsave = [this](bool load) {
+        int mode = 0;
+        if (SP() > 2 && IS_OBJ(SS(-3))) mode = POPi();
         POPi(); uint32_t adr = (uint32_t)POPi();
         const char *fn = (const char *)&pmem_[adr];
-        if (!TOS1T() || load) { pstr("tensor load: n/a\n"); return; }
-        FILE *f = fopen(fn, "w"); if (!f) { pstr(" failed to open for output\n"); return; }
-        std::string s = fmt_tensor(TTOS()); fwrite(s.data(), 1, s.size(), f); fclose(f);
+        if (!TOS1T()) { pstr("tensor adr len [mode]?\n"); return; }
+        Tensor &t = TTOS();
+        if (load) {
+            FILE *f = fopen(fn, "rb"); if (!f) { pstr(" failed to open for input\n"); return; }
+            char hdr[2] = {0, 0}; uint32_t shp[4] = {0, 0, 0, 0};
+            const bool ok = fread(hdr, 1, 2, f) == 2 && hdr[0] == 'T' && hdr[1] == '4' && fread(shp, 4, 4, f) == 4;
+            const uint64_t n = (uint64_t)shp[0] * shp[1] * shp[2] * shp[3];
+            if (!ok || n != t.numel) { fclose(f); pstr(ok ? " tensor load: element count differs\n" : " tensor load: not a raw T4 file\n"); return; }
+            std::vector<uint8_t> b(n); std::vector<float> h(n);
+            if (fread(b.data(), 1, n, f) != n) { fclose(f); pstr(" tensor load: short file\n"); return; }
+            fclose(f);
+            for (uint64_t i = 0; i < n; i++) h[i] = (float)b[i] / 256.0f;
+            t.from_host(h.data(), n);
+            return;
+        }
+        FILE *f = fopen(fn, mode == 3 ? "wb" : "w"); if (!f) { pstr(" failed to open for output\n"); return; }
+        if (mode == 3) {
+            std::vector<float> h; t.to_host(h, t.numel);
+            const uint32_t shp[4] = { t.H(), t.W(), t.C(), t.N() };
+            std::vector<uint8_t> b(t.numel);
+            for (uint64_t i = 0; i < t.numel; i++) b[i] = static_cast<uint8_t>(h[i] * 256.0);   // [0,1) => [0,256); the double product of :250
+            fwrite("T4", 1, 2, f); fwrite(shp, 4, 4, f); fwrite(b.data(), 1, b.size(), f);
+        } else { std::string s = fmt_tensor(t, 1024); fwrite(s.data(), 1, s.size(), f); }
+        fclose(f);
     };
     CODE("save", [tsave] { tsave(false); });
     CODE("load", [tsave] { tsave(true); });

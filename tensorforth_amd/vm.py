@@ -40,6 +40,11 @@ class VM:
         so.ten4_grad_slab.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long)]
         so.ten4_stream.restype = ctypes.c_void_p
         so.ten4_stream.argtypes = [ctypes.c_void_p]
+        so.ten4_rand_tell.restype = ctypes.c_ulonglong
+        so.ten4_rand_tell.argtypes = [ctypes.c_void_p]
+        so.ten4_rand_seek.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
+        so.ten4_fetch.restype = ctypes.c_long
+        so.ten4_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_int * 4)]
         self._HOOK = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_void_p)
         so.ten4_set_grad_hook.argtypes = [ctypes.c_void_p, self._HOOK, ctypes.c_void_p]
         self._hook_ref = None
@@ -52,6 +57,28 @@ class VM:
         """Run Forth source; returns the text the VM printed."""
         self._so.ten4_eval(self._h, src.encode())
         return self._so.ten4_output(self._h).decode(errors="replace")
+
+    def rand_tell(self):
+        """Position (in elements) of this VM's Philox stream."""
+        return int(self._so.ten4_rand_tell(self._h))
+
+    def rand_seek(self, off):
+        self._so.ten4_rand_seek(self._h, int(off))
+
+    def fetch(self, expr=None):
+        """Full-precision copy of the tensor `expr` leaves on top of the stack, as a numpy array shaped (N, H, W, C); the
+        stack is left as `expr` left it (callers `drop` what they pushed)."""
+        import numpy as np
+        if expr:
+            self.eval(expr)
+        shp = (ctypes.c_int * 4)()
+        n = self._so.ten4_fetch(self._h, None, 0, ctypes.byref(shp))
+        if n < 0:
+            raise RuntimeError("top of stack is not a tensor")
+        a = np.empty(n, np.float32)
+        self._so.ten4_fetch(self._h, a.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(shp))
+        H, W, C, N = shp
+        return a.reshape(N, H, W, C) if n == N * H * W * C else a
 
     def grad_slab(self):
         """torch view (no copy) of the current model's gradient slab."""

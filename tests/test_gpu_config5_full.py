@@ -1,0 +1,169 @@
+"""GPU: BASELINE config #5 AT ITS OWN SIZE - the t4_30a/30e LeNet net, batch 1024 sharded 8 x 128 - through the product VM.
+
+Eight product VMs (same seed => identical replicas, each with its own Philox stream position, include/ten4.h) train on their 128 rows
+of the 1024-image batch with both dropouts on: shard (r, 8) set with t4k_rand_set_shard, the eight gradient slabs summed and written
+back (exactly what the RCCL all-reduce(SUM) does between `backprop` and `nn.sgd`), then the optimizer word; two steps.  Compared on
+FULL fp32 tensors (ten4_fetch - not the printer's 4-decimal text) at the north_star tolerance, 1e-4 relative per tensor:
+  * against ONE product VM training on the whole 1024-image batch, and
+  * against the CPU oracle VM (oracle/libten4_oracle.so, tests/oracle_vm_worker.py) training on the whole batch;
+the dropout masks of the shards concatenate BIT-EXACTLY to the whole batch's masks (index work: keyed by global sample).
+Only the transport between the ranks is emulated - kernels, fused launch plan, slab layout and host orchestration are the product's.
+The second test runs the same 128-image shard step through a world-1 library communicator with the early-bucket overlap forced
+(T4_DP_OVERLAP=2) and checks it against the same step without a communicator."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from vm_util import ROOT, OracleVM, rel_err
+
+pytestmark = pytest.mark.gpu
+
+NET = "0.5 10 conv2d 2 maxpool relu 0.5 20 conv2d 0.5 dropout 2 maxpool relu flatten 100 linear 0.5 dropout 10 linear softmax"
+PARAMS = [("w0", "0 nn.w"), ("b0", "0 nn.b"), ("w3", "3 nn.w"), ("b3", "3 nn.b"), ("w8", "8 nn.w"), ("b8", "8 nn.b"), ("w10", "10 nn.w"), ("b10", "10 nn.b")]
+GRADS = [("dw0", "0 nn.dw"), ("db0", "0 nn.db"), ("dw3", "3 nn.dw"), ("db3", "3 nn.db"), ("dw8", "8 nn.dw"), ("db8", "8 nn.db"), ("dw10", "10 nn.dw"), ("db10", "10 nn.db")]
+TOL = 1e-4                                                    # north_star: "outputs within 1e-4 relative of the reference"
+
+
+def _setup(vm, n, row0, total):
+    """the net at batch n, rows [row0, row0+n) of the whole batch's image draw, labels by GLOBAL row index"""
+    out = vm.eval("0 trace\n%d 28 28 1 nn.model %s constant net\n" % (n, NET))
+    off0 = vm.rand_tell()
+    vm.rand_seek(off0 + row0 * 784)
+    out += vm.eval("%d 28 28 1 tensor rand constant img\n" % n)
+    vm.rand_seek(off0 + total * 784)
+    out += vm.eval(": hot ( T -- T ) %d 0 do 1 i 10 * i %d + 7 * 10 mod + t! loop ;\n"
+                   "%d vector zeros hot %d 1 10 1 reshape4 constant lbl\n"
+                   ": fb ( N -- N ) img forward lbl backprop ;\n: opt ( N -- N ) 0.01 0.0 nn.sgd ;\n" % (n, row0, n * 10, n))
+    assert "?" not in out.replace("-> ok", ""), out
+    return vm.rand_tell()
+
+
+def _get(vm, expr):
+    a = vm.fetch("net " + expr)                                # ( N -- N T )
+    vm.eval("drop drop")
+    return a
+
+
+def _check(name, got, want, tol=TOL):
+    e = rel_err(got, want)
+    assert e <= tol, "%s: max|d|/max|ref| = %.3g > %.1g" % (name, e, tol)
+
+
+def test_eight_emulated_ranks_x128_equal_one_vm_x1024_equal_the_oracle():
+    import torch
+    from tensorforth_amd import lib as t4lib
+    from tensorforth_amd.vm import VM
+    k = t4lib.load()
+    W, B, seed = 8, 128, 505
+    N = W * B
+    whole = VM(device=0, seed=seed); ranks = [VM(device=0, seed=seed) for _ in range(W)]
+    orc = OracleVM(seed=seed)
+    try:
+        end0 = _setup(whole, N, 0, N)
+        assert _setup(orc, N, 0, N) == end0
+        for r, vm in enumerate(ranks):
+            assert _setup(vm, B, r * B, N) == end0              # identical replicas: every VM is at the same stream position
+        # the shards' images ARE the rows of the whole batch (bit-exact: same Philox slice), on the GPU and in the oracle
+        img_w = whole.fetch("img"); whole.eval("drop")
+        for r, vm in enumerate(ranks):
+            assert np.array_equal(vm.fetch("img"), img_w[r * B:(r + 1) * B]); vm.eval("drop")
+        assert np.array_equal(orc.fetch("img"), img_w); orc.eval("drop")
+        for step in range(2):
+            k.call("t4k_rand_set_shard", 0, 1)
+            whole.eval("net fb\n"); orc.eval("net fb\n")
+            end = whole.rand_tell()
+            assert orc.rand_tell() == end
+            views = []
+            for r, vm in enumerate(ranks):
+                k.call("t4k_rand_set_shard", r, W)
+                vm.eval("net fb\n")
+                assert vm.rand_tell() == end, "a rank moves its stream by the WHOLE batch's draws"
+                views.append(vm.grad_slab())                    # zero-copy view of THIS rank's slab (the model that ran last)
+            torch.cuda.synchronize()
+            total = views[0].clone()
+            for v in views[1:]:
+                total += v                                      # fixed rank order, like a ring's
+            # ---- after backprop, before the optimizer: masks, forward-side tensors and the (summed) gradients
+            k.call("t4k_rand_set_shard", 0, 1)
+            for lab, expr in (("mask_conv", "4 nn.ex"), ("mask_lin", "9 nn.ex")):
+                mw = _get(whole, expr)
+                cat = np.concatenate([_get(vm, expr) for vm in ranks], axis=0)
+                assert np.array_equal(cat.reshape(mw.shape), mw), lab + ": shard masks do not partition the whole batch's mask"
+                assert np.array_equal(_get(orc, expr), mw), lab + " (oracle)"
+            gw = {n_: _get(whole, e) for n_, e in GRADS}; go = {n_: _get(orc, e) for n_, e in GRADS}
+            for v in views:
+                v.copy_(total)                                  # the all-reduce(SUM): raw batch sums (quirk a-19)
+            torch.cuda.synchronize()
+            for n_, e in GRADS:
+                _check("step %d %s: 1 x 1024 vs oracle" % (step, n_), gw[n_], go[n_])
+                _check("step %d %s: SUM of 8 x 128 vs oracle" % (step, n_), _get(ranks[3], e), go[n_])
+            dxo = _get(orc, "0 n@")                             # dX of the image layer, per sample
+            _check("step %d dx: 1 x 1024 vs oracle" % step, _get(whole, "0 n@"), dxo)
+            _check("step %d dx: 8 x 128 vs oracle" % step, np.concatenate([_get(vm, "0 n@") for vm in ranks], axis=0), dxo)
+            whole.eval("opt drop\n"); orc.eval("opt drop\n")
+            for vm in ranks:
+                vm.eval("opt drop\n")
+            # ---- after the optimizer: every parameter tensor, every replica
+            for n_, e in PARAMS:
+                po = _get(orc, e); pw = _get(whole, e); pr = [_get(vm, e) for vm in ranks]
+                _check("step %d %s: 1 x 1024 vs oracle" % (step, n_), pw, po)
+                for r in range(1, W):
+                    assert np.array_equal(pr[r], pr[0]), "replicas diverged at %s" % n_
+                _check("step %d %s: 8 x 128 vs oracle" % (step, n_), pr[0], po)
+                _check("step %d %s: 8 x 128 vs 1 x 1024" % (step, n_), pr[0], pw)
+        # a fresh forward with the trained weights: outputs of the shards == rows of the whole batch's output
+        whole.eval("net img forward\n"); orc.eval("net img forward\n")
+        for r, vm in enumerate(ranks):
+            k.call("t4k_rand_set_shard", r, W); vm.eval("net img forward\n")
+        k.call("t4k_rand_set_shard", 0, 1)
+        oo = _get(orc, "-1 n@")
+        _check("out: 1 x 1024 vs oracle", _get(whole, "-1 n@"), oo)
+        _check("out: 8 x 128 vs oracle", np.concatenate([_get(vm, "-1 n@") for vm in ranks], axis=0), oo)
+    finally:
+        k.call("t4k_rand_set_shard", 0, 1)
+        for vm in [whole, orc] + ranks:
+            vm.close()
+
+
+_OVERLAP = r'''
+import ctypes, os, sys
+sys.path.insert(0, os.environ["T4_ROOT"]); sys.path.insert(0, os.path.join(os.environ["T4_ROOT"], "tests"))
+import numpy as np
+from tensorforth_amd.vm import VM
+from tensorforth_amd import lib as t4lib
+NET = "%s"
+v = VM(device=0, seed=77)
+out = v.eval("0 trace\n128 28 28 1 nn.model " + NET + " constant net\n128 28 28 1 tensor rand constant img\n"
+             ": hot ( T -- T ) 128 0 do 1 i 10 * i 7 * 10 mod + t! loop ;\n1280 vector zeros hot 128 1 10 1 reshape4 constant lbl\n"
+             ": step ( N -- N ) img forward lbl backprop 0.01 0.0 nn.sgd ;\nnet\n")
+assert "?" not in out.replace("-> ok", ""), out
+k = t4lib.load()
+if os.environ.get("WITH_COMM") == "1":
+    raw = (ctypes.c_ubyte * 128)()
+    assert k.lib.t4k_comm_unique_id(raw) == 0 and k.lib.t4k_comm_init(raw, 0, 1) == 0, k.lib.t4k_last_error()
+v.eval("step step step")
+arrs = {}
+for name, e in [("w0", "0 nn.w"), ("b0", "0 nn.b"), ("w3", "3 nn.w"), ("b3", "3 nn.b"), ("w8", "8 nn.w"), ("b8", "8 nn.b"), ("w10", "10 nn.w"), ("b10", "10 nn.b"), ("m4", "4 nn.ex"), ("m9", "9 nn.ex")]:
+    arrs[name] = v.fetch(e); v.eval("drop")
+np.savez(sys.argv[1], **arrs)
+''' % NET
+
+
+def test_config5_shard_step_through_world1_communicator_with_forced_overlap(tmp_path):
+    """the 128-image shard step of config #5 with the library-owned RCCL communicator (world 1) and the early-bucket overlap path
+    forced (T4_DP_OVERLAP=2: event -> communication stream -> all-reduce -> join): bit-identical to the step without a communicator"""
+    f = tmp_path / "ov.py"; f.write_text(_OVERLAP)
+    outs = []
+    for comm in ("0", "1"):
+        npz = str(tmp_path / ("o%s.npz" % comm))
+        env = dict(os.environ, T4_ROOT=ROOT, WITH_COMM=comm, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if comm == "1":
+            env["T4_DP_OVERLAP"] = "2"
+        r = subprocess.run([sys.executable, str(f), npz], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(npz))
+    for name in outs[0].files:
+        assert np.array_equal(outs[0][name], outs[1][name]), name

@@ -30,6 +30,72 @@ def run_vm(binary, script_path=None, source=None, seed=1, timeout=300, env_extra
     return r.stdout
 
 
+class OracleVM:
+    """The CPU oracle VM with the interface of tensorforth_amd.vm.VM (eval / fetch / rand_tell / rand_seek), served by
+    tests/oracle_vm_worker.py in its own process.  `fetch` returns FULL fp32 tensors, so parity is checked on every element
+    at the north_star tolerance instead of on the printer's 4-decimal text."""
+
+    def __init__(self, seed=1234):
+        import sys
+        if not os.path.exists(os.path.join(ROOT, "oracle", "libten4_oracle.so")):
+            raise FileNotFoundError("oracle/libten4_oracle.so not built (make -C oracle)")
+        self._p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oracle_vm_worker.py"), str(seed)],
+                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=dict(os.environ, OMP_NUM_THREADS="1"))
+
+    def _rpc(self, *req):
+        import pickle
+        import struct
+        blob = pickle.dumps(req)
+        self._p.stdin.write(struct.pack("<Q", len(blob))); self._p.stdin.write(blob); self._p.stdin.flush()
+        hdr = self._p.stdout.read(8)
+        assert len(hdr) == 8, "oracle VM worker died"
+        rep = pickle.loads(self._p.stdout.read(struct.unpack("<Q", hdr)[0]))
+        if isinstance(rep, Exception):
+            raise rep
+        return rep
+
+    def eval(self, src):
+        return self._rpc("eval", src)
+
+    def fetch(self, expr=None):
+        a, _txt = self._rpc("fetch", expr)
+        if a is None:
+            raise RuntimeError("top of stack is not a tensor")
+        return a
+
+    def rand_tell(self):
+        return self._rpc("tell")
+
+    def rand_seek(self, off):
+        self._rpc("seek", off)
+
+    def set_shard(self, rank, world):
+        assert self._rpc("shard", rank, world) == 0
+
+    def grad_slab(self):
+        return self._rpc("slab")
+
+    def set_grad_slab(self, a):
+        self._rpc("slab_set", a)
+
+    def close(self):
+        if self._p and self._p.poll() is None:
+            try:
+                self._rpc("quit")
+            except Exception:
+                pass
+            self._p.stdin.close(); self._p.wait(timeout=10)
+        self._p = None
+
+
+def rel_err(got, want):
+    """max |got - want| / max |want| over one tensor: the north_star "1e-4 relative" bar, per tensor and on every element."""
+    import numpy as np
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.max(np.abs(got - want)) / max(1e-30, np.max(np.abs(want))))
+
+
 def tokens(text):
     out = []
     for line in text.splitlines():
