@@ -34,6 +34,8 @@ void ten4_rand_seek(ten4_vm *vm, unsigned long long element_offset);
  * when the top of stack is not a tensor); nothing is copied when cap < count or dst is NULL; shape = {H, W, C, N} if non-NULL.
  * Full-precision read-back for hosts and tests - the printer rounds to 4 decimals, `bin save` to 8 bits (aio_tensor.cpp:240-255). */
 long ten4_fetch(ten4_vm *vm, float *dst, long cap, int shape[4]);
+/* the inverse: fill the tensor on top of the data stack from n host floats (n must equal its element count; returns n or -1) */
+long ten4_store(ten4_vm *vm, const float *src, long n);
 /* Called during `backprop`, on the calling thread, right after the kernels that complete one layer's dW|dB have been
  * enqueued on the VM stream: `off`/`n` locate that layer's segment in the gradient slab (floats).  Layers finish in
  * reverse order, so [off, slab end) is complete (stream-ordered) at each call - a data-parallel launcher can start

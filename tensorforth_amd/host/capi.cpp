@@ -52,6 +52,12 @@ long ten4_fetch(ten4_vm *h, float *dst, long cap, int shape[4]) {
     if (dst && cap >= n && n > 0) { t4k_memcpy_d2h(dst, t->data, (size_t)n * sizeof(float), t4::stream()); t4k_sync(t4::stream()); }
     return n;
 }
+long ten4_store(ten4_vm *h, const float *src, long n) {
+    t4::Tensor *t = h->vm.tos_tensor();
+    if (!t || !src || n != (long)t->numel) return -1;
+    t->from_host(src, (uint64_t)n);
+    return n;
+}
 void ten4_set_grad_hook(ten4_vm *, ten4_grad_hook_fn fn, void *user) { t4::Model::grad_hook = fn; t4::Model::grad_hook_user = user; }
 
 } // extern "C"

@@ -45,6 +45,8 @@ class VM:
         so.ten4_rand_seek.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
         so.ten4_fetch.restype = ctypes.c_long
         so.ten4_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_int * 4)]
+        so.ten4_store.restype = ctypes.c_long
+        so.ten4_store.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
         self._HOOK = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_void_p)
         so.ten4_set_grad_hook.argtypes = [ctypes.c_void_p, self._HOOK, ctypes.c_void_p]
         self._hook_ref = None
@@ -79,6 +81,15 @@ class VM:
         self._so.ten4_fetch(self._h, a.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(shp))
         H, W, C, N = shp
         return a.reshape(N, H, W, C) if n == N * H * W * C else a
+
+    def store(self, array, expr=None):
+        """Fill the tensor `expr` leaves on top of the stack (a view from `nn.w`, `n@` ... writes through) with `array` (fp32)."""
+        import numpy as np
+        if expr:
+            self.eval(expr)
+        a = np.ascontiguousarray(array, np.float32).ravel()
+        if self._so.ten4_store(self._h, a.ctypes.data_as(ctypes.c_void_p), a.size) != a.size:
+            raise RuntimeError("top of stack is not a tensor of %d elements" % a.size)
 
     def grad_slab(self):
         """torch view (no copy) of the current model's gradient slab."""

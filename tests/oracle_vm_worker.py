@@ -3,7 +3,7 @@
 Test infrastructure only (the oracle is the checker, never the product).  It runs in a process of its own so that the oracle's
 t4k_* / t4:: symbols can never meet the product's (libt4hip.so / libten4.so) in one address space.  Protocol on stdin/stdout:
 length-prefixed pickles, one request -> one reply; requests are tuples ("eval", src) ("fetch", expr) ("tell",) ("seek", off)
-("shard", rank, world) ("slab",) ("slab_set", ndarray) ("quit",)."""
+("store", expr, ndarray) ("shard", rank, world) ("slab",) ("slab_set", ndarray) ("quit",)."""
 import ctypes
 import os
 import pickle
@@ -28,6 +28,8 @@ def main():
     so.ten4_rand_seek.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
     so.ten4_fetch.restype = ctypes.c_long
     so.ten4_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_int * 4)]
+    so.ten4_store.restype = ctypes.c_long
+    so.ten4_store.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
     so.ten4_grad_slab.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long)]
     so.t4k_rand_set_shard.argtypes = [ctypes.c_int, ctypes.c_int]
     h = so.ten4_new(-1, seed, 0)
@@ -62,6 +64,11 @@ def main():
             if req[1]:
                 so.ten4_eval(h, req[1].encode()); txt = so.ten4_output(h).decode(errors="replace")
             rep = (fetch(), txt)
+        elif op == "store":
+            if req[1]:
+                so.ten4_eval(h, req[1].encode()); so.ten4_output(h)
+            a = np.ascontiguousarray(req[2], np.float32).ravel()
+            rep = int(so.ten4_store(h, a.ctypes.data_as(ctypes.c_void_p), a.size))
         elif op == "tell":
             rep = int(so.ten4_rand_tell(h))
         elif op == "seek":

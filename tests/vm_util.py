@@ -63,6 +63,11 @@ class OracleVM:
             raise RuntimeError("top of stack is not a tensor")
         return a
 
+    def store(self, array, expr=None):
+        import numpy as np
+        a = np.ascontiguousarray(array, np.float32)
+        assert self._rpc("store", expr, a) == a.size, "top of stack is not a tensor of %d elements" % a.size
+
     def rand_tell(self):
         return self._rpc("tell")
 
