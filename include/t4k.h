@@ -302,6 +302,28 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *blk, int N, int H1, i
  * layer takes the gather-MFMA kernel (the pool window is four consecutive accumulator registers of a lane) */
 int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
                          int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P, t4k_stream_t s);
+/* SAMPLE-RESIDENT convolution stack (csrc/conv_stack.hip): 1..3 stages of [conv2d KxK, stride 1, padding K/2 (K = 3 | 5; _fconv
+ * forward.cu:115-155, k_conv2d nmath.tcu:34-104) + the element-wise run behind it (t4k_poolblock; 2x2 pool or none)], one workgroup
+ * per image with the activations in LDS, ONE launch for the whole stack each way.  Stage s+1 reads the result of stage s's run
+ * (H, W of stage s+1 = the pooled grid, C1 = C0 of stage s); only the last run may carry a flatten copy.  Every tensor the separate
+ * layers write is written, dropout draws the same Philox slices in layer order.
+ * Backward (_bconv backprop.cu:152-191, k_dconv2d nmath.tcu:211-338 incl. its un-flipped dX; _bactivate, _bpool): DY = gradient
+ * w.r.t. the last run's last tensor; every run stage's input buffer receives its dX, each conv's input tensor X (forward values on
+ * entry) receives dX (`in = dx`) and so does DXS when not NULL; train != 0: DF += sum over the batch, DB likewise (per-image
+ * partials in the library workspace, folded in image order by a second small launch - deterministic). */
+typedef struct t4k_conv_stage {
+    const float *F, *B;       /* filter T4(C1,K,K,C0), bias [C0] */
+    float *O;                 /* conv output [N,H,W,C0] */
+    float *DF, *DB;           /* backward: parameter gradients (accumulated); unused by the forward */
+    float *X, *DXS;           /* backward: the conv's input tensor [N,H,W,C1] and the optional second dX copy */
+    int H, W, C1, C0, K;
+    t4k_poolblock run;        /* all-zero layers + KS = 1: no run */
+} t4k_conv_stage;
+int t4k_conv_stack_ok(const t4k_conv_stage *st, int n_stage, int N);           /* 1 when the stack qualifies (shapes, layers, LDS) and its kernels are built */
+int t4k_conv_stack_selftest(void);   /* the stack kernels are compiled at run time (hipRTC) for the model's shapes: this compiles two reference
+                                      * shape sets for gfx950 - no device needed - and returns 0, or an error with the compiler log in t4k_last_error() */
+int t4k_conv_stack_fwd(const float *X, float *XCOPY, const t4k_conv_stage *st, int n_stage, int N, t4k_stream_t s);
+int t4k_conv_stack_bwd(const float *DY, const t4k_conv_stage *st, int n_stage, int N, int train, t4k_stream_t s);
 /* backward of the same run (_bactivate backprop.cu:256-263, _bpool, flatten `in = out`): DY is the gradient
  * w.r.t. the run's last tensor; each stage's input buffer receives its dX (X receives the run's dX). */
 int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);

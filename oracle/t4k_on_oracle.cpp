@@ -265,4 +265,9 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab, int nt, int, float lr, f
     return t4k_opt_multi(kind, tab, nt, 0, lr, b1, b2, wd, st);
 }
 
+// the sample-resident conv stack is a launch-count optimisation of the product: the oracle VM always runs the separate layers
+int t4k_conv_stack_ok(const t4k_conv_stage *, int, int) { return 0; }
+int t4k_conv_stack_fwd(const float *, float *, const t4k_conv_stage *, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
+int t4k_conv_stack_bwd(const float *, const t4k_conv_stage *, int, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
+
 } // extern "C"

@@ -100,6 +100,7 @@ Model *Model::current = nullptr;
 void (*Model::grad_hook)(int, long, long, void *) = nullptr;
 void *Model::grad_hook_user = nullptr;
 bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
+bool Model::use_stack  = getenv("T4_STACK") ? atoi(getenv("T4_STACK")) != 0 : true;
 bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
 
@@ -170,6 +171,31 @@ void Model::plan_runs() {
         run_of_[i] = (int)runs_.size(); runs_.push_back(r);
         i = j;
     }
+}
+// A run of [conv KxK stride 1 "same" + element-wise run] blocks that one workgroup per image can carry through LDS (conv_stack.hip).
+// Returns the number of stages (0: layer i does not start such a stack), fills the C-ABI stage records for both directions.
+int Model::stack_at(int i, t4k_conv_stage *st, int &ops) {
+    const int L = (int)layer.size() - 1;
+    int ns = 0, j = i, cnt[3] = {0, 0, 0};
+    while (ns < 3 && j < L && at(j).grad_fn == T4K_L_CONV) {
+        Tensor &in = at(j), &out = at(j + 1);
+        const int K = in.grad[0]->H();
+        if (in.stride[0] != 1 || in.stride[2] != K / 2 || !(K & 1) || out.H() != in.H() || out.W() != in.W()) break;
+        t4k_conv_stage &t = st[ns]; memset(&t, 0, sizeof(t));
+        t.F = in.grad[0]->data; t.B = in.grad[1]->data; t.O = out.data;
+        t.DF = in.grad[2] ? in.grad[2]->data : nullptr; t.DB = in.grad[3] ? in.grad[3]->data : nullptr;
+        t.X = in.data; t.DXS = in.grad[4] ? in.grad[4]->data : nullptr;
+        t.H = in.H(); t.W = in.W(); t.C1 = in.C(); t.C0 = out.C(); t.K = K;
+        t.run.KS = 1;
+        cnt[ns] = 1;
+        if (j + 1 < L && run_of_[j + 1] >= 0) { const Run &r = runs_[run_of_[j + 1]]; t.run = r.blk; cnt[ns] += r.count; }
+        j += cnt[ns]; ns++;
+        if (t.run.copy_out) break;                          // a flatten closes the stack
+    }
+    while (ns > 0 && !t4k_conv_stack_ok(st, ns, at(i).N())) ns--;     // longest prefix the kernel can hold
+    ops = 0;
+    for (int s = 0; s < ns; s++) ops += cnt[s];
+    return ns;
 }
 t4k_stream_t Model::fork() {
     if (!concurrent()) return stream();
@@ -306,6 +332,15 @@ void Model::run_forward(Tensor &input) {
             chk(t4k_linear_softmax_fwd(x, in.grad[0]->data, in.grad[1]->data, out.data, prob.data, out.N(), (int)out.HWC(), (int)in.HWC(), stream()), "nn#flinear+softmax");
             x = prob.data; i++;
             continue;
+        }
+        if (fused && use_stack && in.grad_fn == T4K_L_CONV) {   // [conv + run] x n, one workgroup per image, activations in LDS: ONE launch
+            t4k_conv_stage stg[3]; int ops = 0;
+            const int ns = stack_at(i, stg, ops);
+            if (ns >= 2 || (ns == 1 && stack_single_)) {
+                chk(t4k_conv_stack_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, stg, ns, in.N(), stream()), "nn#fstack");
+                x = at(i + ops).data; i += ops - 1;
+                continue;
+            }
         }
         if (fused && in.grad_fn == T4K_L_CONV && i + 2 < L && run_of_[i + 1] >= 0 && runs_[run_of_[i + 1]].blk.pool_layer &&
             runs_[run_of_[i + 1]].blk.KS == 2) {        // conv + the element-wise run behind it: the run rides in the conv epilogue

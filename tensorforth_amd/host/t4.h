@@ -271,6 +271,10 @@ private:
     std::vector<Run> runs_;
     void plan_runs();
     static bool use_fusion;                    // T4_FUSE=0 keeps one launch per layer
+    bool stack_single_ = false;                // single-stage stacks too (measured: off)
+    static bool use_stack;                     // T4_STACK=0: no sample-resident conv stacks (csrc/conv_stack.hip)
+    // sample-resident conv stack starting at layer i: [conv + run] x ns (stages filled for the C-ABI); ops = layers it covers
+    int  stack_at(int i, t4k_conv_stage *st, int &ops);
     bool finalized_ = false, side_dirty_ = false, capturable_ = true;
     bool concurrent() const { return side_ != nullptr && !(trace && *trace); }
     t4k_stream_t fork();                       // side stream, ordered after everything issued on main so far

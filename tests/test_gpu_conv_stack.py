@@ -1,0 +1,227 @@
+"""GPU parity of the sample-resident convolution stack (csrc/conv_stack.hip: t4k_conv_stack_fwd / _bwd) against the oracle's
+SEPARATE layers - conv2d, activate / dropout (Philox slice of t4k_rand), pool, dpool, mask multiplies, conv2d backward - on every
+tensor the separate layers write.  Forward: 1e-4 relative (dropout masks and the layer-0 copy bit-exact, Philox stream advanced
+identically).  Backward: the GPU buffers are loaded with the ORACLE's forward state first, so arg-max positions and derivative masks are
+the same on both sides and every dX / dF / dB is compared at 1e-4 relative."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import Dev, PoolBlock, p, rel
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+class ConvStage(ctypes.Structure):
+    _fields_ = [("F", ctypes.c_void_p), ("B", ctypes.c_void_p), ("O", ctypes.c_void_p), ("DF", ctypes.c_void_p), ("DB", ctypes.c_void_p),
+                ("X", ctypes.c_void_p), ("DXS", ctypes.c_void_p),
+                ("H", ctypes.c_int), ("W", ctypes.c_int), ("C1", ctypes.c_int), ("C0", ctypes.c_int), ("K", ctypes.c_int),
+                ("run", PoolBlock)]
+
+
+@pytest.fixture(scope="module")
+def dev(t4k):
+    return Dev(t4k)
+
+
+def _lay(oracle):
+    return {"dropout": (oracle.L_DROPOUT, 0.5), "relu": (oracle.L_RELU, 0.0), "leaky": (oracle.L_LEAKYRL, 0.1), "tanh": (oracle.L_TANH, 0.0),
+            "elu": (oracle.L_ELU, 1.0), "max": oracle.L_MAXPOOL, "avg": oracle.L_AVGPOOL, "min": oracle.L_MINPOOL}
+
+
+# (N, H, W, C_in, [(C0, K, pre, pool, post)], flatten)
+CASES = [
+    (128, 28, 28, 1, [(10, 3, None, "max", "relu"), (20, 3, "dropout", "max", "relu")], True),      # the LeNet front end of bench.py
+    (5, 12, 8, 3, [(8, 5, "relu", "avg", None), (6, 3, None, None, "tanh")], False),               # 5x5, non-square, a stage without pool
+    (3, 16, 16, 2, [(7, 3, "leaky", "max", "dropout"), (9, 3, None, "min", "elu"), (4, 3, "dropout", None, None)], True),   # 3 stages, odd channels
+    (2, 8, 8, 4, [(32, 3, None, "max", "relu")], True),                                             # one stage, two channel tiles
+    (1, 6, 6, 1, [(3, 3, None, None, None), (5, 3, None, "max", None)], False),                     # a bare conv in front
+]
+
+
+def _oracle_forward(oracle, X, stages, flat, params, seed, off):
+    """the separate layers; returns per stage a dict of every tensor written"""
+    o = oracle.lib(); P = oracle.P; LAY = _lay(oracle)
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    N = X.shape[0]
+    x = X; out = []
+    for si, (C0, K, pre, pool, post) in enumerate(stages):
+        F, B = params[si]
+        H, W, C1 = x.shape[1:]
+        Y = np.zeros((N, H, W, C0), np.float32)
+        assert o.t4o_conv2d_fwd(P(x), P(Y), P(F), P(B), N, H, W, C1, H, W, C0, K, 1, K // 2) == 0
+        t = {"in": x, "O": Y}; cur = Y
+        if pre:
+            L, a = LAY[pre]; f = np.zeros(cur.size, np.float32); y = np.zeros_like(cur)
+            if pre == "dropout":
+                o.t4o_rand(P(f), f.size, 0, 0.0, 1.0)
+            o.t4o_activate(L, P(cur), P(y), P(f), a, cur.size); t["pre_mask"] = f.reshape(cur.shape); t["pre_out"] = y; cur = y
+        if pool:
+            q = np.zeros((N, H // 2, W // 2, C0), np.float32)
+            o.t4o_pool(LAY[pool], P(cur), P(q), N, H, W, H // 2, W // 2, C0, 2); t["pool_out"] = q; cur = q
+        if post:
+            L, a = LAY[post]; f = np.zeros(cur.size, np.float32); y = np.zeros_like(cur)
+            if post == "dropout":
+                o.t4o_rand(P(f), f.size, 0, 0.0, 1.0)
+            o.t4o_activate(L, P(cur), P(y), P(f), a, cur.size); t["post_mask"] = f.reshape(cur.shape); t["post_out"] = y; cur = y
+        if flat and si == len(stages) - 1:
+            t["copy_out"] = cur.copy()
+        t["last"] = cur
+        out.append(t); x = cur
+    return out, o.t4o_rand_offset()
+
+
+def _build(dev, oracle, X, stages, flat, params, ref):
+    """device buffers + the t4k_conv_stage array"""
+    LAY = _lay(oracle)
+    arr = (ConvStage * len(stages))()
+    bufs = []
+    for si, (C0, K, pre, pool, post) in enumerate(stages):
+        t = ref[si]; d = {k: dev.zeros(v.shape) for k, v in t.items() if k not in ("in", "last")}
+        F, B = params[si]
+        d["F"], d["B"] = dev.up(F), dev.up(B)
+        d["DF"], d["DB"] = dev.zeros(F.shape), dev.zeros(B.shape)
+        # the conv's input tensor: for s > 0 it IS the last tensor of the run in front (the model's layers share it)
+        prev_last = None
+        if si > 0:
+            pt = stages[si - 1]; pd = bufs[si - 1]
+            prev_last = pd["post_out"] if pt[4] else (pd["pool_out"] if pt[3] else (pd["pre_out"] if pt[2] else pd["O"]))
+        d["X"] = prev_last if prev_last is not None else dev.zeros(t["in"].shape); d["DXS"] = dev.zeros(t["in"].shape)
+        s = arr[si]
+        s.F, s.B, s.O, s.DF, s.DB, s.X, s.DXS = p(d["F"]), p(d["B"]), p(d["O"]), p(d["DF"]), p(d["DB"]), p(d["X"]), p(d["DXS"])
+        s.H, s.W, s.C1, s.C0, s.K = t["in"].shape[1], t["in"].shape[2], t["in"].shape[3], C0, K
+        b = s.run; b.KS = 2 if pool else 1
+        if pre:
+            b.pre_layer, b.pre_alpha = LAY[pre]; b.pre_mask = p(d["pre_mask"]); b.pre_out = p(d["pre_out"])
+        if pool:
+            b.pool_layer = LAY[pool]; b.pool_out = p(d["pool_out"])
+        if post:
+            b.post_layer, b.post_alpha = LAY[post]; b.post_mask = p(d["post_mask"]); b.post_out = p(d["post_out"])
+        if "copy_out" in t:
+            b.copy_out = p(d["copy_out"])
+        bufs.append(d)
+    return arr, bufs
+
+
+def _params(rng, Cin, stages):
+    out = []; c1 = Cin
+    for C0, K, *_ in stages:
+        out.append(((rng.standard_normal((c1, K, K, C0)) * 0.3).astype(np.float32), rng.standard_normal(C0).astype(np.float32)))
+        c1 = C0
+    return out
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_conv_stack_forward_matches_the_separate_layers(t4k, dev, oracle, case):
+    N, H, W, Cin, stages, flat = CASES[case]
+    rng = np.random.default_rng(100 + case)
+    X = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    params = _params(rng, Cin, stages)
+    seed, off = 1234 + case, 4096 * (case + 1)
+    ref, end = _oracle_forward(oracle, X, stages, flat, params, seed, off)
+    arr, bufs = _build(dev, oracle, X, stages, flat, params, ref)
+    assert t4k.lib.t4k_conv_stack_ok(arr, len(stages), N) == 1
+    t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+    dX, dX0 = dev.up(X), dev.zeros(X.shape)
+    t4k.call("t4k_conv_stack_fwd", p(dX), p(dX0), arr, len(stages), N, None)
+    assert np.array_equal(dev.down(dX0), X)                                  # the model's layer-0 copy
+    assert t4k.lib.t4k_rand_offset() == end                                  # Philox stream advanced exactly as the separate layers do
+    for si, (C0, K, pre, pool, post) in enumerate(stages):
+        t, d = ref[si], bufs[si]
+        for k_ in ("O", "pre_mask", "pre_out", "pool_out", "post_mask", "post_out", "copy_out"):
+            if k_ not in t:
+                continue
+            got = dev.down(d[k_]).reshape(t[k_].shape)
+            if k_.endswith("mask"):
+                which = pre if k_ == "pre_mask" else post
+                if which == "dropout":
+                    assert np.array_equal(got, t[k_]), "stage %d %s" % (si, k_)   # same Philox slice: bit-exact
+                else:
+                    # derivative masks flip where a pre-activation sits within rounding of the kink: all but a few elements equal
+                    assert np.mean(np.abs(got - t[k_]) > 1e-3) < 1e-4, "stage %d %s" % (si, k_)
+                continue
+            assert rel(got, t[k_]) < RTOL, "stage %d %s: %.3g" % (si, k_, rel(got, t[k_]))
+
+
+def _oracle_backward(oracle, ref, stages, flat, params, DY):
+    """the separate layers in reverse, in the reference's in-place convention; returns per stage the buffers after backprop"""
+    o = oracle.lib(); P = oracle.P; LAY = _lay(oracle)
+    out = [None] * len(stages)
+    g = DY
+    for si in range(len(stages) - 1, -1, -1):
+        C0, K, pre, pool, post = stages[si]
+        t = {k: v.copy() for k, v in ref[si].items()}
+        F, B = params[si]
+        X = t["in"]; N, H, W, C1 = X.shape
+        last = "post_out" if post else ("pool_out" if pool else ("pre_out" if pre else "O"))
+        g = g.reshape(t[last].shape)
+        if "copy_out" in t:
+            t[last][...] = g                                                  # flatten: in = out
+        if post:
+            tgt = "pool_out" if pool else ("pre_out" if pre else "O")
+            r = np.zeros(g.size, np.float32); o.t4o_tt_op(oracle.MUL, P(np.ascontiguousarray(g)), P(t["post_mask"]), P(r), g.size)
+            t[tgt][...] = r.reshape(t[tgt].shape); g = t[tgt].copy()
+        if pool:
+            tgt = "pre_out" if pre else "O"
+            o.t4o_dpool(LAY[pool], P(t[tgt]), P(np.ascontiguousarray(g)), N, H, W, H // 2, W // 2, C0, 2); g = t[tgt].copy()
+        if pre:
+            r = np.zeros(g.size, np.float32); o.t4o_tt_op(oracle.MUL, P(np.ascontiguousarray(g)), P(t["pre_mask"]), P(r), g.size)
+            t["O"][...] = r.reshape(t["O"].shape); g = t["O"].copy()
+        DX = np.zeros_like(X); DF = np.zeros_like(F); DB = np.zeros_like(B)
+        assert o.t4o_conv2d_bwd(P(X), P(np.ascontiguousarray(g)), P(DX), P(F), P(DF), P(DB), N, H, W, C1, H, W, C0, K, 1, K // 2, 1) == 0
+        t["DX"], t["DF"], t["DB"] = DX, DF, DB
+        out[si] = t; g = DX
+    return out
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_conv_stack_backward_matches_the_separate_layers(t4k, dev, oracle, case):
+    N, H, W, Cin, stages, flat = CASES[case]
+    if any(a in ("sigmoid",) for st_ in stages for a in st_[2:]):
+        pytest.skip("pass-through activation")
+    rng = np.random.default_rng(200 + case)
+    X = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    params = _params(rng, Cin, stages)
+    ref, _end = _oracle_forward(oracle, X, stages, flat, params, 77 + case, 8192)
+    arr, bufs = _build(dev, oracle, X, stages, flat, params, ref)
+    assert t4k.lib.t4k_conv_stack_ok(arr, len(stages), N) == 1
+    # load the ORACLE's forward state: same arg-max positions and masks on both sides
+    for si in range(len(stages)):
+        for k_, v in ref[si].items():
+            if k_ in bufs[si]:
+                bufs[si][k_].copy_(dev.torch.from_numpy(np.ascontiguousarray(v)))
+        if si == 0:
+            bufs[0]["X"].copy_(dev.torch.from_numpy(X))
+        # pre-existing gradient values: the fold must ADD (gradient accumulation over several backprops)
+        bufs[si]["DF"].fill_(0.25); bufs[si]["DB"].fill_(-0.5)
+    DY = rng.standard_normal(ref[-1]["last"].shape).astype(np.float32)
+    want = _oracle_backward(oracle, ref, stages, flat, params, DY)
+    t4k.call("t4k_conv_stack_bwd", p(dev.up(DY)), arr, len(stages), N, 1, None)
+    for si in range(len(stages) - 1, -1, -1):
+        t, d = want[si], bufs[si]
+        C0, K, pre, pool, post = stages[si]
+        assert rel(dev.down(d["DXS"]), t["DX"]) < RTOL, "stage %d dX (scratch copy): %.3g" % (si, rel(dev.down(d["DXS"]), t["DX"]))
+        assert np.array_equal(dev.down(d["X"]), dev.down(d["DXS"])), "stage %d: in = dx" % si
+        assert rel(dev.down(d["DF"]) - 0.25, t["DF"]) < RTOL, "stage %d dF: %.3g" % (si, rel(dev.down(d["DF"]) - 0.25, t["DF"]))
+        assert rel(dev.down(d["DB"]) + 0.5, t["DB"]) < RTOL, "stage %d dB: %.3g" % (si, rel(dev.down(d["DB"]) + 0.5, t["DB"]))
+        last = "post_out" if post else ("pool_out" if pool else ("pre_out" if pre else "O"))
+        for k_ in ("O", "pre_out", "pool_out", "post_out"):
+            if k_ not in t:
+                continue
+            if si + 1 < len(stages) and k_ == last:
+                continue                                   # shared with the next stage's input tensor: holds that stage's dX (checked above)
+            if k_ == last and "copy_out" not in t:
+                continue                                   # the run's last tensor without a flatten behind it: nothing writes it
+            got = dev.down(d[k_]).reshape(t[k_].shape)
+            assert rel(got, t[k_]) < RTOL, "stage %d bwd %s: %.3g" % (si, k_, rel(got, t[k_]))
+
+
+def test_conv_stack_refuses_what_it_cannot_hold(t4k, dev, oracle):
+    arr = (ConvStage * 1)()
+    s = arr[0]; s.H, s.W, s.C1, s.C0, s.K = 32, 32, 64, 64, 3; s.run.KS = 1
+    s.F = s.B = s.O = 1                                                      # non-null placeholders: the check is on shapes
+    assert t4k.lib.t4k_conv_stack_ok(arr, 1, 4) == 0                         # 64 channels: the LDS-staged MFMA GEMM kernels' territory
+    s.C1, s.C0, s.K = 4, 4, 4
+    assert t4k.lib.t4k_conv_stack_ok(arr, 1, 4) == 0                         # even kernel size

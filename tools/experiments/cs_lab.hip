@@ -1,0 +1,44 @@
+// cs_lab.hip - lab harness for the conv-stack kernels (csrc/conv_stack.hip): event timing of the LeNet front end through the C-ABI.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/experiments/cs_lab.hip -L tensorforth_amd -lt4hip -Wl,-rpath,'$ORIGIN/../../tensorforth_amd' -o tools/experiments/cs_lab.bin
+//   usage: cs_lab.bin [N] [fwd|bwd]      (T4K_STACK_SPLIT=1|2|4 forces the number of bands per image)
+#include <hip/hip_runtime.h>
+#include "t4k.h"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <cstdlib>
+static float *dalloc(size_t n, bool rnd = false) {
+    float *d; hipMalloc((void **)&d, n * 4);
+    std::vector<float> h(n, 0.f); if (rnd) for (auto &v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d;
+}
+int main(int argc, char **argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 128;
+    if (t4k_init(0) != 0) { printf("init failed\n"); return 1; }
+    t4k_conv_stage st[2]; memset(st, 0, sizeof(st));
+    st[0].H = 28; st[0].W = 28; st[0].C1 = 1; st[0].C0 = 10; st[0].K = 3;
+    st[1].H = 14; st[1].W = 14; st[1].C1 = 10; st[1].C0 = 20; st[1].K = 3;
+    for (int s = 0; s < 2; s++) {
+        t4k_conv_stage &t = st[s];
+        t.F = dalloc(t.C1 * 9 * t.C0, true); t.B = dalloc(t.C0, true); t.O = dalloc((size_t)N * t.H * t.W * t.C0);
+        t.DF = dalloc(t.C1 * 9 * t.C0); t.DB = dalloc(t.C0); t.X = dalloc((size_t)N * t.H * t.W * t.C1, true); t.DXS = dalloc((size_t)N * t.H * t.W * t.C1);
+        t4k_poolblock &b = t.run; b.KS = 2; b.pool_layer = T4K_L_MAXPOOL; b.pool_out = dalloc((size_t)N * t.H * t.W * t.C0 / 4);
+        b.post_layer = T4K_L_RELU; b.post_mask = dalloc((size_t)N * t.H * t.W * t.C0 / 4); b.post_out = dalloc((size_t)N * t.H * t.W * t.C0 / 4);
+        if (s == 1) { b.pre_layer = T4K_L_DROPOUT; b.pre_alpha = 0.5f; b.pre_mask = dalloc((size_t)N * t.H * t.W * t.C0); b.pre_out = dalloc((size_t)N * t.H * t.W * t.C0);
+                      b.copy_out = dalloc((size_t)N * t.H * t.W * t.C0 / 4); }
+    }
+    float *X = dalloc((size_t)N * 784, true), *X0 = dalloc((size_t)N * 784), *DY = dalloc((size_t)N * 980, true);
+    const char *mode = argc > 2 ? argv[2] : "fwd";
+    const bool bwd = mode[0] == 'b';
+    printf("N=%d mode=%s ok=%d\n", N, mode, t4k_conv_stack_ok(st, 2, N));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipStream_t ls = (hipStream_t)t4k_default_stream();
+    for (int rep = 0; rep < 4; rep++) {
+        hipEventRecord(e0, ls);
+        int rc = 0;
+        for (int i = 0; i < 200; i++) rc |= bwd ? t4k_conv_stack_bwd(DY, st, 2, N, 1, nullptr) : t4k_conv_stack_fwd(X, X0, st, 2, N, nullptr);
+        hipEventRecord(e1, ls); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); printf("%s: %.2f us per call (rc %d %s)\n", mode, ms * 1000 / 200, rc, rc ? t4k_last_error() : "");
+    }
+    return 0;
+}
