@@ -142,6 +142,7 @@ void Model::finalize() {                                // gradient slab: SURVEY
     if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }                  // parameter table holds the old pointers
     if (use_side && !side_) chk(t4k_stream_create(&side_), "side stream");
     plan_runs();
+    stack_end_.clear();
     t4k_sync(stream());
 }
 // Fused element-wise runs: [dropout|activation] [pool] [activation] [flatten] -> one launch each way (csrc/fused.hip).
@@ -584,6 +585,26 @@ void Model::run_backward(Tensor &tgt) {
         if (trace && *trace)
             hprintf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.xparm, o.sum() / o.N() / o.C(), o.N(), o.H(), o.W(), o.C());
+        if (fused && use_stack && j > 0) {              // does a sample-resident conv stack END at op i?  [conv + run] x n backward in ONE launch (+ the partial fold)
+            if (stack_end_.empty()) {                   // op index of a stack's last op -> its first op (conv layer), built once per finalize
+                stack_end_.assign(layer.size(), -1);
+                for (int k = 0; k + 1 < (int)layer.size(); ) {
+                    t4k_conv_stage stg[3]; int ops = 0;
+                    const int ns = at(k).grad_fn == T4K_L_CONV ? stack_at(k, stg, ops) : 0;
+                    if (ns >= 2 || (ns == 1 && stack_single_)) { stack_end_[k + ops - 1] = k; k += ops; } else k++;
+                }
+            }
+            if (stack_end_[i] >= 0) {
+                const int k0 = stack_end_[i];
+                t4k_conv_stage stg[3]; int ops = 0;
+                const int ns = stack_at(k0, stg, ops);
+                if (ns > 0 && k0 + ops - 1 == i && chk(t4k_conv_stack_bwd(dy, stg, ns, at(k0).N(), train ? 1 : 0, s), "nn#bstack") == T4K_OK) {
+                    for (int k = i; k >= k0; k--) if (at(k).grad_fn == T4K_L_CONV) grads_ready(k, at(k));      // slab segments complete, last layer first
+                    dy = at(k0).data; j += i - k0; i = k0;
+                    continue;
+                }
+            }
+        }
         if (fused && j > 0) {                           // does a fused run END at op i?
             int rf = -1;
             for (int k = i; k >= 0 && k > i - 4; k--) if (run_of_[k] >= 0 && k + runs_[run_of_[k]].count - 1 == i) { rf = k; break; }

@@ -271,6 +271,7 @@ private:
     std::vector<Run> runs_;
     void plan_runs();
     static bool use_fusion;                    // T4_FUSE=0 keeps one launch per layer
+    std::vector<int> stack_end_;              // last op of a conv stack -> its first op (run_backward), rebuilt after finalize
     bool stack_single_ = false;                // single-stage stacks too (measured: off)
     static bool use_stack;                     // T4_STACK=0: no sample-resident conv stacks (csrc/conv_stack.hip)
     // sample-resident conv stack starting at layer i: [conv + run] x ns (stages filled for the C-ABI); ops = layers it covers

@@ -15,6 +15,8 @@ static float *dalloc(size_t n, bool rnd = false) {
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 128;
     if (t4k_init(0) != 0) { printf("init failed\n"); return 1; }
+    unsigned long long *prof; hipMalloc((void **)&prof, (size_t)N * 4 * 32 * 8); hipMemset(prof, 0, (size_t)N * 4 * 32 * 8);
+    { static char e[64]; snprintf(e, sizeof(e), "T4K_STACK_PROF_PTR=%llx", (unsigned long long)prof); if (getenv("CS_LAB_PROF")) putenv(e); }
     t4k_conv_stage st[2]; memset(st, 0, sizeof(st));
     st[0].H = 28; st[0].W = 28; st[0].C1 = 1; st[0].C0 = 10; st[0].K = 3;
     st[1].H = 14; st[1].W = 14; st[1].C1 = 10; st[1].C0 = 20; st[1].K = 3;
@@ -39,6 +41,16 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 200; i++) rc |= bwd ? t4k_conv_stack_bwd(DY, st, 2, N, 1, nullptr) : t4k_conv_stack_fwd(X, X0, st, 2, N, nullptr);
         hipEventRecord(e1, ls); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); printf("%s: %.2f us per call (rc %d %s)\n", mode, ms * 1000 / 200, rc, rc ? t4k_last_error() : "");
+    }
+    if (getenv("CS_LAB_PROF")) {
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)N * 32); hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
+        printf("  stamp: cycles since the workgroup's stamp 0, averaged over workgroups\n");
+        for (int k = 1; k < 32; k++) {
+            double sum = 0; int cnt = 0;
+            for (int b = 0; b < N; b++) if (h[b * 32 + k] && h[b * 32]) { sum += (double)(h[b * 32 + k] - h[b * 32]); cnt++; }
+            if (cnt) printf("  %2d: %8.0f\n", k, sum / cnt);
+        }
     }
     return 0;
 }
