@@ -44,3 +44,11 @@ def test_header_cites_reference_lines():
     text = open(os.path.join(ROOT, "include", "t4k.h")).read()
     for needle in ("k_gemm_tile_claude :478", "nmath.tcu:34", "nmath.tcu:211", "nmath.cu:419", "tensor.cu:344"):
         assert needle in text
+
+
+def test_conv_stack_device_source_compiles_for_gfx950_without_a_device():
+    """The sample-resident conv-stack kernels are specialised at run time (hipRTC) for a model's shapes; the embedded source must
+    compile for gfx950 here, with no GPU: the LeNet front end of bench.py and a three-stage stack with every layer kind."""
+    from tensorforth_amd.lib import T4K
+    h = T4K()
+    assert h.lib.t4k_conv_stack_selftest() == 0, h.lib.t4k_last_error().decode(errors="replace")[-3000:]

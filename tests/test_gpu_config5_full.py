@@ -21,71 +21,7 @@ from vm_util import ROOT, OracleVM, rel_err
 
 pytestmark = pytest.mark.gpu
 
-NET = "0.5 10 conv2d 2 maxpool relu 0.5 20 conv2d 0.5 dropout 2 maxpool relu flatten 100 linear 0.5 dropout 10 linear softmax"
-PARAMS = [("w0", "0 nn.w"), ("b0", "0 nn.b"), ("w3", "3 nn.w"), ("b3", "3 nn.b"), ("w8", "8 nn.w"), ("b8", "8 nn.b"), ("w10", "10 nn.w"), ("b10", "10 nn.b")]
-GRADS = [("dw0", "0 nn.dw"), ("db0", "0 nn.db"), ("dw3", "3 nn.dw"), ("db3", "3 nn.db"), ("dw8", "8 nn.dw"), ("db8", "8 nn.db"), ("dw10", "10 nn.dw"), ("db10", "10 nn.db")]
-TOL = 1e-4                                                    # north_star: "outputs within 1e-4 relative of the reference"
-
-
-def _setup(vm, n, row0, total):
-    """the net at batch n, rows [row0, row0+n) of the whole batch's image draw, labels by GLOBAL row index"""
-    out = vm.eval("0 trace\n%d 28 28 1 nn.model %s constant net\n" % (n, NET))
-    off0 = vm.rand_tell()
-    vm.rand_seek(off0 + row0 * 784)
-    out += vm.eval("%d 28 28 1 tensor rand constant img\n" % n)
-    vm.rand_seek(off0 + total * 784)
-    out += vm.eval(": hot ( T -- T ) %d 0 do 1 i 10 * i %d + 7 * 10 mod + t! loop ;\n"
-                   "%d vector zeros hot %d 1 10 1 reshape4 constant lbl\n"
-                   ": fw ( N -- N ) img forward ;\n: bw ( N -- N ) lbl backprop ;\n: opt ( N -- N ) 0.01 0.0 nn.sgd ;\n" % (n, row0, n * 10, n))
-    assert "?" not in out.replace("-> ok", ""), out
-    return vm.rand_tell()
-
-
-def _get(vm, expr):
-    a = vm.fetch("net " + expr)                                # ( N -- N T )
-    vm.eval("drop drop")
-    return a
-
-
-def conv_df64(X, dO, K=3, P=1):
-    """dF / dB of a (K, 1, P) convolution in float64 from the reference's definition (nmath.tcu:211-338: dF is the un-flipped
-    correlation of the layer input with dO, dB the sum of dO) - the exact value both fp32 implementations approximate"""
-    X = np.asarray(X, np.float64); dO = np.asarray(dO, np.float64)
-    N, H, W, C1 = X.shape
-    Xp = np.zeros((N, H + 2 * P, W + 2 * P, C1)); Xp[:, P:P + H, P:P + W] = X
-    dF = np.empty((C1, K, K, dO.shape[3]))
-    for ky in range(K):
-        for kx in range(K):
-            dF[:, ky, kx, :] = np.tensordot(Xp[:, ky:ky + H, kx:kx + W, :], dO, axes=([0, 1, 2], [0, 1, 2]))
-    return dF, dO.sum(axis=(0, 1, 2))
-
-
-def pool_flips(name, got_dx, want_dx, fwd, tol=TOL):
-    """dX of a 2x2 maxpool (= dO of the conv layer in front).  Max-pooling routes each gradient to the arg-max of its window; when
-    the two largest forward values of a window agree to rounding (2 million windows per step here: it happens about once) the fp32
-    summation order of the convolution decides which cell wins, in the reference as much as here.  Every element beyond `tol` must
-    belong to such a tied window (top two values within 1e-5 relative, checked on the oracle's forward tensor `fwd`); returns the
-    set of samples that had a flip."""
-    got_dx = np.asarray(got_dx, np.float64); want_dx = np.asarray(want_dx, np.float64)
-    bad = np.argwhere(np.abs(got_dx - want_dx) > tol * np.abs(want_dx).max())
-    samples = set()
-    for n, y, x, c in bad:
-        win = np.sort(np.asarray(fwd[n, y // 2 * 2:y // 2 * 2 + 2, x // 2 * 2:x // 2 * 2 + 2, c], np.float64).ravel())
-        assert abs(win[-1] - win[-2]) <= 1e-5 * max(abs(win[-1]), 1e-30), "%s: differs at %s away from an arg-max tie (window %s)" % (name, (n, y, x, c), win)
-        samples.add(int(n))
-    assert len(bad) <= 16, "%s: %d elements differ" % (name, len(bad))
-    return samples
-
-
-def _check_rows(name, got, want, skip, tol=TOL):
-    """as _check, but the samples in `skip` (those with an arg-max flip upstream) are compared on their own and only loosely"""
-    keep = np.array([i not in skip for i in range(want.shape[0])])
-    _check(name, got[keep], want[keep], tol)
-
-
-def _check(name, got, want, tol=TOL):
-    e = rel_err(got, want)
-    assert e <= tol, "%s: max|d|/max|ref| = %.3g > %.1g" % (name, e, tol)
+from lenet_parity import GRADS, NET, PARAMS, TOL, _check, _check_rows, _get, _setup, conv_df64, pool_flips
 
 
 def test_eight_emulated_ranks_x128_equal_one_vm_x1024_equal_the_oracle():
