@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 BASELINE_METRIC = 'CNN train images/sec + fp32 GEMM TFLOP/s (% MI355X MFMA peak), 1→8 GPUs'    # BASELINE.json "metric"
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
+STEP_TRAFFIC_BYTES = None        # HBM-side bytes per CNN step from the PMC pass of the same command (profiles/r03_bench_pmc_hbm.txt); None until measured
 GEMM_TRAFFIC_BYTES = 29419306    # fabric-side bytes per 1024^3 launch from the PMC pass (25.2 MB read + 4.2 MB written; algorithmic minimum 12.6 MB;
                                  # the reads are at the floor of 8 private L2s: every XCD fetches the 1 MB of A rows + 2 MB of B columns of its 4 x 8 tile band)
 # algorithmic bytes per image and parameter count (SURVEY.md 8d / BASELINE.md 3)
@@ -68,6 +69,88 @@ def cpu_workers(mode_args, n_workers, timeout=120):
     return [o for o in out if o]
 
 
+GAN_SRC = """0 trace
+256 constant N
+N 1 1 1 tensor ones  constant REAL
+N 1 1 1 tensor zeros constant FAKE
+N 28 28 1 nn.model 512 linear 0.2 leakyrelu 0.3 dropout 256 linear 0.2 leakyrelu 0.3 dropout 1 linear sigmoid constant D
+N 128 1 1 nn.model 256 linear 0.2 leakyrelu 512 linear 0.2 leakyrelu 784 linear tanh constant G
+N 28 28 1 tensor rand constant real
+N 128 1 1 tensor randn constant Z
+: F ( -- t4 ) G Z forward -1 n@ N 28 28 1 reshape4 swap drop ;
+: train_d ( D -- D ) 1 trainable real forward REAL backprop F forward FAKE backprop 0.0001 0.5 nn.adam ;
+: train_g ( D -- D ) 0 trainable F forward REAL backprop 0 n@ G swap backprop 0.0004 0.5 nn.adam drop ;
+: rounds ( D n -- D ) 1- for train_d train_g next ;
+D 20 rounds real forward REAL loss.bce drop
+"""
+
+
+def gan_round_bytes(n=256):
+    """Algorithmic HBM bytes of one `train_d train_g` round of the t4_40b nets (examples/t4_40b.4th), by the rule of SURVEY 8(d): every
+    layer-boundary tensor written once and read once per pass (8 B per activation element forward, 8 B backward), every derivative /
+    dropout mask written forward and read backward (8 B), parameters read once per pass they take part in (4 B), dW|dB read-modify-write
+    when the net trains (8 B), Adam 7 floats per parameter (w rw, dw r + zero, m rw, v rw)."""
+    D = [(784, 512, "ld"), (512, 256, "ld"), (256, 1, "s")]      # l = leakyrelu mask, d = dropout mask, s = sigmoid (pass-through)
+    G = [(128, 256, "l"), (256, 512, "l"), (512, 784, "t")]
+
+    def acts(net):
+        a = net[0][0]; m = 0
+        for _i, o, k in net:
+            a += o * (1 + len(k)); m += o * sum(1 for c in k if c in "ldt")
+        return a, m
+
+    def params(net):
+        return sum(i * o + o for i, o, _k in net)
+    aD, mD = acts(D); aG, mG = acts(G); pD, pG = params(D), params(G)
+    fwd = lambda a, m, p_: 4 * (n * (2 * a + m) + p_)
+    bwd = lambda a, m, p_, train: 4 * (n * (2 * a + m) + p_ + (2 * p_ if train else 0))
+    train_d = fwd(aD, mD, pD) + bwd(aD, mD, pD, True) + fwd(aG, mG, pG) + fwd(aD, mD, pD) + bwd(aD, mD, pD, True) + 28 * pD
+    train_g = fwd(aG, mG, pG) + fwd(aD, mD, pD) + bwd(aD, mD, pD, False) + bwd(aG, mG, pG, True) + 28 * pG
+    flops = 2 * n * (sum(i * o for i, o, _ in D) * (3 + 3 + 2) + sum(i * o for i, o, _ in G) * (1 + 3))   # GEMMs per weight matrix: D (fwd + dW + dX) x 2 in train_d, fwd + dX in train_g; G fwd in train_d, fwd + dW + dX in train_g
+    return train_d + train_g, flops
+
+
+def extras(vm_cls, local, ms_step, args, torch):
+    """BASELINE configs #3 (sustained), #4 (GAN) and the dataset-fed step, all device-synchronised; rank 0 of a 1-GPU run only."""
+    import subprocess
+    import tempfile
+    out = {}
+    # ---- config #4: t4_40b GAN nets, N = 256, Adam beta1 = 0.5 (tools/forth/gan_steps.4th), one `train_d train_g` round
+    g = vm_cls(device=local, seed=4321)
+    txt = g.eval(GAN_SRC)
+    assert "?" not in txt.replace("-> ok", ""), txt
+    torch.cuda.synchronize()
+    rounds = 300
+    t0 = time.perf_counter(); g.eval("%d rounds real forward REAL loss.bce drop\n" % rounds); torch.cuda.synchronize()     # the loss read-back is a device sync as well
+    gdt = (time.perf_counter() - t0) / rounds
+    gb, gf = gan_round_bytes(256)
+    out["gan_round_ms"] = round(gdt * 1e3, 4)
+    out["gan"] = {"workload": "examples/t4_40b.4th nets (D 784-512-256-1 leakyrelu+dropout+sigmoid, G 128-256-512-784 leakyrelu+tanh), N=256, BCE, Adam b1=0.5, one train_d + train_g round, HBM-resident batch",
+                  "rounds_timed": rounds, "algorithmic_bytes_per_round": gb, "hbm_frac": round(gb / gdt / 1e9 / PEAK_HBM_GBS, 5),
+                  "flop_per_round": gf, "mfma_frac": round(gf / gdt / 1e12 / PEAK_F32_MFMA_TFLOPS, 5)}
+    g.close()
+    # ---- dataset-fed step: IDX file -> pinned double buffer (reader thread) -> one staging launch -> forward backprop nn.sgd
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_mnist.py"), os.path.join(d, "data", "MNIST", "raw"), "8192", "256"], check=True, capture_output=True)
+        os.chdir(d)
+        try:
+            v = vm_cls(device=local, seed=99)
+            txt = v.eval("0 trace\n128 28 28 1 nn.model 0.5 10 conv2d 2 maxpool relu 0.5 20 conv2d 0.5 dropout 2 maxpool relu flatten 100 linear 0.5 dropout 10 linear softmax constant net\n"
+                         "128 dataset mnist_train constant ds0\n: epoch ( N D -- N ) for forward backprop 0.01 0.0 nn.sgd next ;\nnet ds0 epoch ds0 rewind drop\n")
+            assert "?" not in txt.replace("-> ok", ""), txt
+            torch.cuda.synchronize()
+            epochs = 6
+            t0 = time.perf_counter()
+            v.eval(" ".join(["ds0 epoch ds0 rewind drop"] * epochs) + " nn.hit drop\n"); torch.cuda.synchronize()
+            out["dataset_fed_ms_per_step"] = round((time.perf_counter() - t0) / (epochs * 64) * 1e3, 4)
+            out["dataset_fed_note"] = "synthetic MNIST-shaped IDX corpus (8192 images, tools/make_synth_mnist.py), batches of 128 through the dataset words: host read + pinned staging + on-GPU normalise + the same training step; %d steps" % (epochs * 64)
+            v.close()
+        finally:
+            os.chdir(cwd)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +160,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-iters", type=int, default=200)
+    ap.add_argument("--sustain-s", type=float, default=3.0, help="length of the sustained loop behind the timed region (seconds; 0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the GAN / dataset-fed / sustained legs")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction plumbing only (gloo, no GPU work, no metric): CPU test of the N-rank path")
     args = ap.parse_args()
 
@@ -194,9 +279,19 @@ def main():
     dt = time.perf_counter() - t0
     if dp:
         tmax = torch.tensor([dt], device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.cpu()[0])
-    loss_txt = vm.eval("img forward lbl loss.ce .")       # a fresh forward: after backprop the output tensor holds out - target (reference in-place convention)
     ms_step = dt / args.steps * 1e3
     img_s = world * N * args.steps / dt
+    # ---- sustained loop (same work, >= 3 s): what a long training run sees, and long enough for an external GPU-busy sampler
+    sustained = None
+    if args.sustain_s > 0 and not args.no_extras:
+        n_sus = max(args.steps, int(args.sustain_s / (ms_step * 1e-3)))
+        barrier()
+        t0 = time.perf_counter(); run(n_sus); barrier()
+        sdt = time.perf_counter() - t0
+        if dp:
+            tmax = torch.tensor([sdt], device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); sdt = float(tmax.cpu()[0])
+        sustained = (sdt / n_sus * 1e3, n_sus)
+    loss_txt = vm.eval("img forward lbl loss.ce .")       # a fresh forward: after backprop the output tensor holds out - target (reference in-place convention)
 
     out = None
     if rank == 0:
@@ -209,13 +304,19 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
-                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
+                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": 8, "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
                        "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None,
                        "final_loss_note": "random images and labels, batch-SUM gradients (reference semantics): a throughput run, not a convergence test; training parity vs the oracle is in tests/"},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-                              "traffic": None, "algorithmic_bytes_per_step": step_bytes},
+                              "traffic": STEP_TRAFFIC_BYTES, "traffic_source": "profiles/r03_bench_pmc_hbm.txt (sum over the step's kernels, TCC_EA0 request counters, reads x2 on gfx950)" if STEP_TRAFFIC_BYTES else None,
+                              "algorithmic_bytes_per_step": step_bytes},
         }
+        if sustained:
+            out["sustained_ms_per_step"] = round(sustained[0], 4)
+            out["sustained_steps"] = sustained[1]
+        if world == 1 and not args.no_extras:
+            out.update(extras(VM, local, ms_step, args, torch))
         # ---- GEMM 1024^3 fp32 (word `matmul`), HIP events on the launch stream
         g = torch.Generator(device="cuda"); g.manual_seed(1234)
         A = torch.rand(1024, 1024, device="cuda", generator=g); B = torch.rand(1024, 1024, device="cuda", generator=g)
@@ -261,7 +362,7 @@ def main():
             t0 = time.perf_counter(); nst = 0
             while True:
                 om.forward(x); om.backprop(); om.sgd(0.01, 0.0); nst += 1
-                if time.perf_counter() - t0 > 6.0 or nst >= 50:
+                if time.perf_counter() - t0 > 3.0 or nst >= 50:
                     break
             cdt = time.perf_counter() - t0
             a = np.random.default_rng(1).random((1024, 1024)).astype(np.float32); o_ = np.zeros((1024, 1024), np.float32)
@@ -274,20 +375,20 @@ def main():
                 ncore = len(os.sched_getaffinity(0))
             except Exception:
                 ncore = os.cpu_count() or 1
-            wr = cpu_workers(["step", args.net, N, 6.0], ncore)
+            wr = cpu_workers(["step", args.net, N, 4.0], ncore)
             all_img_s = sum(N * r[0] / r[1] for r in wr if len(r) == 2 and r[1] > 0)
             rows = max(4, 1024 // ncore)
-            gr = cpu_workers(["gemm", rows, 1024, 1024, 3.0], ncore)
+            gr = cpu_workers(["gemm", rows, 1024, 1024, 2.0], ncore)
             all_gflops = sum(r[0] * 2.0 * rows * 1024 * 1024 / r[1] for r in gr if len(r) == 2 and r[1] > 0) / 1e9
             out["cpu_baseline"] = {"value": round(all_img_s, 1), "unit": "images/s", "cores": len(wr), "kind": "port",
-                                   "sample": "%d worker processes (one per core), each ~6 s of oracle training steps of the same %s batch-%d workload "
+                                   "sample": "%d worker processes (one per core), each ~4 s of oracle training steps of the same %s batch-%d workload "
                                              "(%d steps in total); single thread: %d steps in %.1f s" % (len(wr), args.net, N, int(sum(r[0] for r in wr)), nst, cdt),
                                    "single_thread_value": round(N * nst / cdt, 1),
                                    "host_cores_available": os.cpu_count(),
                                    "gemm_1024_host_blocked_ms": round(gdt * 1e3, 1),
                                    "gemm_1024_host_gflops": round(flops / gdt / 1e9, 2),
                                    "gemm_1024_host_gflops_all_cores": round(all_gflops, 1), "gemm_all_cores_workers": len(gr),
-                                   "gemm_note": "reference's blocked host GEMM (tensor.cu:97-123 restated): one thread on the full 1024^3 product, then %d workers on %d-row slabs for ~3 s" % (len(gr), rows)}
+                                   "gemm_note": "reference's blocked host GEMM (tensor.cu:97-123 restated): one thread on the full 1024^3 product, then %d workers on %d-row slabs for ~2 s" % (len(gr), rows)}
         print(json.dumps(out), flush=True)
     if dp:
         if native:
