@@ -24,8 +24,9 @@ sys.path.insert(0, ROOT)
 BASELINE_METRIC = 'CNN train images/sec + fp32 GEMM TFLOP/s (% MI355X MFMA peak), 1→8 GPUs'    # BASELINE.json "metric"
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
-STEP_TRAFFIC_BYTES = None        # HBM-side bytes per CNN step from the PMC pass of the same command (profiles/r03_bench_pmc_hbm.txt); None until measured
-GEMM_TRAFFIC_BYTES = 29419306    # fabric-side bytes per 1024^3 launch from the PMC pass (25.2 MB read + 4.2 MB written; algorithmic minimum 12.6 MB;
+STEP_TRAFFIC_BYTES = 58457920    # HBM-side bytes per CNN step: sum over the step's 8 kernels in profiles/r03_bench_pmc_hbm.txt (26.6 MB read, x2-corrected, + 31.8 MB written;
+                                 # algorithmic 66.15 MB: the activations the backward re-reads come partly out of the Infinity Cache)
+GEMM_TRAFFIC_BYTES = 29425487    # fabric-side bytes per 1024^3 launch from the PMC pass (25.2 MB read + 4.2 MB written; algorithmic minimum 12.6 MB;
                                  # the reads are at the floor of 8 private L2s: every XCD fetches the 1 MB of A rows + 2 MB of B columns of its 4 x 8 tile band)
 # algorithmic bytes per image and parameter count (SURVEY.md 8d / BASELINE.md 3)
 NETS = {"nn_f": dict(bytes_per_img=494720, params=101030, flop_per_img=3134160),
@@ -338,7 +339,7 @@ def main():
         tf = flops / (avg_ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": "k_gemm_nn_plain (1024^3 fp32 matmul: 64x64 tiles, 8 waves/WG = 2 k-groups x 2x2 v_mfma_f32_32x32x2_f32 accumulator pairs, LDS-DMA from inline asm, 128-deep double-buffered stages)", "bound": "mfma", "achieved": round(tf, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": GEMM_TRAFFIC_BYTES, "traffic_source": "profiles/r02_bench_pmc_hbm.txt (TCC_EA0_RDREQ*64B x2 gfx950 correction + WRREQ_64B*64B, separate --pmc pass)",
+                           "traffic": GEMM_TRAFFIC_BYTES, "traffic_source": "profiles/r03_bench_pmc_hbm.txt (TCC_EA0_RDREQ*64B x2 gfx950 correction + WRREQ_64B*64B, separate --pmc pass)",
                            "avg_launch_us": round(avg_ms * 1e3, 2), "best_launch_us": round(best * 1e3, 2),
                            "flop_per_launch": flops}
         # ---- the same product through the Forth word, reference idiom `for @ drop next` (examples/t4_20a.4th:20-29): per call an arena
