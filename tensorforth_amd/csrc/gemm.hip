@@ -30,6 +30,8 @@
 using namespace t4k;
 
 namespace {
+T4K_SPIN_DECL
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));       // first-class 16-byte value (HIP's float4 is a struct: its
@@ -342,7 +344,7 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmP &p, const int bx, con
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (gate_mode == 2) {
-        if (tid == 0) while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_n) __builtin_amdgcn_s_sleep(1);
+        if (tid == 0) T4K_SPIN_WAIT(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_n, 1);
         __syncthreads();
     }
 #pragma unroll
@@ -503,7 +505,8 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
             // only the readers of the columns this tile overwrites matter: dW tiles (e0t, tn), e0t = 0 .. gate_n / tiles_n - 1 (both GEMMs
             // have the same column tiling), each with 4 per-wave slots when those fit the 512-int block (gate_n <= 128)
             const int per = gate_n <= 128 ? 4 : 1, rows = gate_n / p.tiles_n, nslot = rows * per;
-            for (;;) {
+            for (int spin_it = 0;; spin_it++) {
+                if (spin_it > T4K_SPIN_MAX) { if (lane == 0 && g_spin_err_dev) __hip_atomic_store(g_spin_err_dev, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // bounded: see t4k_common.h
                 bool ok = true;
                 unsigned bad = 0;                                  // no short-circuit: the loads of one pass are independent and go out together
 #pragma unroll 4
@@ -744,7 +747,7 @@ __global__ void __launch_bounds__(256) k_gemm_glds(GemmP p) {
             return;
         }
         if (tid == 0) {
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+            T4K_SPIN_WAIT(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0, 3);
             __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1461,6 +1464,8 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
 } // namespace
 
 namespace t4k {
+void gemm_set_spin_err(int *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spin_err_dev), &p, sizeof(p)); }
+
 int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
 // linear_small.hip: classifier-head sized layers on the vector ALUs, one launch each way
 bool linear_small_ok(int E0, int E1);

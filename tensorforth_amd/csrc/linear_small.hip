@@ -15,6 +15,8 @@
 using namespace t4k;
 
 namespace {
+T4K_SPIN_DECL
+
 
 constexpr int LS_MAX_FLOATS = 12288;          // 48 KiB of dynamic LDS
 
@@ -196,8 +198,8 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
     }
     if (alias) {                                                 // DX overwrites X: wait until every dW workgroup is done reading it
         if (tid == 0) {
-            while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nB) __builtin_amdgcn_s_sleep(1);
-            if (TGT) while (__hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nA + nB) __builtin_amdgcn_s_sleep(1);
+            T4K_SPIN_WAIT(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nB, 4);
+            if (TGT) T4K_SPIN_WAIT(__hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nA + nB, 5);
         }
         __syncthreads();
         if (TGT)                                                 // every reader of DY has staged: out -= target lands in place
@@ -242,6 +244,8 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
 } // namespace
 
 namespace t4k {
+void linsmall_set_spin_err(int *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spin_err_dev), &p, sizeof(p)); }
+
 
 bool linear_small_ok(int E0, int E1) {
     return E0 >= 1 && E0 <= 64 && E1 >= 1 && E1 <= 512 && E0 * (E1 + 1) + 16 * E1 <= LS_MAX_FLOATS && E0 * E1 + 64 * E0 <= LS_MAX_FLOATS;

@@ -26,6 +26,18 @@ int hip_fail(hipError_t e, const char *what) {
 using namespace t4k;
 
 namespace t4k { void rng_sync_device(hipStream_t hs); }   // optim.hip
+namespace t4k {
+int spin_check() {
+    State &g = st();
+    if (!g.spin_err) return T4K_OK;
+    const int code = *(volatile int *)g.spin_err;
+    if (!code) return T4K_OK;
+    *(volatile int *)g.spin_err = 0;
+    static const char *what[] = { "", "dual GEMM writer gate", "dual-GEMM epoch slots", "pair-mode GEMM flag", "head backward dW gate", "head backward staging gate" };
+    return fail(T4K_ERR_HIP, "an inter-workgroup wait timed out (%s): the launch's workgroups were not co-resident - results of that launch are invalid; "
+                             "set T4K_GEMM_DUAL=0 T4K_GEMM_DUAL32=0 T4K_LINSMALL_GATE=0 on a shared or partitioned device", what[code > 0 && code < 6 ? code : 0]);
+}
+}
 namespace { struct GraphRec { hipGraphExec_t exec; uint64_t rng_adv; }; }
 
 extern "C" {
@@ -55,6 +67,10 @@ int t4k_init(int device) {
         T4K_HIP(hipMemsetAsync(g.ws, 0, g.ws_bytes, g.stream));
     }
     if (!g.d_sync) { T4K_HIP(hipMalloc((void **)&g.d_sync, 32768 * sizeof(int))); T4K_HIP(hipMemset(g.d_sync, 0, 32768 * sizeof(int))); }
+    if (!g.spin_err) {                                  // error word of the bounded inter-workgroup waits: pinned host memory the kernels can write
+        T4K_HIP(hipHostMalloc((void **)&g.spin_err, 64, hipHostMallocMapped)); *g.spin_err = 0;
+        gemm_set_spin_err(g.spin_err); linsmall_set_spin_err(g.spin_err);
+    }
     g.device = device;
     g.ready  = true;
     return T4K_OK;
@@ -115,7 +131,7 @@ int t4k_memset(void *dst, int byte, size_t bytes, t4k_stream_t s) {
     T4K_HIP(hipMemsetAsync(dst, byte, bytes, S(s)));
     return T4K_OK;
 }
-int t4k_sync(t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipStreamSynchronize(S(s))); return T4K_OK; }
+int t4k_sync(t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipStreamSynchronize(S(s))); return spin_check(); }
 
 int t4k_stream_create(t4k_stream_t *s) {
     T4K_REQUIRE_INIT();
@@ -147,7 +163,7 @@ t4k_stream_t t4k_default_stream(void) { return (t4k_stream_t)st().stream; }
 
 int t4k_event_create(t4k_event_t *e) { T4K_REQUIRE_INIT(); hipEvent_t h; T4K_HIP(hipEventCreate(&h)); *e = (t4k_event_t)h; return T4K_OK; }
 int t4k_event_record(t4k_event_t e, t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventRecord((hipEvent_t)e, S(s))); return T4K_OK; }
-int t4k_event_sync(t4k_event_t e) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventSynchronize((hipEvent_t)e)); return T4K_OK; }
+int t4k_event_sync(t4k_event_t e) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventSynchronize((hipEvent_t)e)); return spin_check(); }
 int t4k_event_elapsed_ms(t4k_event_t a, t4k_event_t b, float *ms) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return T4K_OK; }
 int t4k_event_destroy(t4k_event_t e) { T4K_REQUIRE_INIT(); if (e) T4K_HIP(hipEventDestroy((hipEvent_t)e)); return T4K_OK; }
 

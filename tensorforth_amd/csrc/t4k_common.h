@@ -35,6 +35,7 @@ struct State {
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
     int        *d_sync  = nullptr;     // 32768 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags, [8192,32768) per-stream arrival gates (gate_for / flags_for; ints [512,1024) of a stream's block are the epoch slots of k_gemm_dual32)
+    int        *spin_err = nullptr;   // pinned, device-visible error word of the inter-workgroup waits (spin_check)
     int         cu_count = 256;
     char        err[256] = {0};
 };
@@ -73,6 +74,20 @@ inline float *ws_for(const void *s) {            // accepts a t4k_stream_t or an
     if (s) for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) return (float *)g.lane[i].ws;
     return (float *)g.ws;
 }
+
+// ---- bounded inter-workgroup waits.  The one-launch producer/consumer kernels (dual GEMMs, pair-mode GEMM, in-place head backward)
+// poll an arrival gate in device memory.  Progress rests on every workgroup of the launch being resident (launchers only take the
+// gated path for grids <= the CU count of an exclusively owned device) - if that ever fails (a co-scheduled kernel holds CUs, a
+// partitioned device) a poll gives up after T4K_SPIN_MAX rounds (~seconds), writes a code to a pinned error word and lets the
+// workgroup run on (results of THAT launch are wrong, nothing hangs); the next synchronising entry point (t4k_sync, t4k_event_sync)
+// reports T4K_ERR_HIP.  The word lives per translation unit in a __device__ pointer set by t4k_init.
+#define T4K_SPIN_MAX (1 << 22)
+#define T4K_SPIN_DECL __device__ int *g_spin_err_dev = nullptr;
+#define T4K_SPIN_WAIT(cond_not_met, code) do { int _it = 0; while (cond_not_met) { __builtin_amdgcn_s_sleep(1); \
+        if (++_it > T4K_SPIN_MAX) { if (g_spin_err_dev) __hip_atomic_store(g_spin_err_dev, (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; } } } while (0)
+void gemm_set_spin_err(int *p);          // gemm.hip
+void linsmall_set_spin_err(int *p);      // linear_small.hip
+int  spin_check();                       // runtime.hip: T4K_OK, or T4K_ERR_HIP when a wait timed out since the last check (clears the word)
 
 #define T4K_REQUIRE_INIT() do { if (!t4k::st().ready) return t4k::fail(T4K_ERR_NODEVICE, "t4k_init not called or no gfx950 device"); } while (0)
 #define T4K_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) return t4k::hip_fail(_e, #call); } while (0)

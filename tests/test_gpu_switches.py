@@ -1,0 +1,92 @@
+"""GPU: the non-default dispatch paths of the GEMM / linear kernels cannot rot, and the gated one-launch kernels survive a busy device.
+
+* every `T4K_GEMM_*` / head switch (csrc/gemm.hip, linear_small.hip) is flipped in a process of its own and the integer-exact products
+  are re-run: plain / transposed / alpha-beta GEMMs incl. ragged and sliver shapes, and the linear layer both ways (forward with bias,
+  backward dW += dY^T X, dB += column sums, dX = dY W written IN PLACE over X - the arrival-gate path) - entries in {-2..2} keep every
+  fp32 sum exact, so whatever kernel the switch selects must reproduce numpy's integer result bit for bit;
+* the same set runs while a bandwidth-hogging elementwise kernel chain occupies the device on another stream (the situation of a
+  concurrent RCCL kernel, T4_DP_OVERLAP): results unchanged and no bounded-wait timeout reported by t4k_sync (csrc/t4k_common.h)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from vm_util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_SCRIPT = r'''
+import ctypes, os, sys
+sys.path.insert(0, os.environ["T4_ROOT"])
+import numpy as np, torch
+from tensorforth_amd.lib import load
+k = load(); k.init(0)
+k.call("t4k_set_default_stream", None)
+p = lambda t: t.data_ptr()
+up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+rng = np.random.default_rng(11)
+hog = os.environ.get("HOG") == "1"
+side = torch.cuda.Stream() if hog else None
+big = torch.zeros(512 << 20 >> 2, device="cuda") if hog else None       # 512 MB
+
+def busy():
+    if hog:
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big.mul_(1.0001).add_(1.0)
+
+def ints(*shape): return rng.integers(-2, 3, shape).astype(np.float32)
+fails = []
+for (M, N, K, tA, tB, al, be) in [(1024, 1024, 1024, 0, 0, 1.0, 0.0), (1024, 1024, 784, 0, 1, 1.0, 0.0), (512, 1024, 1024, 0, 1, 2.0, -1.0), (1000, 1028, 256, 0, 1, 2.0, -1.0),
+                                  (996, 1000, 384, 1, 0, 1.0, 1.0), (40, 72, 64, 0, 1, 1.0, 0.0), (200, 100, 832, 0, 1, 2.0, -1.0), (256, 512, 784, 0, 1, 1.0, 0.0),
+                                  (2048, 2048, 256, 0, 0, 1.0, 0.0), (128, 100, 980, 0, 1, 1.0, 0.0)]:
+    A, B, O0 = ints(M, K), ints(K, N), rng.integers(-3, 4, (M, N)).astype(np.float32)
+    want = al * (A.astype(np.float64) @ B.astype(np.float64)) + be * O0        # float64 BLAS: exact on these integers, and fast
+    dA, dB, dO = up(A.T if tA else A), up(B.T if tB else B), up(O0)
+    busy()
+    k.call("t4k_gemm", p(dA), p(dB), p(dO), al, be, tA, tB, M, N, K, 1, None)
+    rc = k.lib.t4k_sync(None)
+    if rc != 0 or not np.array_equal(dO.cpu().numpy().astype(np.float64), want.astype(np.float64)):
+        fails.append(("gemm", M, N, K, tA, tB, rc, k.lib.t4k_last_error()))
+for (Nb, E0, E1) in [(128, 100, 980), (128, 10, 100), (256, 512, 784), (256, 1, 256), (256, 256, 512), (64, 300, 1000)]:
+    X, W, b, dY = ints(Nb, E1), ints(E0, E1), ints(E0), ints(Nb, E0)
+    X64, W64, dY64 = X.astype(np.float64), W.astype(np.float64), dY.astype(np.float64)
+    Y = (X64 @ W64.T + b).astype(np.int64)
+    dW = (dY64.T @ X64).astype(np.int64); dBv = dY.sum(0).astype(np.int64); dX = (dY64 @ W64).astype(np.int64)
+    dXd, dWd, dbd, dYd, dYo = up(X), up(W), up(b), up(dY), torch.zeros(Nb, E0, device="cuda")
+    busy()
+    k.call("t4k_linear_fwd", p(dXd), p(dWd), p(dbd), p(dYo), Nb, E0, E1, None)
+    gW, gB = torch.ones(E0, E1, device="cuda"), torch.ones(E0, device="cuda")            # gradients ACCUMULATE
+    k.call("t4k_linear_bwd", p(dXd), p(dWd), p(dYd), p(dXd), p(gW), p(gB), Nb, E0, E1, 1, None)       # dX over X: the in-place / gated path
+    rc = k.lib.t4k_sync(None)
+    ok = (rc == 0 and np.array_equal(dYo.cpu().numpy().astype(np.int64), Y) and np.array_equal(gW.cpu().numpy().astype(np.int64), dW + 1)
+          and np.array_equal(gB.cpu().numpy().astype(np.int64), dBv + 1) and np.array_equal(dXd.cpu().numpy().astype(np.int64), dX))
+    if not ok:
+        fails.append(("linear", Nb, E0, E1, rc, k.lib.t4k_last_error()))
+torch.cuda.synchronize()
+print("FAILS", fails)
+sys.exit(1 if fails else 0)
+'''
+
+SWITCHES = [{}, {"T4K_GEMM_DUAL": "0"}, {"T4K_GEMM_DUAL32": "0"}, {"T4K_GEMM_S32": "0"}, {"T4K_GEMM_DUAL": "0", "T4K_GEMM_DUAL32": "0", "T4K_GEMM_S32": "0"},
+            {"T4K_GEMM_FULLK": "0"}, {"T4K_GEMM_FASTPRO": "0"}, {"T4K_GEMM_RAGGED_DMA": "0"}, {"T4K_GEMM_PLAIN_BIG": "0"}, {"T4K_GEMM_BIG_DMA": "0"},
+            {"T4K_GEMM_BIG_FULLK": "0"}, {"T4K_GEMM_DUAL_FULL": "0"}, {"T4K_GEMM_DUAL_FULLK": "0"}, {"T4K_GEMM_SPLIT_DIV": "2"}, {"T4K_GEMM_S32_NW8": "0"},
+            {"T4K_GEMM_S32_MAXK": "256"}, {"T4K_GEMM_DUAL_MAXK": "256"}, {"T4K_GEMM_DUAL32_MAXK": "128"}, {"T4K_HEAD_FOLD": "0"}, {"T4K_LINSMALL_GATE": "0"},
+            {"T4K_GEMM_VARIANT": "21"}, {"T4K_GEMM_VARIANT": "37"}, {"T4K_GEMM_VARIANT": "61"}, {"T4K_GEMM_VARIANT": "5"}]
+
+
+def _run(tmp_path, env_extra):
+    f = tmp_path / "sw.py"; f.write_text(_SCRIPT)
+    env = dict(os.environ, T4_ROOT=ROOT); env.update(env_extra)
+    r = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, "%s\n%s\n%s" % (env_extra, r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("sw", SWITCHES, ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "defaults")
+def test_integer_exact_products_under_every_dispatch_switch(tmp_path, sw):
+    _run(tmp_path, sw)
+
+
+def test_gated_kernels_while_another_stream_hogs_the_device(tmp_path):
+    _run(tmp_path, {"HOG": "1"})
