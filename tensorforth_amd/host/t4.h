@@ -49,6 +49,9 @@ bool tb_configure(const char *logdir, const char *run_id);
 bool tb_active();
 void tb_init(const char *run_id);
 void tb_step(int i);
+struct Model;
+void tb_graph(Model &m);
+void tb_embed(const char *tag, Tensor &t);
 void tb_scalar(const char *tag, float v);
 void tb_text(const char *tag, const char *txt);
 void tb_histo(const char *tag, Tensor &t, int n_bucket);

@@ -8,7 +8,8 @@
 // Written from scratch as one flat byte builder; what follows the reference is behaviour, not code: the log layout
 // <logdir>/<run_id>/events.out.tfevents.<time>.<host>.<pid>.0, the `brain.Event:2` header record, scalars as simple_value,
 // and the histogram bucketing of writer.h:178-208 (an empty underflow bin at min, n equal-width bins, last limit = max + 1e-10),
-// so the dashboards of t4_40a / t4_40b / t4_42a look the same.  .graph / .embed are not written (messages only).
+// so the dashboards of t4_40a / t4_40b / t4_42a look the same.  .graph writes the model as a GraphDef event (Summary::graph summary.cpp:115-160,
+// graph.h, writer.h:131-150), .embed the projector files of tb/projector.h (tensor / metadata TSV + projector_config.pbtxt).
 //
 // The sink is off unless a log directory is configured (`ten4 -t <logdir> [-r <run_id>]` or T4_TB_LOGDIR / T4_TB_RUN): the words then
 // print the reference's "check TensorBoard param" message, exactly as the reference does without -t.
@@ -85,6 +86,7 @@ Bytes png_rgb(int w, int h, const uint8_t *rgb) {
 
 struct Sink {
     std::string root, run;
+    std::vector<std::string> embeds;                     // embeddings of the current run (projector_config.pbtxt lists all of them)
     FILE *f = nullptr;
     int step = 0;
     double now() const { const char *t = getenv("T4_TB_FIXED_TIME"); return t ? atof(t) : (double)time(nullptr); }   // fixed clock: reproducible files for tests
@@ -97,7 +99,7 @@ struct Sink {
     }
     bool open(const std::string &run_id) {                // Summary::init summary.cpp:18-28
         if (f) { fclose(f); f = nullptr; }
-        run = run_id;
+        run = run_id; embeds.clear();
         std::string dir_run = run; for (char &c : dir_run) if (c == ' ' || c == '/' || c == '\\') c = '_';
         mkdir(root.c_str(), 0755);
         const std::string dir = root + "/" + dir_run;
@@ -201,6 +203,52 @@ void tb_image(const char *tag, Tensor &t) {              // Summary::image summa
             for (int c = 0; c < 3; c++) { const float vx = (v[c < C ? c : C - 1] + mean) * scale; px[(size_t)i * 3 + c] = (uint8_t)std::min(255.0f, std::max(vx, 0.0f)); }
         tb_png(tag, W, H, px);
     }
+}
+// .graph ( N -- ): Event { 2: step = 0, 4: GraphDef { 1: NodeDef* } } - no wall_time, as the reference writes it (writer.h:139-150).
+// NodeDef { 1: name, 2: op, 3: input, 5: attr { 1: key, 2: AttrValue } }: a Placeholder "input" with the model's input shape, then one
+// node per layer tensor named <Op>_<i>/<layer name> whose input is the node in front; attrs dtype = DT_FLOAT and shape = [N,H,W,C].
+void tb_graph(Model &m) {
+    if (!tb_active()) return;
+    static const char *op[] = { "Output", "Conv2D", "MatMul", "Reshape", "Relu", "Tanh", "Sigmoid", "Selu", "LeakyRelu", "Elu", "Dropout", "Softmax", "LogSoftmax",
+                                "AvgPool", "MaxPool", "MinPool", "BatchNorm", "UpSample", "UpSample" };     // summary.cpp:120-125 (+ dconv2d, which the reference's table lacks)
+    auto attrs = [](PB &node, Tensor &t) {
+        PB dt; dt.i64(6, 1);                                                       // AttrValue.type = DT_FLOAT
+        PB a1; a1.str(1, "dtype"); a1.msg(2, dt); node.msg(5, a1);
+        PB dims;
+        for (uint32_t d : { t.N(), t.H(), t.W(), t.C() }) { PB sz; sz.i64(1, d); dims.msg(2, sz); }   // TensorShapeProto.dim { size }
+        PB av; av.msg(7, dims);                                                    // AttrValue.shape
+        PB a2; a2.str(1, "shape"); a2.msg(2, av); node.msg(5, a2);
+    };
+    auto name_of = [&](int i) { Tensor &t = m.at(i); return std::string(op[t.grad_fn]) + "_" + std::to_string(i) + "/" + LAYER_NAME[t.grad_fn]; };
+    PB graph;
+    { PB n0; n0.str(1, "input"); n0.str(2, "Placeholder"); attrs(n0, m.at(0)); graph.msg(1, n0); }
+    const int n = (int)m.layer.size();
+    for (int i = 0; i < n; i++) {
+        PB nd; nd.str(1, name_of(i)); nd.str(2, op[m.at(i).grad_fn]); nd.str(3, i == 0 ? std::string("input") : name_of(i - 1));
+        attrs(nd, m.at(i)); graph.msg(1, nd);
+    }
+    PB ev; ev.i64(2, 0); ev.msg(4, graph);
+    g_tb->record(ev.b);
+}
+// .embed ( T tag -- ): <run dir>/<tag>_tensors.tsv (one row per sample, tab-separated, operator<< float format), <tag>_metadata.tsv
+// (<tag>.<n> per row) and projector_config.pbtxt listing every embedding of the run so far (projector.h:31-71, summary.cpp:162-177)
+void tb_embed(const char *tag_in, Tensor &t) {
+    if (!tb_active() || t.numel == 0) return;
+    auto esc = [](std::string v) { for (char &c : v) if (c == ' ' || c == '/' || c == '\\') c = '_'; return v; };
+    const std::string dir = g_tb->root + "/" + esc(g_tb->run), tag = esc(tag_in), base = dir + "/" + tag;
+    std::vector<float> h; t.to_host(h);
+    const size_t N = t.N(), D = (size_t)t.HWC();
+    FILE *f = fopen((base + "_tensors.tsv").c_str(), "w"); if (!f) { hprintf("  tb#embed cannot write %s_tensors.tsv\n", base.c_str()); return; }
+    for (size_t n = 0; n < N; n++) { for (size_t i = 0; i < D; i++) fprintf(f, "%s%g", i ? "\t" : "", h[n * D + i]); fputc('\n', f); }   // %g == ostream << float
+    fclose(f);
+    f = fopen((base + "_metadata.tsv").c_str(), "w"); if (!f) return;
+    for (size_t n = 0; n < N; n++) fprintf(f, "%s.%zu\n", tag.c_str(), n);
+    fclose(f);
+    g_tb->embeds.push_back(tag);
+    f = fopen((dir + "/projector_config.pbtxt").c_str(), "w"); if (!f) return;
+    for (const std::string &e : g_tb->embeds)
+        fprintf(f, "embeddings {\n  tensor_name: \"%s\"\n  tensor_path: \"%s/%s_tensors.tsv\"\n  metadata_path: \"%s/%s_metadata.tsv\"\n}\n", e.c_str(), dir.c_str(), e.c_str(), dir.c_str(), e.c_str());
+    fclose(f);
 }
 void tb_close() { if (g_tb && g_tb->f) { fclose(g_tb->f); g_tb->f = nullptr; } }
 

@@ -251,6 +251,7 @@ void VM::init_tensor() {
             else if (!strcmp(nm, "histo") && t) tb_histo(tag.c_str(), *t, i);
             else if (!strcmp(nm, "tile") && t) tb_tile(tag.c_str(), *t, i);
             else if (!strcmp(nm, "image") && t) tb_image(tag.c_str(), *t);
+            else if (!strcmp(nm, "embed") && t) tb_embed(tag.c_str(), *t);
             else { char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%s, tag=%s): not written by this sink\n", nm, tag.c_str()); pstr(b); }
         } else {
             char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%s, n=%g, i=%d%s%s), check TensorBoard param -tlogdir -rrun_id\n", nm, IS_OBJ(n) ? 0.0f : n, i,
@@ -268,7 +269,11 @@ void VM::init_tensor() {
     CODE(".tile",   [tb] { tb("tile", 2, true); });
     CODE(".histo",  [tb] { tb("histo", 2, true); });
     CODE(".embed",  [tb] { tb("embed", 1, true); });
-    CODE(".graph",  [this] { POP(); pstr(tb_active() ? "  sys#tbx(op=graph): not written by this sink\n" : "  sys#tbx(op=graph), check TensorBoard param -tlogdir -rrun_id\n"); });
+    CODE(".graph",  [this] {                              // ( N -- ) tenvm.cpp:611 -> sys.cpp:241: the model's layer list as a GraphDef event
+        DU n = POP();
+        if (!tb_active()) { pstr("  sys#tbx(op=graph), check TensorBoard param -tlogdir -rrun_id\n"); return; }
+        if (is_m(n)) tb_graph((Model &)st().du2obj(n)); else pstr("summary#graph requires model\n");
+    });
     CODE(".png",    [this] { POPi(); POPi(); pstr("  .png: n/a\n"); });
     // redefined words
     CODE("@", [this] { if (TOS2T()) blas2(B_DOT, true); else { uint32_t i = (uint32_t)POPi(); PUSH(DUP(mem_du(i))); } });

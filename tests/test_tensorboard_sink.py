@@ -1,4 +1,4 @@
-"""TensorBoard sink (words .tbinit .tbstep .scalar .histo .text .tile, host/tboard.cpp).
+"""TensorBoard sink (words .tbinit .tbstep .scalar .histo .text .tile .graph .embed, host/tboard.cpp).
 
 CPU test through the oracle-backed VM (same host sources as the product): a script logs a scalar, a histogram, a text and an image
 tile; the tfevents file is then (1) checked record by record against TensorBoard's framing - length, masked crc32c of the length,
@@ -162,6 +162,56 @@ def _byte_exact(binary, tmp_path):
     idat = png[png.index(b"IDAT") + 4: png.index(b"IEND") - 8]
     raw = zlib.decompress(idat)
     assert len(raw) == HT * (WT * 3 + 1)
+
+
+GRAPH_SCRIPT = '''0 trace
+2 8 8 1 nn.model 0.5 3 conv2d 2 maxpool relu flatten 5 linear softmax constant net
+net .graph
+3 2 2 1 tensor ={ 0.5 -1 2 0.25 1 1 1 1 0 0 0 0.0000001 } s" act/l 1" .embed
+2 3 matrix{ 1 2 3 4 5 6 } s" w" .embed
+bye
+'''
+
+
+def _graph_and_embed(binary, tmp_path):
+    """.graph / .embed (tenvm.cpp:610-611, Summary::graph / embed summary.cpp:115-177): the GraphDef event rebuilt here from the
+    protobuf schema (NodeDef 1 name, 2 op, 3 input, 5 attr{key, AttrValue}; AttrValue 6 type / 7 shape; TensorShapeProto 2 dim{1 size};
+    Event 2 step, 4 graph_def - no wall_time, as the reference writes it) and the projector's three text files, byte for byte."""
+    env = dict(os.environ, T4_SEED="1", T4_TB_FIXED_TIME=str(int(T0)))
+    r = subprocess.run([binary, "-t", str(tmp_path), "-r", "g1"], input=GRAPH_SCRIPT, capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "check TensorBoard param" not in r.stdout and "not written" not in r.stdout, r.stdout
+    run = os.path.join(str(tmp_path), "g1")
+    recs = records(open(glob.glob(os.path.join(run, "events.out.tfevents.*"))[0], "rb").read())
+    OP = {"conv2d ": "Conv2D", "maxpool": "MaxPool", "relu   ": "Relu", "flatten": "Reshape", "linear ": "MatMul", "softmax": "Softmax", "output ": "Output"}
+    layers = [("conv2d ", (2, 8, 8, 1)), ("maxpool", (2, 8, 8, 3)), ("relu   ", (2, 4, 4, 3)), ("flatten", (2, 4, 4, 3)), ("linear ", (2, 1, 48, 1)),
+              ("softmax", (2, 1, 5, 1)), ("output ", (2, 1, 5, 1))]
+
+    def attrs(shape):
+        dims = b"".join(f_len(2, f_i64(1, d)) for d in shape)
+        return f_len(5, f_len(1, b"dtype") + f_len(2, f_i64(6, 1))) + f_len(5, f_len(1, b"shape") + f_len(2, f_len(7, dims)))
+    names = ["%s_%d/%s" % (OP[l], i, l) for i, (l, _s) in enumerate(layers)]
+    graph = f_len(1, f_len(1, b"input") + f_len(2, b"Placeholder") + attrs(layers[0][1]))
+    for i, (l, shp) in enumerate(layers):
+        graph += f_len(1, f_len(1, names[i].encode()) + f_len(2, OP[l].encode()) + f_len(3, (names[i - 1] if i else "input").encode()) + attrs(shp))
+    want = [f_f64(1, T0) + f_i64(2, 0) + f_len(3, b"brain.Event:2"), f_i64(2, 0) + f_len(4, graph)]
+    assert len(recs) == 2
+    for i, (g, w) in enumerate(zip(recs, want)):
+        assert g == w, "record %d differs:\n got %s\nwant %s" % (i, g.hex(), w.hex())
+    # projector files: rows = samples, tab-separated, C++ `ostream << float` text; tag escaped like the run id
+    assert open(os.path.join(run, "act_l_1_tensors.tsv")).read() == "0.5\t-1\t2\t0.25\n1\t1\t1\t1\n0\t0\t0\t1e-07\n"
+    assert open(os.path.join(run, "act_l_1_metadata.tsv")).read() == "act_l_1.0\nact_l_1.1\nact_l_1.2\n"
+    assert open(os.path.join(run, "w_tensors.tsv")).read() == "1\t2\t3\t4\t5\t6\n"        # a matrix is one sample (N = 1) of H*W*C values
+    cfg = "".join('embeddings {\n  tensor_name: "%s"\n  tensor_path: "%s/%s_tensors.tsv"\n  metadata_path: "%s/%s_metadata.tsv"\n}\n' % (t, run, t, run, t) for t in ("act_l_1", "w"))
+    assert open(os.path.join(run, "projector_config.pbtxt")).read() == cfg
+
+
+def test_graph_event_and_projector_files_are_byte_exact(oracle_vm, tmp_path):
+    _graph_and_embed(oracle_vm, tmp_path)
+
+
+@pytest.mark.gpu
+def test_graph_event_and_projector_files_from_the_product_vm(tmp_path):
+    _graph_and_embed(TEN4, tmp_path)
 
 
 def test_words_only_hint_without_a_log_directory(oracle_vm):
