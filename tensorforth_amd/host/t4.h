@@ -12,6 +12,7 @@
 #include <math.h>
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include "../../include/t4k.h"
@@ -71,12 +72,18 @@ public:
     void   free(float *p);
     size_t used() const { return used_; }
     size_t live() const { return blocks_.size(); }
+    size_t peak() const { return peak_; }
+    size_t slabs() const { return slabs_.size(); }
+    size_t free_blocks() const { return free_.size(); }
 private:
     struct Slab { char *base; size_t size; };
     std::vector<Slab> slabs_;
     std::map<char *, size_t> free_;       // address -> bytes (coalesced)
     std::map<char *, size_t> blocks_;     // live allocations
-    size_t used_ = 0;
+    std::set<std::pair<size_t, char *>> by_size_;   // the free blocks again, ordered by (bytes, address): best fit
+    size_t used_ = 0, peak_ = 0;
+    void put_free(char *p, size_t sz);
+    void take_free(std::map<char *, size_t>::iterator it);
     void add_slab(size_t need);
 };
 

@@ -57,19 +57,23 @@ void Arena::add_slab(size_t need) {
     void *p = nullptr;
     if (chk(t4k_malloc(&p, sz), "arena slab")) { fprintf(stderr, "out of HBM\n"); exit(3); }
     slabs_.push_back({(char *)p, sz});
-    free_[(char *)p] = sz;
+    put_free((char *)p, sz);
 }
+// Free blocks are kept twice: by address (coalescing with the neighbours on free) and by size (best fit in O(log n) on alloc - the
+// reference's TLSF gives O(1); a `matmul drop` loop or a training script allocates and frees a tensor per word).  No headers live in
+// device memory: everything here is host-side bookkeeping over 256 MiB hipMalloc slabs.
+void Arena::put_free(char *p, size_t sz) { free_[p] = sz; by_size_.insert({sz, p}); }
+void Arena::take_free(std::map<char *, size_t>::iterator it) { by_size_.erase({it->second, it->first}); free_.erase(it); }
 float *Arena::alloc(size_t nfloat) {
-    size_t need = ((nfloat ? nfloat : 1) * sizeof(float) + 255) & ~(size_t)255;
+    const size_t need = ((nfloat ? nfloat : 1) * sizeof(float) + 255) & ~(size_t)255;
     for (int pass = 0; pass < 2; pass++) {
-        for (auto it = free_.begin(); it != free_.end(); ++it) {
-            if (it->second >= need) {
-                char *p = it->first; size_t rest = it->second - need;
-                free_.erase(it);
-                if (rest) free_[p + need] = rest;
-                blocks_[p] = need; used_ += need;
-                return (float *)p;
-            }
+        auto fit = by_size_.lower_bound({need, nullptr});  // smallest block that fits (lowest address among equals)
+        if (fit != by_size_.end()) {
+            char *p = fit->second; const size_t rest = fit->first - need;
+            take_free(free_.find(p));
+            if (rest) put_free(p + need, rest);
+            blocks_[p] = need; used_ += need; peak_ = std::max(peak_, used_);
+            return (float *)p;
         }
         add_slab(need);
     }
@@ -80,15 +84,14 @@ void Arena::free(float *fp) {
     auto b = blocks_.find(p);
     if (b == blocks_.end()) return;
     size_t sz = b->second; blocks_.erase(b); used_ -= sz;
+    auto same_slab = [this](char *a, char *c) { for (auto &s : slabs_) if (a >= s.base && a < s.base + s.size) return c >= s.base && c < s.base + s.size; return false; };
     auto nx = free_.lower_bound(p);
-    if (nx != free_.end() && p + sz == nx->first) { sz += nx->second; nx = free_.erase(nx); }     // merge with next
+    if (nx != free_.end() && p + sz == nx->first && same_slab(p, nx->first)) { sz += nx->second; auto dead = nx++; take_free(dead); }   // merge with next
     if (nx != free_.begin()) {
         auto pv = std::prev(nx);
-        bool same_slab = false;
-        for (auto &s : slabs_) if (pv->first >= s.base && p < s.base + s.size && p >= s.base) same_slab = true;
-        if (same_slab && pv->first + pv->second == p) { pv->second += sz; return; }                // merge with previous
+        if (pv->first + pv->second == p && same_slab(pv->first, p)) { p = pv->first; sz += pv->second; take_free(pv); }                 // merge with previous
     }
-    free_[p] = sz;
+    put_free(p, sz);
 }
 
 // ---------------------------------------------------------------- Store

@@ -462,8 +462,9 @@ void VM::init_core() {
     });
     CODE("trace", [this] { trace_lvl = POPi(); });
     CODE("mstat", [this] {
-        char b[160]; snprintf(b, sizeof(b), "\\ MMU.stat dict[%d/1024], pmem[%d]=%0.1f%%, obj#used[%d], HBM used=%zu KiB in %zu blocks\n",
-                              (int)dict_.size(), here_, 100.0 * here_ / PMEM_SZ, st().live(), Arena::get().used() >> 10, Arena::get().live());
+        char b[240]; snprintf(b, sizeof(b), "\\ MMU.stat dict[%d/1024], pmem[%d]=%0.1f%%, obj#used[%d], HBM used=%zu KiB in %zu blocks (peak %zu KiB, %zu free block(s), %zu slab(s))\n",
+                              (int)dict_.size(), here_, 100.0 * here_ / PMEM_SZ, st().live(), Arena::get().used() >> 10, Arena::get().live(),
+                              Arena::get().peak() >> 10, Arena::get().free_blocks(), Arena::get().slabs());
         pstr(b);
     });
     CODE("ms",    [this] { std::this_thread::sleep_for(std::chrono::milliseconds(POPi())); });
