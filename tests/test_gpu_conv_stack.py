@@ -218,6 +218,50 @@ def test_conv_stack_backward_matches_the_separate_layers(t4k, dev, oracle, case)
             assert rel(got, t[k_]) < RTOL, "stage %d bwd %s: %.3g" % (si, k_, rel(got, t[k_]))
 
 
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_conv_stack_forward_then_backward_uses_what_the_forward_saved(t4k, dev, oracle, case):
+    """forward THEN backward on the GPU: the backward now runs banded (several workgroups per image) on what the forward saved - a copy
+    of every conv input and the pool arg-max codes - instead of reading layer tensors a neighbouring band overwrites in place.  The
+    oracle's separate-layer backward is fed the GPU's own forward tensors, so masks and arg-max positions agree by construction and
+    every dX / dF / dB must match at 1e-4."""
+    N, H, W, Cin, stages, flat = CASES[case]
+    rng = np.random.default_rng(300 + case)
+    X = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    params = _params(rng, Cin, stages)
+    ref, _end = _oracle_forward(oracle, X, stages, flat, params, 55 + case, 4096)
+    arr, bufs = _build(dev, oracle, X, stages, flat, params, ref)
+    assert t4k.lib.t4k_conv_stack_ok(arr, len(stages), N) == 1
+    t4k.call("t4k_rand_init", 55 + case); t4k.call("t4k_rand_set_offset", 4096)
+    bufs[0]["X"].copy_(dev.torch.from_numpy(X))
+    t4k.call("t4k_conv_stack_fwd", p(bufs[0]["X"]), None, arr, len(stages), N, None)       # (the batch already sits in the layer-0 tensor)
+    got_fwd = []
+    x = X
+    for si, st_ in enumerate(stages):
+        t = {k_: dev.down(bufs[si][k_]).reshape(v.shape).copy() for k_, v in ref[si].items() if k_ in bufs[si]}
+        t["in"] = x
+        C0, K, pre, pool, post = st_
+        x = t["post_out"] if post else (t["pool_out"] if pool else (t["pre_out"] if pre else t["O"]))
+        t["last"] = x
+        got_fwd.append(t)
+    for si in range(len(stages)):
+        bufs[si]["DF"].fill_(0.25); bufs[si]["DB"].fill_(-0.5)
+    DY = rng.standard_normal(got_fwd[-1]["last"].shape).astype(np.float32)
+    want = _oracle_backward(oracle, got_fwd, stages, flat, params, DY)
+    t4k.call("t4k_conv_stack_bwd", p(dev.up(DY)), arr, len(stages), N, 1, None)
+    for si in range(len(stages) - 1, -1, -1):
+        t, d = want[si], bufs[si]
+        C0, K, pre, pool, post = stages[si]
+        assert rel(dev.down(d["DXS"]), t["DX"]) < RTOL, "stage %d dX: %.3g" % (si, rel(dev.down(d["DXS"]), t["DX"]))
+        assert np.array_equal(dev.down(d["X"]), dev.down(d["DXS"])), "stage %d: in = dx" % si
+        assert rel(dev.down(d["DF"]) - 0.25, t["DF"]) < RTOL, "stage %d dF: %.3g" % (si, rel(dev.down(d["DF"]) - 0.25, t["DF"]))
+        assert rel(dev.down(d["DB"]) + 0.5, t["DB"]) < RTOL, "stage %d dB: %.3g" % (si, rel(dev.down(d["DB"]) + 0.5, t["DB"]))
+        last = "post_out" if post else ("pool_out" if pool else ("pre_out" if pre else "O"))
+        for k_ in ("O", "pre_out", "pool_out", "post_out"):
+            if k_ not in t or (si + 1 < len(stages) and k_ == last) or (k_ == last and "copy_out" not in t):
+                continue
+            assert rel(dev.down(d[k_]).reshape(t[k_].shape), t[k_]) < RTOL, "stage %d bwd %s: %.3g" % (si, k_, rel(dev.down(d[k_]).reshape(t[k_].shape), t[k_]))
+
+
 def test_conv_stack_refuses_what_it_cannot_hold(t4k, dev, oracle):
     arr = (ConvStage * 1)()
     s = arr[0]; s.H, s.W, s.C1, s.C0, s.K = 32, 32, 64, 64, 3; s.run.KS = 1

@@ -33,6 +33,7 @@ int main(int argc, char **argv) {
     const char *mode = argc > 2 ? argv[2] : "fwd";
     const bool bwd = mode[0] == 'b';
     printf("N=%d mode=%s ok=%d\n", N, mode, t4k_conv_stack_ok(st, 2, N));
+    if (bwd && !getenv("CS_LAB_NOFWD")) t4k_conv_stack_fwd(X, X0, st, 2, N, nullptr);      // the banded backward runs on what a forward saved
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipStream_t ls = (hipStream_t)t4k_default_stream();
     for (int rep = 0; rep < 4; rep++) {
