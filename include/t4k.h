@@ -310,7 +310,11 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
  * Backward (_bconv backprop.cu:152-191, k_dconv2d nmath.tcu:211-338 incl. its un-flipped dX; _bactivate, _bpool): DY = gradient
  * w.r.t. the last run's last tensor; every run stage's input buffer receives its dX, each conv's input tensor X (forward values on
  * entry) receives dX (`in = dx`) and so does DXS when not NULL; train != 0: DF += sum over the batch, DB likewise (per-image
- * partials in the library workspace, folded in image order by a second small launch - deterministic). */
+ * partials in the library workspace, folded in image order by a second small launch - deterministic).
+ * t4k_conv_stack_fwd also leaves, per stack, a copy of every conv input and the pool arg-max codes in library memory; a backward that
+ * follows it (same N) runs BANDED - several workgroups per image - on those instead of on layer tensors a neighbouring band overwrites in
+ * place.  A caller whose latest forward did NOT go through t4k_conv_stack_fwd must say so with bit 1 of `train` (train | 2): the
+ * whole-image kernel then reads the layer tensors themselves. */
 typedef struct t4k_conv_stage {
     const float *F, *B;       /* filter T4(C1,K,K,C0), bias [C0] */
     float *O;                 /* conv output [N,H,W,C0] */

@@ -285,6 +285,7 @@ void Model::run_forward(Tensor &input) {
                 Tensor &m = *at(i).grad[4];
                 chk(t4k_dropout_mask(m.data, (long)m.numel, fork()), "rand"); masks = true;
             }
+    stack_fresh_.assign(layer.size(), 0);                // which conv stacks this forward ran through t4k_conv_stack_fwd (their saved state is current)
     const float *x = input.data;
     for (int i = 0; i + 1 < L; i++) {
         Tensor &in = at(i), &out = at(i + 1);
@@ -339,6 +340,7 @@ void Model::run_forward(Tensor &input) {
             const int ns = stack_at(i, stg, ops);
             if (ns >= 2 || (ns == 1 && stack_single_)) {
                 chk(t4k_conv_stack_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, stg, ns, in.N(), stream()), "nn#fstack");
+                stack_fresh_[i] = 1;
                 x = at(i + ops).data; i += ops - 1;
                 continue;
             }
@@ -598,7 +600,7 @@ void Model::run_backward(Tensor &tgt) {
                 const int k0 = stack_end_[i];
                 t4k_conv_stage stg[3]; int ops = 0;
                 const int ns = stack_at(k0, stg, ops);
-                if (ns > 0 && k0 + ops - 1 == i && chk(t4k_conv_stack_bwd(dy, stg, ns, at(k0).N(), train ? 1 : 0, s), "nn#bstack") == T4K_OK) {
+                if (ns > 0 && k0 + ops - 1 == i && chk(t4k_conv_stack_bwd(dy, stg, ns, at(k0).N(), (train ? 1 : 0) | ((k0 < (int)stack_fresh_.size() && stack_fresh_[k0]) ? 0 : 2), s), "nn#bstack") == T4K_OK) {
                     for (int k = i; k >= k0; k--) if (at(k).grad_fn == T4K_L_CONV) grads_ready(k, at(k));      // slab segments complete, last layer first
                     dy = at(k0).data; j += i - k0; i = k0;
                     continue;

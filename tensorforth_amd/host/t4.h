@@ -281,6 +281,7 @@ private:
     std::vector<Run> runs_;
     void plan_runs();
     static bool use_fusion;                    // T4_FUSE=0 keeps one launch per layer
+    std::vector<char> stack_fresh_;            // per first-op index: the latest forward took the stack kernel (so what it saved for the backward is current)
     std::vector<int> stack_end_;              // last op of a conv stack -> its first op (run_backward), rebuilt after finalize
     bool stack_single_ = false;                // single-stage stacks too (measured: off)
     static bool use_stack;                     // T4_STACK=0: no sample-resident conv stacks (csrc/conv_stack.hip)

@@ -176,8 +176,12 @@ def _oracle_backward(oracle, ref, stages, flat, params, DY):
     return out
 
 
+@pytest.mark.parametrize("stale", [False, True], ids=["cold", "stale-saved-state"])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_conv_stack_backward_matches_the_separate_layers(t4k, dev, oracle, case):
+def test_conv_stack_backward_matches_the_separate_layers(t4k, dev, oracle, case, stale):
+    """backward from the layer tensors alone (whole-image kernel).  `stale`: a stack forward of ANOTHER batch ran first and left its
+    saved conv inputs / arg-max codes behind, then the layer tensors were rewritten by some other path (here: loaded from the oracle);
+    the caller says so with train | 2 and the backward must not touch the saved state."""
     N, H, W, Cin, stages, flat = CASES[case]
     if any(a in ("sigmoid",) for st_ in stages for a in st_[2:]):
         pytest.skip("pass-through activation")
@@ -187,6 +191,9 @@ def test_conv_stack_backward_matches_the_separate_layers(t4k, dev, oracle, case)
     ref, _end = _oracle_forward(oracle, X, stages, flat, params, 77 + case, 8192)
     arr, bufs = _build(dev, oracle, X, stages, flat, params, ref)
     assert t4k.lib.t4k_conv_stack_ok(arr, len(stages), N) == 1
+    if stale:
+        other = dev.up(rng.standard_normal((N, H, W, Cin)).astype(np.float32) * 3)
+        t4k.call("t4k_conv_stack_fwd", p(other), p(bufs[0]["X"]), arr, len(stages), N, None)
     # load the ORACLE's forward state: same arg-max positions and masks on both sides
     for si in range(len(stages)):
         for k_, v in ref[si].items():
@@ -198,7 +205,7 @@ def test_conv_stack_backward_matches_the_separate_layers(t4k, dev, oracle, case)
         bufs[si]["DF"].fill_(0.25); bufs[si]["DB"].fill_(-0.5)
     DY = rng.standard_normal(ref[-1]["last"].shape).astype(np.float32)
     want = _oracle_backward(oracle, ref, stages, flat, params, DY)
-    t4k.call("t4k_conv_stack_bwd", p(dev.up(DY)), arr, len(stages), N, 1, None)
+    t4k.call("t4k_conv_stack_bwd", p(dev.up(DY)), arr, len(stages), N, 3 if stale else 1, None)
     for si in range(len(stages) - 1, -1, -1):
         t, d = want[si], bufs[si]
         C0, K, pre, pool, post = stages[si]
@@ -269,3 +276,34 @@ def test_conv_stack_refuses_what_it_cannot_hold(t4k, dev, oracle):
     assert t4k.lib.t4k_conv_stack_ok(arr, 1, 4) == 0                         # 64 channels: the LDS-staged MFMA GEMM kernels' territory
     s.C1, s.C0, s.K = 4, 4, 4
     assert t4k.lib.t4k_conv_stack_ok(arr, 1, 4) == 0                         # even kernel size
+
+
+def test_backprop_after_a_traced_forward_ignores_what_an_earlier_stack_forward_saved():
+    """host side of the `train | 2` flag (model.cpp run_forward / run_backward): a fused forward of batch A leaves its conv inputs and
+    arg-max codes saved; a forward of batch B under `1 trace` takes the separate layer kernels; the backprop that follows is fused
+    again and must differentiate B's forward, not A's.  Compared with a VM that ran B's forward through the stack kernel (same
+    Philox positions, so the same dropout masks)."""
+    from lenet_parity import GRADS, NET, TOL, _get
+    from tensorforth_amd.vm import VM
+    from vm_util import rel_err
+    N = 32
+    got = {}
+    for traced in (False, True):
+        vm = VM(device=0, seed=777)
+        try:
+            out = vm.eval("0 trace\n%d 28 28 1 nn.model %s constant net\n%d 28 28 1 tensor rand constant imgA\n%d 28 28 1 tensor rand constant imgB\n"
+                          ": hot ( T -- T ) %d 0 do 1 i 10 * i 7 * 10 mod + t! loop ;\n%d vector zeros hot %d 1 10 1 reshape4 constant lbl\n"
+                          % (N, NET, N, N, N, N * 10, N))
+            assert "?" not in out.replace("-> ok", ""), out
+            vm.eval("net imgA forward drop\n")                                     # fused: saves A's state
+            pos = vm.rand_tell()
+            vm.eval("1 trace net imgB forward drop 0 trace\n" if traced else "net imgB forward drop\n")
+            assert vm.rand_tell() > pos
+            vm.eval("net lbl backprop drop\n")
+            got[traced] = {n_: _get(vm, e) for n_, e in GRADS}
+            got[traced]["dx"] = _get(vm, "0 n@")
+        finally:
+            vm.close()
+    for n_ in got[False]:
+        e = rel_err(got[True][n_], got[False][n_])
+        assert e <= TOL, "%s after a traced forward: %.3g" % (n_, e)
