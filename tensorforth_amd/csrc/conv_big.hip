@@ -261,6 +261,132 @@ __global__ void __launch_bounds__(256) k_convbig_df(CdP p) {
     }
 }
 
+// ------------------------------------------------------------------ dF partials, 8-wave LDS-DMA pipeline (round 3)
+// The same split-K GEMM (one tap x 64 ci x 64 co per workgroup, K = the slice's pixels) on the dense GEMM's lean pipeline
+// (gemm.hip k_gemm_nn_plain, both operands k-major - its fastest layout): 8 waves = 2 k-groups x 2x2 waves of 32x32 accumulator pairs,
+// stages of BKP pixels moved by global_load_lds_dwordx4 (no VGPR round trip, no ds_write), operand reads of chunk c+1 issued before the
+// MFMAs of chunk c, the next stage's first reads before the last MFMAs of this one.  What the conv adds is the address of a lane's
+// 16 bytes: row k of the A stage is the input pixel under tap (ky, kx) of output pixel k - each lane keeps the (n, y, x) of its rows and
+// advances them by BKP pixels per stage without divisions - and rows outside the image / past the slice / channel groups past C1, C0
+// read from a 4 KiB page of zeros (State::d_zero), so the LDS stage needs no zero fill and the MFMA loop no predicates.
+struct Cd8 { const float *I, *DO, *Z; float *part; int N, H1, W1, C1, H0, W0, C0; int pix_per_slice, ci_tiles; long npix; };
+
+template <int K, int S, int P, int BKP>
+__global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
+    constexpr int BM = 64, BN = 64, KK = K * K;
+    constexpr int NCH = BKP / 8, NCG = NCH / 2;            // 8-deep chunks per stage, per k-group
+    constexpr int STAGE = (BM + BN) * BKP;                 // floats per stage buffer
+    constexpr int NJ = BKP / 32;                           // DMA instructions (4 k rows x 256 B) per operand per wave per stage
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = w >> 2, w4 = w & 3, wm = w4 >> 1, wn = w4 & 1, h = lane >> 5, l31 = lane & 31;
+    const int c0 = kg * NCG;
+    const int tap = blockIdx.y / p.ci_tiles, cit = blockIdx.y - tap * p.ci_tiles;
+    const int ky = tap / K, kx = tap - ky * K;
+    const int m0 = cit * BM, n0 = blockIdx.z * BN;          // ci0, co0
+    const long k_beg = (long)blockIdx.x * p.pix_per_slice, k_end = min(p.npix, k_beg + p.pix_per_slice);
+    const int nst = k_end > k_beg ? (int)((k_end - k_beg + BKP - 1) / BKP) : 0;
+
+    // this lane's rows of a stage: kk = (w * NJ + j) * 4 + lane / 16, its 16-byte channel group ch = lane % 16
+    const int ch = lane & 15;
+    const bool a_col = m0 + ch * 4 < p.C1, b_col = n0 + ch * 4 < p.C0;
+    int cx[NJ], cy[NJ], cn[NJ]; long cp[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const long pix = k_beg + (w * NJ + j) * 4 + (lane >> 4);
+        cp[j] = pix; cx[j] = (int)(pix % p.W0); const long t = pix / p.W0; cy[j] = (int)(t % p.H0); cn[j] = (int)(t / p.H0);
+    }
+    const int dxs = BKP % p.W0, dys = BKP / p.W0, dyr = dys % p.H0, dns = dys / p.H0;
+    const float *zsrc = p.Z + ch * 4;
+    const float *abase = p.I + m0 + ch * 4, *bbase = p.DO + n0 + ch * 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    // issue the DMA of the stage the coordinates stand at, then advance them one stage
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int gi = cy[j] * S + ky - P, gj = cx[j] * S + kx - P;
+            const bool in = cp[j] < k_end;
+            const bool oka = in && a_col && gi >= 0 && gi < p.H1 && gj >= 0 && gj < p.W1;
+            const float *pa = oka ? abase + (((long)cn[j] * p.H1 + gi) * p.W1 + gj) * p.C1 : zsrc;
+            const float *pb = (in && b_col) ? bbase + cp[j] * p.C0 : zsrc;
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(pa), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(pb), "s"(la + BM * BKP * 4) : "memory");
+            cp[j] += BKP;
+            cx[j] += dxs; const int c1 = cx[j] >= p.W0 ? 1 : 0; cx[j] -= c1 ? p.W0 : 0;
+            cy[j] += dyr + c1; const int c2 = cy[j] >= p.H0 ? 1 : 0; cy[j] -= c2 ? p.H0 : 0;
+            cn[j] += dns + c2;
+        }
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int ra_ = wm * 32 + l31, rb_ = wn * 32 + l31;
+    auto rd = [&](const float *a, const float *b, int ci, float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { av[j] = a[(ci * 8 + 4 * h + j) * BM + ra_]; bv[j] = b[(ci * 8 + 4 * h + j) * BN + rb_]; }
+    };
+    auto mm = [&](float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
+    };
+    float ca[4], cb[4];
+    if (nst > 0) {
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        rd(lds, lds + BM * BKP, c0, ca, cb);
+    }
+    int buf = 0;
+    for (int kt = 0; kt < nst; kt++) {
+        const int b1 = buf ^ 1;
+        if (kt + 1 < nst) issue(b1);
+        const float *a = lds + buf * STAGE, *b = a + BM * BKP;
+#pragma unroll
+        for (int ci = 0; ci + 1 < NCG; ci++) {
+            float na[4], nbv[4];
+            rd(a, b, c0 + ci + 1, na, nbv);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float na[4], nbv[4];
+        if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BKP, c0, na, nbv);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ca, cb);
+        if (kt + 1 < nst) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
+        }
+        buf = b1;
+    }
+    // the two k-groups meet in LDS (the stage buffers are free now), group 0 writes the slab rows
+    __syncthreads();
+    if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[(w4 * 16 + r) * 64 + lane] = acc0[r] + acc1[r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+    // partial slab [slice][row = (ci*K+ky)*K+kx][co]  (the fold's layout, without a bias row)
+    const int co = n0 + wn * 32 + l31;
+    const long nrow = (long)p.C1 * KK;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int ci = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = (acc0[r] + acc1[r]) + lds[(w4 * 16 + r) * 64 + lane];
+        if (co < p.C0 && ci < p.C1) p.part[((long)blockIdx.x * nrow + ((long)ci * KK + tap)) * p.C0 + co] = v;
+    }
+}
+
 } // namespace
 
 namespace t4k {
@@ -309,6 +435,33 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
     // L2 instead of crossing the fabric once per tap (a trailing slice may be empty: it writes a zero slab)
     static int x8 = -1; if (x8 < 0) { const char *e = getenv("T4K_DF_XCD"); x8 = e ? atoi(e) : 1; }
     if (x8 && nslice >= 8) { nslice = (nslice + 7) / 8 * 8; pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; }
+    static int df8 = -1; if (df8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8"); df8 = e ? atoi(e) : 64; }     // 0: the 4-wave register-staged kernel; 64 / 128: pixels per stage of the 8-wave LDS-DMA kernel
+    if (df8 && npix < (1L << 31) && st().d_zero) {
+        // 64-pixel stages: 64 KiB of LDS, two workgroups per CU (one's barrier under the other's MFMAs) -> up to 2 x CUs workgroups at once, all resident
+        const int bkp = df8 >= 128 ? 128 : df8 >= 64 ? 64 : 32;
+        static int wpc8 = -1; if (wpc8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8_WPC"); wpc8 = e ? atoi(e) : 0; }
+        const long slots = (long)st().cu_count * (wpc8 > 0 ? wpc8 : bkp == 128 ? 1 : bkp == 64 ? 2 : 3);
+        long ns = slots / tiles; if (ns < 1) ns = 1;
+        if (x8 && ns >= 8) ns = ns / 8 * 8;                  // every tap / channel tile of one pixel slice on the same XCD (see above)
+        long pp = (npix + ns - 1) / ns; pp = (pp + bkp - 1) / bkp * bkp; if (pp < 4 * bkp) pp = 4 * bkp;
+        ns = (npix + pp - 1) / pp;
+        if ((size_t)ns * C1 * KK * C0 > part_floats) return 0;
+        Cd8 q = { I, DO, st().d_zero, part, N, H1, W1, C1, H0, W0, C0, (int)pp, ci_tiles, npix };
+        const dim3 g8((unsigned)ns, (unsigned)(KK * ci_tiles), (unsigned)co_tiles), b8(512);
+#define DF8(k, s, pd) do { if (bkp == 128) { static bool a1 = false; const int lb = 2 * 128 * 128 * 4; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_df8<k, s, pd, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); a1 = true; } \
+                                             hipLaunchKernelGGL((k_convbig_df8<k, s, pd, 128>), g8, b8, lb, hs, q); } \
+                           else if (bkp == 32) hipLaunchKernelGGL((k_convbig_df8<k, s, pd, 32>), g8, b8, 2 * 128 * 32 * 4, hs, q); \
+                           else { static bool a2 = false; const int lb = 2 * 128 * 64 * 4; if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_df8<k, s, pd, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); a2 = true; } \
+                                  hipLaunchKernelGGL((k_convbig_df8<k, s, pd, 64>), g8, b8, lb, hs, q); } } while (0)
+        switch ((K << 8) | (S << 4) | P) {
+        case 0x110: DF8(1, 1, 0); break;
+        case 0x311: DF8(3, 1, 1); break;
+        case 0x421: DF8(4, 2, 1); break;
+        case 0x512: DF8(5, 1, 2); break;
+        }
+#undef DF8
+        return (int)ns;
+    }
     if ((size_t)nslice * C1 * KK * C0 > part_floats) return 0;
     CdP p = { I, DO, part, N, H1, W1, C1, H0, W0, C0, (int)pps, ci_tiles };
     const dim3 g((unsigned)nslice, (unsigned)(KK * ci_tiles), (unsigned)co_tiles), b(256);

@@ -773,7 +773,13 @@ __global__ void __launch_bounds__(256) k_gemm_glds(GemmP p) {
 // 8-wave variant: the same pipeline with two waves per SIMD.  Waves 4..7 take the upper half of every stage's k chunks
 // into their own accumulators, so one wave's LDS reads and waits sit under the other's MFMAs; the halves are summed
 // through LDS in the epilogue (fixed order).
-template <int BK, bool AKC, bool BKC, bool PRIO = false>   // PRIO: s_setprio around the MFMA burst - measured +1.2 us at 1024^3, kept off
+//
+// RAGK: K need not be a whole number of stages.  The last, partial stage is one more DMA stage whose source addresses are clamped to the
+// operand's last valid 16-byte group / row (so every lane still moves 16 bytes and the vmcnt bookkeeping is unchanged); the 8-deep chunks
+// past the tail are never read, and in a partial last chunk the k positions past the tail are zeroed in registers on BOTH operands
+// (0 x stale-LDS garbage could be NaN).  The tail's chunks alternate between the two k-groups.  K = 784 (a 28 x 28 image row, the GAN
+// layer width) = 6 stages of 128 + 16: this kernel instead of the predicated register-staged one.
+template <int BK, bool AKC, bool BKC, bool PRIO = false, bool RAGK = false>   // PRIO: s_setprio around the MFMA burst - measured +1.2 us at 1024^3, kept off
 __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     constexpr int BM = 64, BN = 64;
     constexpr int NC = BK / 8, CH = BK / 4, SW = (64 / BK) > 0 ? (64 / BK) : 1;
@@ -807,6 +813,8 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     const int kbeg = blockIdx.y * p.kchunk;
     const int kend = min(K, kbeg + p.kchunk);
     const int nst  = (kend - kbeg) / BK;
+    const int tail = RAGK ? (kend - kbeg) - nst * BK : 0;      // k positions of the partial last stage
+    const int nstT = nst + (tail > 0 ? 1 : 0);                 // stages the DMA pipeline moves
 
     // per-lane DMA source offsets (bytes from the operand base) of stage 0; the launcher guarantees both operands span < 4 GiB
     unsigned voffA[NJ], voffB[NJ];
@@ -840,6 +848,35 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
         }
+    };
+    // the partial last stage: same LDS placement (a lane's 16 bytes land at its own slot whatever the exec mask), but only the lanes /
+    // instructions whose k lies inside the tail move anything - a clamped full stage would cost a full stage of L2 bandwidth for 16 columns.
+    // Three-buffer pipelines count vmcnt per stage, so there every instruction is issued (sources clamped into [kb, kend)).
+    auto issue_tail = [&](int buf) __attribute__((always_inline)) {
+        const int kb = kbeg + nst * BK;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int i = w * NJ + j;
+            unsigned va, vb; bool oka, okb;
+            if (AKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
+                       oka = q * 4 < tail;
+                       va = (unsigned)(((long)min(m0 + r, M - 1) * K + min(kb + q * 4, kend - 4)) * 4); }
+            else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
+                       oka = i * 4 < tail;                                  // wave-uniform: whole instructions past the tail are skipped
+                       va = (unsigned)(((long)min(kb + kk, kend - 1) * M + min(m0 + ch * 4, M - 4)) * 4); }
+            if (BKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
+                       okb = q * 4 < tail;
+                       vb = (unsigned)(((long)min(n0 + r, N - 1) * K + min(kb + q * 4, kend - 4)) * 4); }
+            else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
+                       okb = i * 4 < tail;
+                       vb = (unsigned)(((long)min(kb + kk, kend - 1) * N + min(n0 + ch * 4, N - 4)) * 4); }
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + i * 256) * 4));
+            if (NST == 3 || oka) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(va), "s"(p.A), "s"(la) : "memory");
+            if (NST == 3 || okb) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vb), "s"(p.B), "s"(la + BM * BK * 4) : "memory");
+        }
+    };
+    auto issue_any = [&](int kt, int buf) __attribute__((always_inline)) {
+        if (!RAGK || kt < nst) issue(kt, buf); else issue_tail(buf);
     };
 
     f32x16 acc0, acc1;
@@ -880,9 +917,9 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
         __builtin_amdgcn_s_barrier();
     };
 
-    if (nst > 0) issue(0, 0);
-    if (NST == 3 && nst > 1) issue(1, 1);
-    wait_next(NST == 3 && nst > 1);
+    if (nstT > 0) issue_any(0, 0);
+    if (NST == 3 && nstT > 1) issue_any(1, 1);
+    wait_next(NST == 3 && nstT > 1);
 
     // Software pipeline: the operands of chunk c+1 are read BEFORE the MFMAs of chunk c are issued,
     // and the MFMAs of a stage's last chunk are issued after the barrier, behind the first reads of
@@ -893,8 +930,8 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
     for (int kt = 0; kt < nst; kt++) {
         int nb = buf + 2; if (nb >= 3) nb -= 3;
         int b1 = buf + 1; if (b1 >= NST) b1 = 0;
-        if (NST == 3) { if (kt + 2 < nst) issue(kt + 2, nb); }      // overwrites the buffer read in stage kt-1
-        else          { if (kt + 1 < nst) issue(kt + 1, b1); }      // two buffers: the other one was read in stage kt-1
+        if (NST == 3) { if (kt + 2 < nstT) issue_any(kt + 2, nb); }      // overwrites the buffer read in stage kt-1
+        else          { if (kt + 1 < nstT) issue_any(kt + 1, b1); }      // two buffers: the other one was read in stage kt-1
         const float *a = lds + buf * STAGE, *b = a + BM * BK;
 #pragma unroll
         for (int ci = 0; ci + 1 < NCG; ci++) {
@@ -906,7 +943,7 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
 #pragma unroll
             for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
         }
-        wait_next(NST == 3 && kt + 2 < nst);                // all my reads of stage kt done; stage kt+1 visible
+        wait_next(NST == 3 && kt + 2 < nstT);               // all my reads of stage kt done; stage kt+1 visible
         float na[4], nbv[4];
         if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, c0, na, nbv);
         __builtin_amdgcn_sched_barrier(0);
@@ -916,6 +953,26 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
             for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
         }
         buf = b1;
+    }
+    if (RAGK && tail > 0) {                                  // the partial stage sits in `buf`, visible since the last barrier
+        const float *a = lds + buf * STAGE, *b = a + BM * BK;
+        const int nct = (tail + 7) >> 3;
+        // k positions past the tail are zeroed when the fragment is handed to the MFMAs (not at the read: that would wait for the LDS round trip)
+        auto zf = [&](int c, float (&dv)[4], float (&ev)[4], const float (&av)[4], const float (&bv)[4]) __attribute__((always_inline)) {
+            const int k0 = c * 8 + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const bool in = k0 + j < tail; dv[j] = in ? av[j] : 0.f; ev[j] = in ? bv[j] : 0.f; }
+        };
+        int c = kg;                                          // its chunks alternate between the k-groups; same read-ahead as the main loop
+        float ra4[4], rb4[4];
+        if (c < nct) { rd(a, b, c, ra4, rb4); zf(c, ca, cb, ra4, rb4); }
+        for (; c < nct; c += 2) {
+            if (c + 2 < nct) rd(a, b, c + 2, ra4, rb4);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nct) zf(c + 2, ca, cb, ra4, rb4);
+        }
     }
 
     const float alpha = p.alpha, beta = p.beta;
@@ -951,8 +1008,17 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
 // The plain product O = A @ B (word `matmul`, tA = tB = 0, alpha = 1, beta = 0, no bias, interior 64x64 tiles, K % 128 == 0) has its own
 // copy of the 8-wave kernel with nothing else in it: the same loop inside the general template above measures 20.1 us at 1024^3, this
 // one 19.4 (tools/gemm_lab.hip: every variant with in-kernel cycle stamps; the loop is sensitive to the code around it).
-struct PlainP { const float *A, *B; float *O; int M, N, K; };
-template <bool POW2>
+struct PlainP { const float *A, *B; float *O; int M, N, K; float alpha, beta; const float *bias; int *sync; float *part; };
+// The other operand layouts (word `matmul` on transposed views; Tensor::linear tensor.cu:79-87 = X @ W^T + b with alpha / beta) get the same
+// lean kernel instead of the general template: AKC / BKC pick the operand layout (K-contiguous rows, read with ds_read_b128 through the
+// XOR swizzle, or k-major rows read per k), EPI adds alpha / beta / bias to the store.  Interior 64x64 tiles, K % 128 == 0, unsplit.
+// PAIR: an output of 65..128 tiles would leave half the CUs idle (512 x 1024 x 1024: 128 tiles).  gridDim.y = 2 workgroups share a tile,
+// one K half each; the first to finish parks its 64x64 partial in the workspace and raises a flag, the second adds it and stores -
+// a + b == b + a, so the result does not depend on who arrives first and no fold launch follows.  The parker never waits, so the
+// waiter's (bounded) spin cannot deadlock whatever the residency.
+// RAGK: K >= 128 with a partial last stage (784 = 6 x 128 + 16), see k_gemm_glds8: the tail is one more DMA stage in which only the lanes whose
+// k lies inside the tail move anything, its 8-deep chunks alternate between the k-groups, positions past the tail are zeroed in registers.
+template <bool POW2, bool AKC = true, bool BKC = false, bool EPI = false, bool PAIR = false, bool RAGK = false>
 __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
     constexpr int BM = 64, BN = 64, BK = 128;
     constexpr int NC = BK / 8, CH = BK / 4;
@@ -981,20 +1047,25 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
         const int gsz = min(tiles_m - first_m, GROUP_M);
         tm = first_m + (L % per_group) % gsz; tn = (L % per_group) / gsz;
     }
-    const int m0 = tm * BM, n0 = tn * BN, nst = K / BK;
+    const int m0 = tm * BM, n0 = tn * BN, nst = PAIR ? (K >> 1) / BK : K / BK;
+    const int kt0 = PAIR ? (int)blockIdx.y * nst : 0;      // first stage of this workgroup's K half
+    const int tail = RAGK ? K - nst * BK : 0;
     unsigned voffA[NJ], voffB[NJ];
     {
         const int r0 = w * 8 + (lane >> 5), ql = lane & 31, kk0 = w * 16 + (lane >> 4);
-        const unsigned ba = (unsigned)((m0 + r0) * K) * 4u, bb = (unsigned)(kk0 * N + n0 + (lane & 15) * 4) * 4u;   // one multiply per operand
+        // one multiply per operand: a K-contiguous operand's instruction j covers rows r0 + 2j (swizzled 16-byte groups), a k-major one's k rows kk0 + 4j
+        const unsigned ba = AKC ? (unsigned)((m0 + r0) * K) * 4u : (unsigned)(kk0 * M + m0 + (lane & 15) * 4) * 4u;
+        const unsigned bb = BKC ? (unsigned)((n0 + r0) * K) * 4u : (unsigned)(kk0 * N + n0 + (lane & 15) * 4) * 4u;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            voffA[j] = ba + (unsigned)(2 * j * K) * 4u + (unsigned)((ql ^ ((r0 + 2 * j) & 31)) << 4);
-            voffB[j] = bb + (unsigned)(4 * j * N) * 4u;
+            voffA[j] = AKC ? ba + (unsigned)(2 * j * K) * 4u + (unsigned)((ql ^ ((r0 + 2 * j) & 31)) << 4) : ba + (unsigned)(4 * j * M) * 4u;
+            voffB[j] = BKC ? bb + (unsigned)(2 * j * K) * 4u + (unsigned)((ql ^ ((r0 + 2 * j) & 31)) << 4) : bb + (unsigned)(4 * j * N) * 4u;
         }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
     auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        const float *ba = p.A + (long)kt * BK, *bb = p.B + (long)kt * BK * N;
+        const long ks = kt0 + kt;
+        const float *ba = p.A + (AKC ? ks * BK : ks * BK * M), *bb = p.B + (BKC ? ks * BK : ks * BK * N);
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
@@ -1002,15 +1073,34 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
         }
     };
+    auto issue_tail = [&](int buf) __attribute__((always_inline)) {        // stage nst: same lane offsets, lanes past the tail switched off (nothing read out of bounds)
+        const float *ba = p.A + (AKC ? (long)nst * BK : (long)nst * BK * M), *bb = p.B + (BKC ? (long)nst * BK : (long)nst * BK * N);
+        const int r0 = w * 8 + (lane >> 5), ql = lane & 31, kk0 = w * 16 + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
+            const bool kin = ((ql ^ ((r0 + 2 * j) & 31)) << 2) < tail, rin = kk0 + 4 * j < tail;
+            if (AKC ? kin : rin) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
+            if (BKC ? kin : rin) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
+        }
+    };
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const int ra_ = wm * 32 + l31, rb_ = wn * 32 + l31;
     auto rd = [&](const float *a, const float *b, int ci, float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
-        const v4f t = *reinterpret_cast<const v4f *>(a + ra_ * BK + (((ci * 2 + h) ^ (ra_ & (CH - 1))) << 2));
-        av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3];
+        if (AKC) { const v4f t = *reinterpret_cast<const v4f *>(a + ra_ * BK + (((ci * 2 + h) ^ (ra_ & (CH - 1))) << 2));
+                   av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3]; }
+        else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) bv[j] = b[(ci * 8 + 4 * h + j) * BN + rb_];
+            for (int j = 0; j < 4; j++) av[j] = a[(ci * 8 + 4 * h + j) * BM + ra_];
+        }
+        if (BKC) { const v4f t = *reinterpret_cast<const v4f *>(b + rb_ * BK + (((ci * 2 + h) ^ (rb_ & (CH - 1))) << 2));
+                   bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3]; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[j] = b[(ci * 8 + 4 * h + j) * BN + rb_];
+        }
     };
     auto mm = [&](float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
@@ -1029,6 +1119,7 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
     for (int kt = 0; kt < nst; kt++) {
         const int b1 = buf ^ 1;
         if (kt + 1 < nst) issue(kt + 1, b1);
+        else if (RAGK && tail > 0) issue_tail(b1);
         const float *a = lds + buf * STAGE, *b = a + BM * BK;
 #pragma unroll
         for (int ci = 0; ci + 1 < NCG; ci++) {
@@ -1051,6 +1142,25 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
         }
         buf = b1;
     }
+    if (RAGK && tail > 0) {                                  // the partial stage sits in `buf`, visible since the last barrier
+        const float *a = lds + buf * STAGE, *b = a + BM * BK;
+        const int nct = (tail + 7) >> 3;
+        auto zf = [&](int c, float (&dv)[4], float (&ev)[4], const float (&av)[4], const float (&bv)[4]) __attribute__((always_inline)) {
+            const int k0 = c * 8 + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const bool in = k0 + j < tail; dv[j] = in ? av[j] : 0.f; ev[j] = in ? bv[j] : 0.f; }
+        };
+        int c = kg;
+        float ra4[4], rb4[4];
+        if (c < nct) { rd(a, b, c, ra4, rb4); zf(c, ca, cb, ra4, rb4); }
+        for (; c < nct; c += 2) {
+            if (c + 2 < nct) rd(a, b, c + 2, ra4, rb4);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nct) zf(c + 2, ca, cb, ra4, rb4);
+        }
+    }
     const int gn = n0 + wn * 32 + l31;
     float add[16];
     __syncthreads();
@@ -1059,29 +1169,96 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
         for (int r = 0; r < 16; r++) lds[(w4 * 16 + r) * 64 + lane] = acc0[r] + acc1[r];
     }
     __syncthreads();
-    if (kg == 1) return;
+    if (!PAIR && kg == 1) return;
+    if (PAIR) {
+        if (kg == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) add[r] = lds[(w4 * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; r++) add[r] = (acc0[r] + acc1[r]) + lds[(w4 * 16 + r) * 64 + lane];      // this workgroup's K half, complete
+        }
+        __shared__ int role_s;
+        const int tile_id = tm * tiles_n + tn;
+        int *ticket = p.sync + tile_id, *flag = p.sync + 2048 + tile_id;
+        float *slot = p.part + (long)tile_id * (BM * BN);
+        const int t4 = tid & 255;
+        if (tid == 0) role_s = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // agent-scope (cache-bypassing) stores and loads carry the payload: the two workgroups may sit on different XCDs (private L2s)
+        if (role_s == 0) {
+            if (kg == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        __builtin_nontemporal_store((acc0[r] + acc1[r]) + add[r], &p.O[(long)gm * N + gn]);
+                for (int r = 0; r < 16; r++) __hip_atomic_store(&slot[r * 256 + t4], add[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            T4K_SPIN_WAIT(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0, 3);
+            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = add[r]; acc1[r] = 0.f; add[r] = __hip_atomic_load(&slot[r * 256 + t4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) add[r] = lds[(w4 * 16 + r) * 64 + lane];
+    }
+    if (EPI) {
+        const float alpha = p.alpha, beta = p.beta;
+        const float bv_ = p.bias ? p.bias[gn] : 0.f;
+        float old[16];
+        if (beta != 0.f) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) old[r] = p.O[(long)(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + gn];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float o = ((acc0[r] + acc1[r]) + add[r]) * alpha;
+            if (beta != 0.f) o += old[r] * beta;
+            if (p.bias) o += bv_;
+            __builtin_nontemporal_store(o, &p.O[(long)gm * N + gn]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            __builtin_nontemporal_store((acc0[r] + acc1[r]) + add[r], &p.O[(long)gm * N + gn]);
+        }
     }
 }
-void launch_nn_plain(const GemmP &p, dim3 grid, hipStream_t s) {
+template <bool AKC, bool BKC, bool EPI, bool PAIR = false, bool RAGK = false>
+void launch_plain_(const PlainP &q, int tmq, int tnq, unsigned gx, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)2 * 128 * 128 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain<false, AKC, BKC, EPI, PAIR, RAGK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain<true, AKC, BKC, EPI, PAIR, RAGK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_done = true;
     }
-    PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K };
-    const int tmq = p.M / 64, tnq = p.N / 64;
     static int fastpro = -1; if (fastpro < 0) { const char *e = getenv("T4K_GEMM_FASTPRO"); fastpro = e ? atoi(e) : 1; }
     const bool pow2 = fastpro && (tmq & (tmq - 1)) == 0 && (tnq & (tnq - 1)) == 0 && tmq >= 4 && (tmq * tnq) % 32 == 0;
-    if (pow2) hipLaunchKernelGGL(k_gemm_nn_plain<true>,  dim3(grid.x), dim3(512), lds_bytes, s, q);
-    else      hipLaunchKernelGGL(k_gemm_nn_plain<false>, dim3(grid.x), dim3(512), lds_bytes, s, q);
+    const dim3 grid(gx, PAIR ? 2 : 1);
+    if (pow2) hipLaunchKernelGGL((k_gemm_nn_plain<true, AKC, BKC, EPI, PAIR, RAGK>),  grid, dim3(512), lds_bytes, s, q);
+    else      hipLaunchKernelGGL((k_gemm_nn_plain<false, AKC, BKC, EPI, PAIR, RAGK>), grid, dim3(512), lds_bytes, s, q);
+}
+void launch_nn_plain(const GemmP &p, dim3 grid, hipStream_t s) {
+    PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, 1.0f, 0.0f, nullptr, nullptr, nullptr };
+    launch_plain_<true, false, false>(q, p.M / 64, p.N / 64, grid.x, s);
+}
+// any layout, alpha / beta / bias: interior tiles, K % 128 == 0, unsplit - or, pair = true, K % 256 == 0 and two workgroups per tile (the caller checks)
+void launch_plain_any(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s, bool pair = false, bool ragk = false) {
+    PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, p.sync, p.part };
+    const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias;
+    const int tmq = p.M / 64, tnq = p.N / 64;
+#define T4K_PL(A_, B_) do { if (ragk) { if (epi) launch_plain_<A_, B_, true, false, true>(q, tmq, tnq, grid.x, s); else launch_plain_<A_, B_, false, false, true>(q, tmq, tnq, grid.x, s); } \
+                            else if (pair) { if (epi) launch_plain_<A_, B_, true, true>(q, tmq, tnq, grid.x, s); else launch_plain_<A_, B_, false, true>(q, tmq, tnq, grid.x, s); } \
+                            else if (epi) launch_plain_<A_, B_, true>(q, tmq, tnq, grid.x, s); else launch_plain_<A_, B_, false>(q, tmq, tnq, grid.x, s); } while (0)
+    if (!tA && !tB) T4K_PL(true, false); else if (!tA) T4K_PL(true, true); else if (!tB) T4K_PL(false, false); else T4K_PL(false, true);
+#undef T4K_PL
 }
 
 template <int BK>
@@ -1101,22 +1278,26 @@ void launch_glds(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
     else            hipLaunchKernelGGL((k_gemm_glds<BK, false, true>),  grid, dim3(256), lds_bytes, s, p);
 }
 
-template <int BK>
-void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
+template <int BK, bool RAGK>
+void launch_glds8_(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)((BK >= 128) ? 2 : 3) * 128 * BK * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, true, false>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, true, true>),   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, false, true>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, true, false, false, RAGK>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, true, true, false, RAGK>),   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, false, false, false, RAGK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, false, true, false, RAGK>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_done = true;
     }
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm_glds8<BK, true,  false>), grid, dim3(512), lds_bytes, s, p);
-    else if (!tA)   hipLaunchKernelGGL((k_gemm_glds8<BK, true,  true>),  grid, dim3(512), lds_bytes, s, p);
-    else if (!tB)   hipLaunchKernelGGL((k_gemm_glds8<BK, false, false>), grid, dim3(512), lds_bytes, s, p);
-    else            hipLaunchKernelGGL((k_gemm_glds8<BK, false, true>),  grid, dim3(512), lds_bytes, s, p);
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm_glds8<BK, true,  false, false, RAGK>), grid, dim3(512), lds_bytes, s, p);
+    else if (!tA)   hipLaunchKernelGGL((k_gemm_glds8<BK, true,  true,  false, RAGK>), grid, dim3(512), lds_bytes, s, p);
+    else if (!tB)   hipLaunchKernelGGL((k_gemm_glds8<BK, false, false, false, RAGK>), grid, dim3(512), lds_bytes, s, p);
+    else            hipLaunchKernelGGL((k_gemm_glds8<BK, false, true,  false, RAGK>), grid, dim3(512), lds_bytes, s, p);
 }
+template <int BK>
+void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) { launch_glds8_<BK, false>(p, grid, tA, tB, s); }
+template <int BK>
+void launch_glds8_ragk(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) { launch_glds8_<BK, true>(p, grid, tA, tB, s); }   // K with a partial last stage
 
 // fold split-K slabs in slice order, then the alpha/beta epilogue (reference t4math.cu:580)
 // Optional activation epilogue (the layer that follows a linear layer: relu / tanh / ... / dropout): O keeps the linear
@@ -1197,6 +1378,7 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
 }
 
 struct ColSum { const float *X; float *out; int rows, E; bool done; };
+bool plain_any_big() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_PLAIN_ANY"); v = e ? atoi(e) : 2; } return v >= 2; }   // 0 off, 1 one-tile-per-CU shapes only, 2 (default) large ones too
 bool big_dma() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_BIG_DMA"); v = e ? atoi(e) : 1; } return v != 0; }
 bool capturing(hipStream_t hs) { hipStreamCaptureStatus st_ = hipStreamCaptureStatusNone; return hipStreamIsCapturing(hs, &st_) == hipSuccess && st_ != hipStreamCaptureStatusNone; }   // a replayed graph would repeat the epoch argument
 bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0; }
@@ -1348,6 +1530,20 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             return T4K_OK;
         }
     }
+    {   // 65..128 interior tiles, K in whole 256s: two workgroups per tile on the lean kernel, combined in its epilogue (k_gemm_nn_plain<.., PAIR>) -
+        // 512 x 1024 x 1024: one launch instead of split-K slabs + a fold launch.  Tickets are per tile: default stream only.
+        static int ppair = -1; if (ppair < 0) { const char *e = getenv("T4K_GEMM_PLAIN_PAIR"); ppair = e ? atoi(e) : 1; }
+        const int var0 = gemm_variant();
+        if (ppair && !big && vec && C == 1 && (var0 & 4) && (var0 & 16) && (var0 & 32) && !(var0 & 64) && M % 64 == 0 && N % 64 == 0 && K % 256 == 0 && K >= 512 &&
+            tiles * 2 <= st().cu_count && tiles * 3 > st().cu_count && tiles <= 2048 && !defer && !(epi && epi->layer) && !rider && !cs &&
+            st().d_sync && lane_of(S(s)) == 0 && (size_t)tiles * 4096 * sizeof(float) <= st().ws_bytes / 2 &&
+            (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
+            p.sync = st().d_sync; p.pair = 0; p.nsplit = 1; p.kchunk = K;
+            launch_plain_any(p, dim3((unsigned)tiles), tA, tB, S(s), true);
+            T4K_LAUNCH_CHECK();
+            return T4K_OK;
+        }
+    }
     // split K when the output alone cannot fill the chip (granularity = the deepest stage, 64)
     constexpr int KG = 64;
     int nsplit = 1, kchunk = ((K + KG - 1) / KG) * KG; if (kchunk == 0) kchunk = KG;
@@ -1379,19 +1575,37 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     const bool ragged8 = rag && !big && vec && C == 1 && nsplit == 1 && !p.pair && (var & 4) && (var & 16) && (M % 64 != 0 || N % 64 != 0) &&
                          kchunk % 64 == 0 && K % kchunk == 0 && M >= 4 && N >= 4 &&
                          (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);
+    // ragged K (784 = 28 x 28, the GAN layer width; any K when no operand is K-contiguous): the same kernel with a partial last stage
+    // (k_gemm_glds8<.., RAGK>) instead of the predicated register-staged one (1024 x 1024 x 784: 28.5 us there).  T4K_GEMM_RAGGED_K: 0 off,
+    // 1 unsplit products (default), 2 split-K slabs too
+    static int ragk_on = -1; if (ragk_on < 0) { const char *e = getenv("T4K_GEMM_RAGGED_K"); ragk_on = e ? atoi(e) : 1; }
+    const bool ragk = ragk_on && !big && vec && C == 1 && !p.pair && (var & 4) && (var & 16) && !(kchunk % 64 == 0 && K % kchunk == 0) &&
+                      (nsplit == 1 || ragk_on >= 2) && M >= 4 && N >= 4 && K >= 8 &&
+                      (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);
     p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
     {   // column-sum rider: only the generic kernel carries it, and only when one workgroup per tile writes the output
         const bool full64 = !big && vec && M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
-        const bool generic = big || !vec || !((full64 || ragged8) && (var & 4));
+        const bool generic = big || !vec || !((full64 || ragged8 || ragk) && (var & 4));
         if (cs && generic && nsplit == 1 && C == 1 && cs->rows > 0 && cs->rows <= 4096 && cs->E > 0) {
             p.cs_X = cs->X; p.cs_out = cs->out; p.cs_rows = cs->rows; p.cs_E = cs->E; cs->done = true;
             grid.x += (unsigned)((cs->E + 63) / 64);
         }
     }
     static int plain_big = -1; if (plain_big < 0) { const char *e = getenv("T4K_GEMM_PLAIN_BIG"); plain_big = e ? atoi(e) : 1; }
+    // interior tiles, unsplit, K >= 128 with a partial last stage: the lean kernel with a tail (any size of output)
+    static int pragk = -1; if (pragk < 0) { const char *e = getenv("T4K_GEMM_PLAIN_RAGK"); pragk = e ? atoi(e) : 2; }   // 0 off (the general kernel's tail), 1 only K % 64 != 0, 2 (default) every K % 128 != 0 (K = 960: 18.9 vs 19.6 us on the 64-deep general kernel)
+    if (pragk && ragk_on && vec && C == 1 && nsplit == 1 && !p.pair && !p.cs_X && (var & 4) && (var & 16) && (var & 32) && !(var & 64) && M % 64 == 0 && N % 64 == 0 &&
+        K > 128 && K % 128 != 0 && (pragk >= 2 || K % 64 != 0) &&
+        (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
+        p.kchunk = K;
+        launch_plain_any(p, dim3((unsigned)((M / 64) * (N / 64))), tA, tB, hs, false, true);
+    } else
     if (big && plain_big && vec && C == 1 && !tA && !tB && alpha == 1.0f && beta == 0.0f && !bias && !p.cs_X && M % 64 == 0 && N % 64 == 0 && K % 128 == 0 &&
         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
         launch_nn_plain(p, dim3((unsigned)((M / 64) * (N / 64))), hs);      // large plain products on the 64x64 LDS-DMA kernel, several tiles per CU
+    } else if (big && plain_any_big() && vec && C == 1 && !p.cs_X && M % 64 == 0 && N % 64 == 0 && K % 128 == 0 && nsplit == 1 &&
+               (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
+        launch_plain_any(p, dim3((unsigned)((M / 64) * (N / 64))), tA, tB, hs);      // large interior products of every layout on the lean kernel (2048^2 x 1024 linear + bias: 86 -> 72 us vs the 128x128 register-staged kernel)
     } else if (big && big_dma() && vec && C == 1 && !p.cs_X && K % 64 == 0 && K >= 2048 && M >= 4 && N >= 4 && nsplit == 1 &&   // deep K only: at K = 1024 the 128x128 kernel's fewer, fatter tiles win (292 vs 318 us at 4096 x 4096 x 1024)
                (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
         // every other large product (transposed operands, alpha / beta / bias: the linear layers of an MLP) on the 8-wave LDS-DMA kernel too,
@@ -1410,12 +1624,16 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
         launch_variant<64, 64, 32, false, false, false>(p, grid, tA, tB, hs);
     } else {
         const bool full = M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
-        if (ragged8) {
+        if (ragk) {
+            if ((var & 32) && K >= 128 && (nsplit == 1 || kchunk % 128 == 0)) launch_glds8_ragk<128>(p, grid, tA, tB, hs); else launch_glds8_ragk<64>(p, grid, tA, tB, hs);
+        } else if (ragged8) {
             if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs); else launch_glds8<64>(p, grid, tA, tB, hs);
         } else if (full && (var & 4)) {
             const bool span32 = (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);   // 32-bit DMA lane offsets
             if ((var & 16) && !p.pair && span32) {
+                static int plany = -1; if (plany < 0) { const char *e = getenv("T4K_GEMM_PLAIN_ANY"); plany = e ? atoi(e) : 1; }
                 if ((var & 32) && kchunk % 128 == 0 && !tA && !tB && nsplit == 1 && alpha == 1.0f && beta == 0.0f && !bias && !(var & 64)) launch_nn_plain(p, grid, hs);   // `matmul`
+                else if (plany && (var & 32) && kchunk % 128 == 0 && nsplit == 1 && !(var & 64)) launch_plain_any(p, grid, tA, tB, hs);   // the other layouts, alpha / beta / bias: the same lean kernel
                 else if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs);   // bit5: 128-deep stages, 2 buffers
                 else if (var & 1) launch_glds8<64>(p, grid, tA, tB, hs); else launch_glds8<32>(p, grid, tA, tB, hs);
             }

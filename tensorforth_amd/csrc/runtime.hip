@@ -66,6 +66,7 @@ int t4k_init(int device) {
         T4K_HIP(hipMalloc(&g.ws, g.ws_bytes));
         T4K_HIP(hipMemsetAsync(g.ws, 0, g.ws_bytes, g.stream));
     }
+    if (!g.d_zero) { T4K_HIP(hipMalloc((void **)&g.d_zero, 4096)); T4K_HIP(hipMemset(g.d_zero, 0, 4096)); }
     if (!g.d_sync) { T4K_HIP(hipMalloc((void **)&g.d_sync, 32768 * sizeof(int))); T4K_HIP(hipMemset(g.d_sync, 0, 32768 * sizeof(int))); }
     if (!g.spin_err) {                                  // error word of the bounded inter-workgroup waits: pinned host memory the kernels can write
         T4K_HIP(hipHostMalloc((void **)&g.spin_err, 64, hipHostMallocMapped)); *g.spin_err = 0;

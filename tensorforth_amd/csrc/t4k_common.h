@@ -34,6 +34,7 @@ struct State {
     bool        capturing = false;
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
+    float      *d_zero  = nullptr;     // 4 KiB of zeros, never written: the source of LDS-DMA lanes whose operand row lies outside the tensor (conv_big.hip)
     int        *d_sync  = nullptr;     // 32768 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags, [8192,32768) per-stream arrival gates (gate_for / flags_for; ints [512,1024) of a stream's block are the epoch slots of k_gemm_dual32)
     int        *spin_err = nullptr;   // pinned, device-visible error word of the inter-workgroup waits (spin_check)
     int         cu_count = 256;

@@ -1068,7 +1068,16 @@ def test_gemm_large_plain_products_exact_on_integer_operands(t4k, dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,tA,tB", [(1024, 1000, 512, 0, 0), (1000, 1028, 256, 0, 1), (996, 1000, 384, 1, 0), (516, 2044, 128, 1, 1),
-                                         (40, 72, 64, 0, 1), (200, 100, 832, 0, 1), (36, 28, 96, 1, 0)])
+                                         (40, 72, 64, 0, 1), (200, 100, 832, 0, 1), (36, 28, 96, 1, 0),
+                                         # ragged K on the LDS-DMA kernel (partial last stage): 784 = 6 x 128 + 16, every layout; a tail of 4 (half a
+                                         # chunk: zeroed in registers); K below one stage; K % 4 != 0 where no operand is K-contiguous; ragged M, N and K
+                                         (1024, 1024, 784, 0, 0), (1024, 1024, 784, 0, 1), (1024, 1024, 784, 1, 0), (1024, 1024, 784, 1, 1),
+                                         (1024, 1024, 132, 0, 1), (1024, 1024, 100, 0, 0), (1024, 1088, 50, 1, 0), (1024, 1024, 1021, 1, 0),
+                                         (1000, 1028, 1004, 0, 1), (1028, 1000, 252, 1, 1), (1024, 1024, 8, 0, 1), (1024, 1024, 12, 0, 0),
+                                         # 65..128 tiles, K in 256s: two workgroups per tile, combined in the epilogue (k_gemm_nn_plain<.., PAIR>)
+                                         (512, 1024, 1024, 0, 0), (512, 1024, 1024, 0, 1), (1024, 512, 512, 1, 0), (576, 832, 768, 1, 1),
+                                         # interior tiles, every layout, on the lean kernel (one tile per CU and several)
+                                         (1024, 1024, 1024, 0, 1), (1024, 1024, 512, 1, 0), (1024, 1024, 256, 1, 1), (1088, 1024, 384, 0, 1)])
 def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N, K, tA, tB):
     """Ragged M / N (not multiples of the tile) on the LDS-DMA kernel with clamped source rows, and sliver shapes on the 32x32
     register-fetch kernel, every operand layout: entries in {-2..2} keep fp32 sums exact, so the product must equal numpy's bit for bit
@@ -1081,6 +1090,8 @@ def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N,
     dO = dev.up(O0)
     t4k.call("t4k_gemm", p(dA), p(dB), p(dO), 2.0, -1.0, tA, tB, M, N, K, 1, None)        # alpha, beta exact in fp32 too
     assert np.array_equal(dev.down(dO), 2.0 * want - O0)
+    t4k.call("t4k_gemm", p(dA), p(dB), p(dO), 1.0, 0.0, tA, tB, M, N, K, 1, None)         # again, no epilogue (tickets / flags of a paired launch were left clean)
+    assert np.array_equal(dev.down(dO), want)
 
 
 @pytest.mark.parametrize("M,N,K,tA,tB", [(2048, 2048, 2048, 0, 1), (1024, 4096, 2048, 1, 0), (2040, 2048, 2112, 1, 1)])
