@@ -269,9 +269,9 @@ __global__ void __launch_bounds__(256) k_convbig_df(CdP p) {
 // 16 bytes: row k of the A stage is the input pixel under tap (ky, kx) of output pixel k - each lane keeps the (n, y, x) of its rows and
 // advances them by BKP pixels per stage without divisions - and rows outside the image / past the slice / channel groups past C1, C0
 // read from a 4 KiB page of zeros (State::d_zero), so the LDS stage needs no zero fill and the MFMA loop no predicates.
-struct Cd8 { const float *I, *DO, *Z; float *part; int N, H1, W1, C1, H0, W0, C0; int pix_per_slice, ci_tiles; long npix; };
+struct Cd8 { const float *I, *DO, *Z; float *part; int N, H1, W1, C1, H0, W0, C0; int pix_per_slice, ci_tiles; long npix; int dbg; int nslice, ctiles; };
 
-template <int K, int S, int P, int BKP>
+template <int K, int S, int P, int BKP, int NST = 2>     // NST stage buffers: the DMA runs NST - 1 stages ahead of the MFMAs
 __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     constexpr int BM = 64, BN = 64, KK = K * K;
     constexpr int NCH = BKP / 8, NCG = NCH / 2;            // 8-deep chunks per stage, per k-group
@@ -282,41 +282,59 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = w >> 2, w4 = w & 3, wm = w4 >> 1, wn = w4 & 1, h = lane >> 5, l31 = lane & 31;
     const int c0 = kg * NCG;
-    const int tap = blockIdx.y / p.ci_tiles, cit = blockIdx.y - tap * p.ci_tiles;
+    // 1-D grid, XCD-aware: workgroup id % 8 is the XCD it runs on.  The K*K taps of one (pixel slice, ci tile, co tile) group re-read the same
+    // dO rows and overlapping input rows, so a group's workgroups are consecutive ON ONE XCD (its L2 serves 8 of the 9 reads) and the groups
+    // are dealt round-robin to the XCDs - any slice count balances, not only multiples of 8.
+    const int wg = blockIdx.x, xcd = wg & 7, jx = wg >> 3;
+    const int grp = xcd + 8 * (jx / KK), tap = jx % KK;
+    const int slice = grp / p.ctiles, tl = grp - slice * p.ctiles;
+    if (slice >= p.nslice) return;
+    const int cit = tl % p.ci_tiles, cot = tl / p.ci_tiles;
     const int ky = tap / K, kx = tap - ky * K;
-    const int m0 = cit * BM, n0 = blockIdx.z * BN;          // ci0, co0
-    const long k_beg = (long)blockIdx.x * p.pix_per_slice, k_end = min(p.npix, k_beg + p.pix_per_slice);
+    const int m0 = cit * BM, n0 = cot * BN;                 // ci0, co0
+    const long k_beg = (long)slice * p.pix_per_slice, k_end = min(p.npix, k_beg + p.pix_per_slice);
     const int nst = k_end > k_beg ? (int)((k_end - k_beg + BKP - 1) / BKP) : 0;
 
-    // this lane's rows of a stage: kk = (w * NJ + j) * 4 + lane / 16, its 16-byte channel group ch = lane % 16
+    // this lane's rows of a stage: kk = (w * NJ + j) * 4 + lane / 16, its 16-byte channel group ch = lane % 16.
+    // The address work per stage is kept small (it competes with the MFMAs for the SIMD's issue slot: 100 VALU instructions per stage
+    // cost ~10 %): both row pointers ADVANCE by a constant per stage - dO is linear in the pixel index, and so is the input under a
+    // stride-1 same-size tap (LIN: address = (pixel + (ky-P) W + kx-P) C1, only its validity needs (y, x)) - a stride-2 tap recomputes.
+    constexpr bool LIN = S == 1;
     const int ch = lane & 15;
     const bool a_col = m0 + ch * 4 < p.C1, b_col = n0 + ch * 4 < p.C0;
-    int cx[NJ], cy[NJ], cn[NJ]; long cp[NJ];
+    int cx[NJ], cy[NJ], cn[NJ], left[NJ];
+    int oa[NJ], ob[NJ];                                     // row offsets from I / dO in 16-byte units (64-bit pointer arrays ended up in scratch)
+    const v4f *zsrc = reinterpret_cast<const v4f *>(p.Z) + ch;
+    const v4f *I4 = reinterpret_cast<const v4f *>(p.I), *DO4 = reinterpret_cast<const v4f *>(p.DO);
+    const int C14 = p.C1 >> 2, C04 = p.C0 >> 2;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const long pix = k_beg + (w * NJ + j) * 4 + (lane >> 4);
-        cp[j] = pix; cx[j] = (int)(pix % p.W0); const long t = pix / p.W0; cy[j] = (int)(t % p.H0); cn[j] = (int)(t / p.H0);
+        left[j] = (int)min((long)(1 << 30), k_end - pix);          // > 0: the row lies inside the slice
+        cx[j] = (int)(pix % p.W0); const long t = pix / p.W0; cy[j] = (int)(t % p.H0); cn[j] = (int)(t / p.H0);
+        ob[j] = (int)(pix * C04 + (n0 >> 2) + ch);
+        oa[j] = LIN ? (int)((pix + (long)(ky - P) * p.W1 + (kx - P)) * C14 + (m0 >> 2) + ch) : (m0 >> 2) + ch;
     }
     const int dxs = BKP % p.W0, dys = BKP / p.W0, dyr = dys % p.H0, dns = dys / p.H0;
-    const float *zsrc = p.Z + ch * 4;
-    const float *abase = p.I + m0 + ch * 4, *bbase = p.DO + n0 + ch * 4;
+    const int stepA = (p.dbg & 1) ? 0 : BKP * C14, stepB = (p.dbg & 1) ? 0 : BKP * C04;   // dbg bit 0 (lab only, T4K_CONVBIG_DF8_DBG): re-read the first stage's rows - the kernel without its HBM stream
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
-    // issue the DMA of the stage the coordinates stand at, then advance them one stage
+    // issue the DMA of the stage the row state stands at, then advance it one stage
     auto issue = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int gi = cy[j] * S + ky - P, gj = cx[j] * S + kx - P;
-            const bool in = cp[j] < k_end;
-            const bool oka = in && a_col && gi >= 0 && gi < p.H1 && gj >= 0 && gj < p.W1;
-            const float *pa = oka ? abase + (((long)cn[j] * p.H1 + gi) * p.W1 + gj) * p.C1 : zsrc;
-            const float *pb = (in && b_col) ? bbase + cp[j] * p.C0 : zsrc;
+            const bool in = left[j] > 0;
+            const bool oka = in && a_col && (unsigned)gi < (unsigned)p.H1 && (unsigned)gj < (unsigned)p.W1;
+            const v4f *qa = I4 + (LIN ? (long)oa[j] : (long)oa[j] + (((long)cn[j] * p.H1 + gi) * p.W1 + gj) * C14);
+            const v4f *sa = oka ? qa : zsrc;
+            const v4f *sb = (in && b_col) ? DO4 + (long)ob[j] : zsrc;
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(pa), "s"(la) : "memory");
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(pb), "s"(la + BM * BKP * 4) : "memory");
-            cp[j] += BKP;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sa), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sb), "s"(la + BM * BKP * 4) : "memory");
+            left[j] -= BKP; ob[j] += stepB; if (LIN) oa[j] += stepA;
             cx[j] += dxs; const int c1 = cx[j] >= p.W0 ? 1 : 0; cx[j] -= c1 ? p.W0 : 0;
             cy[j] += dyr + c1; const int c2 = cy[j] >= p.H0 ? 1 : 0; cy[j] -= c2 ? p.H0 : 0;
-            cn[j] += dns + c2;
+            if (!LIN) cn[j] += dns + c2;
         }
     };
     f32x16 acc0, acc1;
@@ -336,16 +354,28 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
         __builtin_amdgcn_sched_barrier(0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
     };
+    // next stage landed (this wave's share; the barrier makes it everybody's), up to NST - 2 later ones may still fly: each stage is
+    // exactly 2 * NJ DMA instructions of this wave
+    auto wait_next = [&](int flying) __attribute__((always_inline)) {
+        constexpr int NPW = 2 * NJ;
+        if (NST >= 4 && flying >= 2) { if (NPW == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else if (NPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); }
+        else if (NST >= 3 && flying >= 1) { if (NPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else if (NPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    constexpr int AHEAD = NST >= 4 ? 3 : NST - 1;          // stages in flight beyond the one being multiplied (vmcnt immediates cover up to 2 flying after the wait)
     float ca[4], cb[4];
     if (nst > 0) {
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < AHEAD; a++) if (a < nst) issue(a);
+        wait_next(min(nst, AHEAD) - 1);
         rd(lds, lds + BM * BKP, c0, ca, cb);
     }
     int buf = 0;
     for (int kt = 0; kt < nst; kt++) {
-        const int b1 = buf ^ 1;
-        if (kt + 1 < nst) issue(b1);
+        int b1 = buf + 1; if (b1 >= NST) b1 -= NST;
+        int bi = buf + AHEAD; if (bi >= NST) bi -= NST;      // the buffer read in stage kt - 1 when AHEAD == NST - 1; a free one otherwise
+        if (kt + AHEAD < nst) issue(bi);
         const float *a = lds + buf * STAGE, *b = a + BM * BKP;
 #pragma unroll
         for (int ci = 0; ci + 1 < NCG; ci++) {
@@ -357,7 +387,7 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
 #pragma unroll
             for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        wait_next(min(nst - kt - 1, AHEAD) - 1);              // stages issued and not yet awaited, minus the one needed now
         float na[4], nbv[4];
         if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BKP, c0, na, nbv);
         __builtin_amdgcn_sched_barrier(0);
@@ -383,7 +413,7 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     for (int r = 0; r < 16; r++) {
         const int ci = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = (acc0[r] + acc1[r]) + lds[(w4 * 16 + r) * 64 + lane];
-        if (co < p.C0 && ci < p.C1) p.part[((long)blockIdx.x * nrow + ((long)ci * KK + tap)) * p.C0 + co] = v;
+        if (co < p.C0 && ci < p.C1) p.part[((long)slice * nrow + ((long)ci * KK + tap)) * p.C0 + co] = v;
     }
 }
 
@@ -436,23 +466,27 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
     static int x8 = -1; if (x8 < 0) { const char *e = getenv("T4K_DF_XCD"); x8 = e ? atoi(e) : 1; }
     if (x8 && nslice >= 8) { nslice = (nslice + 7) / 8 * 8; pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; }
     static int df8 = -1; if (df8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8"); df8 = e ? atoi(e) : 64; }     // 0: the 4-wave register-staged kernel; 64 / 128: pixels per stage of the 8-wave LDS-DMA kernel
-    if (df8 && npix < (1L << 31) && st().d_zero) {
+    if (df8 && npix * (C0 > C1 ? C0 : C1) / 4 + (long)4 * W1 * C1 < (1L << 31) && st().d_zero) {      // row offsets are ints in 16-byte units
         // 64-pixel stages: 64 KiB of LDS, two workgroups per CU (one's barrier under the other's MFMAs) -> up to 2 x CUs workgroups at once, all resident
         const int bkp = df8 >= 128 ? 128 : df8 >= 64 ? 64 : 32;
         static int wpc8 = -1; if (wpc8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8_WPC"); wpc8 = e ? atoi(e) : 0; }
-        const long slots = (long)st().cu_count * (wpc8 > 0 ? wpc8 : bkp == 128 ? 1 : bkp == 64 ? 2 : 3);
+        static int nstb = -1; if (nstb < 0) { const char *e = getenv("T4K_CONVBIG_DF8_NST"); nstb = e ? atoi(e) : (bkp == 32 ? 4 : 2); }
+        const int lds_kb = (bkp == 128 ? 2 : bkp == 64 ? (nstb == 3 ? 3 : 2) : (nstb >= 5 ? 5 : nstb == 4 ? 4 : 3)) * 128 * bkp * 4 / 1024;
+        const long slots = (long)st().cu_count * (wpc8 > 0 ? wpc8 : std::max(1, std::min(160 / lds_kb, 3)));
         long ns = slots / tiles; if (ns < 1) ns = 1;
-        if (x8 && ns >= 8) ns = ns / 8 * 8;                  // every tap / channel tile of one pixel slice on the same XCD (see above)
         long pp = (npix + ns - 1) / ns; pp = (pp + bkp - 1) / bkp * bkp; if (pp < 4 * bkp) pp = 4 * bkp;
         ns = (npix + pp - 1) / pp;
         if ((size_t)ns * C1 * KK * C0 > part_floats) return 0;
-        Cd8 q = { I, DO, st().d_zero, part, N, H1, W1, C1, H0, W0, C0, (int)pp, ci_tiles, npix };
-        const dim3 g8((unsigned)ns, (unsigned)(KK * ci_tiles), (unsigned)co_tiles), b8(512);
-#define DF8(k, s, pd) do { if (bkp == 128) { static bool a1 = false; const int lb = 2 * 128 * 128 * 4; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_df8<k, s, pd, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); a1 = true; } \
-                                             hipLaunchKernelGGL((k_convbig_df8<k, s, pd, 128>), g8, b8, lb, hs, q); } \
-                           else if (bkp == 32) hipLaunchKernelGGL((k_convbig_df8<k, s, pd, 32>), g8, b8, 2 * 128 * 32 * 4, hs, q); \
-                           else { static bool a2 = false; const int lb = 2 * 128 * 64 * 4; if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_df8<k, s, pd, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); a2 = true; } \
-                                  hipLaunchKernelGGL((k_convbig_df8<k, s, pd, 64>), g8, b8, lb, hs, q); } } while (0)
+        static int dbg8 = -1; if (dbg8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8_DBG"); dbg8 = e ? atoi(e) : 0; }
+        const int ctl = ci_tiles * co_tiles;
+        Cd8 q = { I, DO, st().d_zero, part, N, H1, W1, C1, H0, W0, C0, (int)pp, ci_tiles, npix, dbg8, (int)ns, ctl };
+        const long groups = ns * ctl;
+        const dim3 g8((unsigned)(8 * KK * ((groups + 7) / 8))), b8(512);
+#define DF8_(k, s, pd, bk, ns_) do { static bool a1 = false; const int lb = ns_ * 128 * bk * 4; \
+            if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_df8<k, s, pd, bk, ns_>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); a1 = true; } \
+            hipLaunchKernelGGL((k_convbig_df8<k, s, pd, bk, ns_>), g8, b8, lb, hs, q); } while (0)
+#define DF8(k, s, pd) do { if (bkp == 128) DF8_(k, s, pd, 128, 2); else if (bkp == 64 && nstb == 3) DF8_(k, s, pd, 64, 3); else if (bkp == 64) DF8_(k, s, pd, 64, 2); \
+                           else if (nstb >= 5) DF8_(k, s, pd, 32, 5); else if (nstb == 4) DF8_(k, s, pd, 32, 4); else DF8_(k, s, pd, 32, 3); } while (0)
         switch ((K << 8) | (S << 4) | P) {
         case 0x110: DF8(1, 1, 0); break;
         case 0x311: DF8(3, 1, 1); break;
@@ -460,6 +494,7 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
         case 0x512: DF8(5, 1, 2); break;
         }
 #undef DF8
+#undef DF8_
         return (int)ns;
     }
     if ((size_t)nslice * C1 * KK * C0 > part_floats) return 0;

@@ -13,7 +13,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  rocprofv3 --kernel-trace --stats -d "$O/s$i" -o g -- python "$R/tools/experiments/gemm_one.py" $line > "$O/s$i.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d "$O/s$i" -o g -- python "$R/tools/experiments/gemm_one.py" $line > "$O/s$i.log" 2>&1
   DB=$(find "$O/s$i" -name '*.db' | head -1)
   python - "$line" "$DB" >> "$OUT" <<'PY'
 import re, sqlite3, sys
