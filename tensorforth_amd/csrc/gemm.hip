@@ -1261,6 +1261,171 @@ void launch_plain_any(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s, 
 #undef T4K_PL
 }
 
+// Large outputs (>= ~3/4 of the CUs in 128x128 tiles): the lean pipeline on a 128x128 tile.  Same 8 waves = 2 k-groups x 2x2 waves, but every
+// wave owns a 64x64 block (2x2 accumulators of 32x32): one A fragment feeds two MFMAs and so does one B fragment - half the LDS reads and half
+// the L2 -> LDS bytes per MFMA of the 64x64 tile, which is what limits that kernel once the fixed costs are amortised (2048^3: 80 %).
+// 64-deep double-buffered stages (64 KiB each).  Interior tiles, K % 64 == 0, unsplit; layouts and epilogue as k_gemm_nn_plain.
+template <bool AKC, bool BKC, bool EPI>
+__global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
+    constexpr int BM = 128, BN = 128, BK = 64;
+    constexpr int NC = BK / 8, CH = BK / 4, NCG = NC / 2;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int NJ = (BM * BK / 256) / 8;                // 1-KiB DMA instructions per operand per wave per stage (4)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = w >> 2, w4 = w & 3, wm = w4 >> 1, wn = w4 & 1, h = lane >> 5, l31 = lane & 31;
+    const int c0 = kg * NCG;
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = M / BM, tiles_n = N / BN, T = tiles_m * tiles_n;
+    int tm, tn;
+    {
+        int L;
+        { const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
+          L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; }           // XCD x owns a contiguous run of the tile order
+        constexpr int GROUP_M = 4;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = L / per_group, first_m = grp * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        tm = first_m + (L % per_group) % gsz; tn = (L % per_group) / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN, nst = K / BK;
+    unsigned voffA[NJ], voffB[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int i = w * NJ + j;
+        if (AKC) { const int r = i * 4 + (lane >> 4), q = (lane & 15) ^ (r & (CH - 1)); voffA[j] = (unsigned)((m0 + r) * K + q * 4) * 4u; }
+        else     { const int kk = i * 2 + (lane >> 5);                                  voffA[j] = (unsigned)(kk * M + m0 + (lane & 31) * 4) * 4u; }
+        if (BKC) { const int r = i * 4 + (lane >> 4), q = (lane & 15) ^ (r & (CH - 1)); voffB[j] = (unsigned)((n0 + r) * K + q * 4) * 4u; }
+        else     { const int kk = i * 2 + (lane >> 5);                                  voffB[j] = (unsigned)(kk * N + n0 + (lane & 31) * 4) * 4u; }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        const float *ba = p.A + (AKC ? (long)kt * BK : (long)kt * BK * M), *bb = p.B + (BKC ? (long)kt * BK : (long)kt * BK * N);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    const int ra_ = wm * 64 + l31, rb_ = wn * 64 + l31;
+    auto rd = [&](const float *a, const float *b, int ci, float (&av)[2][4], float (&bv)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int ra = ra_ + t * 32, rb = rb_ + t * 32;
+            if (AKC) { const v4f v = *reinterpret_cast<const v4f *>(a + ra * BK + (((ci * 2 + h) ^ (ra & (CH - 1))) << 2));
+                       av[t][0] = v[0]; av[t][1] = v[1]; av[t][2] = v[2]; av[t][3] = v[3]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) av[t][j] = a[(ci * 8 + 4 * h + j) * BM + ra];
+            }
+            if (BKC) { const v4f v = *reinterpret_cast<const v4f *>(b + rb * BK + (((ci * 2 + h) ^ (rb & (CH - 1))) << 2));
+                       bv[t][0] = v[0]; bv[t][1] = v[1]; bv[t][2] = v[2]; bv[t][3] = v[3]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) bv[t][j] = b[(ci * 8 + 4 * h + j) * BN + rb];
+            }
+        }
+    };
+    auto mm = [&](float (&av)[2][4], float (&bv)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                       // four independent accumulators per k step: no MFMA waits on its predecessor
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j], bv[0][j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j], bv[1][j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j], bv[0][j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j], bv[1][j], acc[1][1], 0, 0, 0);
+        }
+    };
+    float ca[2][4], cb[2][4];
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    rd(lds, lds + BM * BK, c0, ca, cb);
+    int buf = 0;
+    for (int kt = 0; kt < nst; kt++) {
+        const int b1 = buf ^ 1;
+        if (kt + 1 < nst) issue(kt + 1, b1);
+        const float *a = lds + buf * STAGE, *b = a + BM * BK;
+#pragma unroll
+        for (int ci = 0; ci + 1 < NCG; ci++) {
+            float na[2][4], nbv[2][4];
+            rd(a, b, c0 + ci + 1, na, nbv);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) { ca[t][j] = na[t][j]; cb[t][j] = nbv[t][j]; }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float na[2][4], nbv[2][4];
+        if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, c0, na, nbv);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ca, cb);
+        if (kt + 1 < nst) {
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) { ca[t][j] = na[t][j]; cb[t][j] = nbv[t][j]; }
+        }
+        buf = b1;
+    }
+    // the two k-groups meet in LDS (64 KiB: 4 waves x 64 accumulator registers x 64 lanes), group 0 stores
+    __syncthreads();
+    if (kg == 1) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) lds[((w4 * 4 + a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+    const float alpha = EPI ? p.alpha : 1.f, beta = EPI ? p.beta : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int gn = n0 + wn * 64 + b * 32 + l31;
+            const float bsv = (EPI && p.bias) ? p.bias[gn] : 0.f;
+            float old[16];
+            if (EPI && beta != 0.f) {                        // all 16 loads of the block in flight before the first store (a store ahead of a may-alias load serialises them)
+#pragma unroll
+                for (int r = 0; r < 16; r++) old[r] = p.O[(long)(m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + gn];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int gm = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float o = acc[a][b][r] + lds[((w4 * 4 + a * 2 + b) * 16 + r) * 64 + lane];
+                if (EPI) { o *= alpha; if (beta != 0.f) o += old[r] * beta; o += bsv; }
+                __builtin_nontemporal_store(o, &p.O[(long)gm * N + gn]);
+            }
+        }
+}
+template <bool AKC, bool BKC, bool EPI>
+void launch_plain128_(const PlainP &q, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)2 * 256 * 64 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain128<AKC, BKC, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
+    hipLaunchKernelGGL((k_gemm_plain128<AKC, BKC, EPI>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
+}
+void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
+    PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, nullptr, nullptr };
+    const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias;
+#define T4K_PL(A_, B_) do { if (epi) launch_plain128_<A_, B_, true>(q, s); else launch_plain128_<A_, B_, false>(q, s); } while (0)
+    if (!tA && !tB) T4K_PL(true, false); else if (!tA) T4K_PL(true, true); else if (!tB) T4K_PL(false, false); else T4K_PL(false, true);
+#undef T4K_PL
+}
+
 template <int BK>
 void launch_glds(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)3 * 128 * BK * sizeof(float);
@@ -1594,6 +1759,17 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     static int plain_big = -1; if (plain_big < 0) { const char *e = getenv("T4K_GEMM_PLAIN_BIG"); plain_big = e ? atoi(e) : 1; }
     // interior tiles, unsplit, K >= 128 with a partial last stage: the lean kernel with a tail (any size of output)
     static int pragk = -1; if (pragk < 0) { const char *e = getenv("T4K_GEMM_PLAIN_RAGK"); pragk = e ? atoi(e) : 2; }   // 0 off (the general kernel's tail), 1 only K % 64 != 0, 2 (default) every K % 128 != 0 (K = 960: 18.9 vs 19.6 us on the 64-deep general kernel)
+    // T4K_GEMM_PLAIN128: 0 off, 1 (default) where it wins, 2 every eligible shape (tests).  A workgroup per CU at a time either way, so the
+    // choice is wave quantisation: tiles / (rounds x CUs) of each tiling, the 128x128 pipeline being ~3.5 % faster per FLOP (2048^3: 136 -> 131 us)
+    static int p128 = -1; if (p128 < 0) { const char *e = getenv("T4K_GEMM_PLAIN128"); p128 = e ? atoi(e) : 1; }
+    auto fill_of = [](long tiles_, long cu_) { return (double)tiles_ / (double)(((tiles_ + cu_ - 1) / cu_) * cu_); };
+    const long t128i = (long)(M / 128) * (N / 128), t64i = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (p128 > 0 && vec && C == 1 && nsplit == 1 && !p.pair && !p.cs_X && (var & 4) && (var & 16) && (var & 32) && !(var & 64) && M % 128 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 256 &&
+        (p128 >= 2 || (t128i >= st().cu_count && fill_of(t128i, st().cu_count) * 1.035 > fill_of(t64i, st().cu_count))) &&
+        (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
+        p.kchunk = K;
+        launch_plain128(p, tA, tB, hs);
+    } else
     if (pragk && ragk_on && vec && C == 1 && nsplit == 1 && !p.pair && !p.cs_X && (var & 4) && (var & 16) && (var & 32) && !(var & 64) && M % 64 == 0 && N % 64 == 0 &&
         K > 128 && K % 128 != 0 && (pragk >= 2 || K % 64 != 0) &&
         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
