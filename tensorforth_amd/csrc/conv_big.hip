@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) k_convbig_df(CdP p) {
 // 16 bytes: row k of the A stage is the input pixel under tap (ky, kx) of output pixel k - each lane keeps the (n, y, x) of its rows and
 // advances them by BKP pixels per stage without divisions - and rows outside the image / past the slice / channel groups past C1, C0
 // read from a 4 KiB page of zeros (State::d_zero), so the LDS stage needs no zero fill and the MFMA loop no predicates.
-struct Cd8 { const float *I, *DO, *Z; float *part; int N, H1, W1, C1, H0, W0, C0; int pix_per_slice, ci_tiles; long npix; int dbg; int nslice, ctiles; };
+struct Cd8 { const float *I, *DO, *Z; float *part; int N, H1, W1, C1, H0, W0, C0; int pix_per_slice, ci_tiles; long npix; int dbg; int nslice, ctiles; int tp2; };
 
 template <int K, int S, int P, int BKP, int NST = 2>     // NST stage buffers: the DMA runs NST - 1 stages ahead of the MFMAs
 __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
@@ -286,10 +286,15 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     // dO rows and overlapping input rows, so a group's workgroups are consecutive ON ONE XCD (its L2 serves 8 of the 9 reads) and the groups
     // are dealt round-robin to the XCDs - any slice count balances, not only multiples of 8.
     const int wg = blockIdx.x, xcd = wg & 7, jx = wg >> 3;
-    const int grp = xcd + 8 * (jx / KK), tap = jx % KK;
+    // tp2 (C1 == 32): a 64-row tile would be half empty, so it carries TWO taps - rows 0..31 the channels under tap 2 ts, rows 32..63 under
+    // tap 2 ts + 1 (the tap is then a per-lane value: DMA lanes 0..7 of a row fetch the first tap's channel groups, lanes 8..15 the second's)
+    const int kks = p.tp2 ? (KK + 1) / 2 : KK;
+    const int grp = xcd + 8 * (jx / kks), ts = jx % kks;
     const int slice = grp / p.ctiles, tl = grp - slice * p.ctiles;
     if (slice >= p.nslice) return;
     const int cit = tl % p.ci_tiles, cot = tl / p.ci_tiles;
+    const int ch = lane & 15;
+    const int tap = p.tp2 ? 2 * ts + (ch >> 3) : ts, ach = p.tp2 ? (ch & 7) : ch;     // this lane's tap and 16-byte channel group of the input row
     const int ky = tap / K, kx = tap - ky * K;
     const int m0 = cit * BM, n0 = cot * BN;                 // ci0, co0
     const long k_beg = (long)slice * p.pix_per_slice, k_end = min(p.npix, k_beg + p.pix_per_slice);
@@ -300,8 +305,7 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     // cost ~10 %): both row pointers ADVANCE by a constant per stage - dO is linear in the pixel index, and so is the input under a
     // stride-1 same-size tap (LIN: address = (pixel + (ky-P) W + kx-P) C1, only its validity needs (y, x)) - a stride-2 tap recomputes.
     constexpr bool LIN = S == 1;
-    const int ch = lane & 15;
-    const bool a_col = m0 + ch * 4 < p.C1, b_col = n0 + ch * 4 < p.C0;
+    const bool a_col = p.tp2 ? tap < KK : m0 + ch * 4 < p.C1, b_col = n0 + ch * 4 < p.C0;
     int cx[NJ], cy[NJ], cn[NJ], left[NJ];
     int oa[NJ], ob[NJ];                                     // row offsets from I / dO in 16-byte units (64-bit pointer arrays ended up in scratch)
     const v4f *zsrc = reinterpret_cast<const v4f *>(p.Z) + ch;
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
         left[j] = (int)min((long)(1 << 30), k_end - pix);          // > 0: the row lies inside the slice
         cx[j] = (int)(pix % p.W0); const long t = pix / p.W0; cy[j] = (int)(t % p.H0); cn[j] = (int)(t / p.H0);
         ob[j] = (int)(pix * C04 + (n0 >> 2) + ch);
-        oa[j] = LIN ? (int)((pix + (long)(ky - P) * p.W1 + (kx - P)) * C14 + (m0 >> 2) + ch) : (m0 >> 2) + ch;
+        oa[j] = LIN ? (int)((pix + (long)(ky - P) * p.W1 + (kx - P)) * C14 + (m0 >> 2) + ach) : (m0 >> 2) + ach;
     }
     const int dxs = BKP % p.W0, dys = BKP / p.W0, dyr = dys % p.H0, dns = dys / p.H0;
     const int stepA = (p.dbg & 1) ? 0 : BKP * C14, stepB = (p.dbg & 1) ? 0 : BKP * C04;   // dbg bit 0 (lab only, T4K_CONVBIG_DF8_DBG): re-read the first stage's rows - the kernel without its HBM stream
@@ -411,9 +415,10 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     const long nrow = (long)p.C1 * KK;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const int ci = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = p.tp2 ? (m & 31) : m0 + m, tp = p.tp2 ? 2 * ts + (m >> 5) : ts;
         const float v = (acc0[r] + acc1[r]) + lds[(w4 * 16 + r) * 64 + lane];
-        if (co < p.C0 && ci < p.C1) p.part[((long)slice * nrow + ((long)ci * KK + tap)) * p.C0 + co] = v;
+        if (co < p.C0 && ci < p.C1 && tp < KK) p.part[((long)slice * nrow + ((long)ci * KK + tp)) * p.C0 + co] = v;
     }
 }
 
@@ -473,15 +478,19 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
         static int nstb = -1; if (nstb < 0) { const char *e = getenv("T4K_CONVBIG_DF8_NST"); nstb = e ? atoi(e) : (bkp == 32 ? 4 : 2); }
         const int lds_kb = (bkp == 128 ? 2 : bkp == 64 ? (nstb == 3 ? 3 : 2) : (nstb >= 5 ? 5 : nstb == 4 ? 4 : 3)) * 128 * bkp * 4 / 1024;
         const long slots = (long)st().cu_count * (wpc8 > 0 ? wpc8 : std::max(1, std::min(160 / lds_kb, 3)));
-        long ns = slots / tiles; if (ns < 1) ns = 1;
+        static int tp2on = -1; if (tp2on < 0) { const char *e = getenv("T4K_CONVBIG_DF8_TP2"); tp2on = e ? atoi(e) : 1; }
+        const int tp2 = (tp2on && C1 == 32) ? 1 : 0;         // two taps per 64-row tile
+        const int kks = tp2 ? (KK + 1) / 2 : KK;
+        const int tiles8 = kks * ci_tiles * co_tiles;
+        long ns = slots / tiles8; if (ns < 1) ns = 1;
         long pp = (npix + ns - 1) / ns; pp = (pp + bkp - 1) / bkp * bkp; if (pp < 4 * bkp) pp = 4 * bkp;
         ns = (npix + pp - 1) / pp;
         if ((size_t)ns * C1 * KK * C0 > part_floats) return 0;
         static int dbg8 = -1; if (dbg8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8_DBG"); dbg8 = e ? atoi(e) : 0; }
         const int ctl = ci_tiles * co_tiles;
-        Cd8 q = { I, DO, st().d_zero, part, N, H1, W1, C1, H0, W0, C0, (int)pp, ci_tiles, npix, dbg8, (int)ns, ctl };
+        Cd8 q = { I, DO, st().d_zero, part, N, H1, W1, C1, H0, W0, C0, (int)pp, ci_tiles, npix, dbg8, (int)ns, ctl, tp2 };
         const long groups = ns * ctl;
-        const dim3 g8((unsigned)(8 * KK * ((groups + 7) / 8))), b8(512);
+        const dim3 g8((unsigned)(8 * kks * ((groups + 7) / 8))), b8(512);
 #define DF8_(k, s, pd, bk, ns_) do { static bool a1 = false; const int lb = ns_ * 128 * bk * 4; \
             if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_df8<k, s, pd, bk, ns_>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); a1 = true; } \
             hipLaunchKernelGGL((k_convbig_df8<k, s, pd, bk, ns_>), g8, b8, lb, hs, q); } while (0)

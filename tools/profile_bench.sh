@@ -9,10 +9,10 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$O/bench.json" 2> "$O/bench.err"
 B="python $R/bench.py --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats -d "$O/kt" -o bench -- $B > "$O/kt.log" 2>&1
-rocprofv3 --kernel-trace -f csv -d "$O/pmc_mfma" -o bench --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -- $B > "$O/pmc_mfma.log" 2>&1
-rocprofv3 --kernel-trace -f csv -d "$O/pmc_hbm" -o bench --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -- $B > "$O/pmc_hbm.log" 2>&1
-rocprofv3 --kernel-trace -f csv -d "$O/pmc_lds" -o bench --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -- $B > "$O/pmc_lds.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$O/kt" -o bench -- $B > "$O/kt.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace -f csv -d "$O/pmc_mfma" -o bench --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -- $B > "$O/pmc_mfma.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace -f csv -d "$O/pmc_hbm" -o bench --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -- $B > "$O/pmc_hbm.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace -f csv -d "$O/pmc_lds" -o bench --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -- $B > "$O/pmc_lds.log" 2>&1
 DB=$(find "$O/kt" -name '*.db' | head -1)
 python "$R/tools/rocpd_summary.py" "$DB" > "$O/kernel_trace.txt"
 for p in mfma hbm lds; do
