@@ -241,6 +241,93 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
     }
 }
 
+// Column-sliced head backward (round 3).  dW[e0, c] = sum_n dY[n, e0] X[n, c] and dX[n, c] = sum_e0 dY[n, e0] W[e0, c] are both separable
+// in the column c of the layer input, so a workgroup that owns a slice of CW columns needs nothing from the others: it stages ALL of dY
+// (N x E0, with `out -= target` applied on the fly), its slice of X and of W in LDS - one memory round trip - and after ONE local barrier
+// computes and stores dW[:, slice] (fmaf chain ascending n), dX[:, slice] over X in place (it alone read those columns) and the mask
+// multiplies behind it.  No arrival gate stands between the dW readers and the dX writers any more (k_linsmall_bwd above: two dependent
+// agent-scope round trips on the critical path).  Only the in-place `out -= target` store of the loss preparation is shared: every workgroup
+// reports once it has staged dY, workgroup 0 stores it when all have (off everybody else's critical path; bounded spin).
+constexpr int LSC_CW = 8;
+__global__ void __launch_bounds__(256) k_linsmall_bwd_cols(const float *X, const float *__restrict__ W, const float *DY, float *DX, float *DW, float *DB,
+                                                           int N, int E0, int E1, int train, int *sync,
+                                                           const float *__restrict__ MASK, float *__restrict__ DXM,
+                                                           const float *__restrict__ TGT, float *DYW, float *DY2,
+                                                           const float *__restrict__ MASKB, float *__restrict__ DXMB) {
+    extern __shared__ float sm[];
+    constexpr int CW = LSC_CW, ZI = 8;                         // ZI x 256 outputs of dX per pass
+    float *dys = sm, *Ws = sm + N * E0, *Xs = Ws + E0 * CW;          // dY [N][E0], W slice [E0][CW], X slice [N][CW]
+    float *red = Xs + N * CW;                                  // [G][E0 * CW] partial dW sums
+    const int tid = threadIdx.x, c0 = blockIdx.x * CW, cw = min(CW, E1 - c0);
+    // the masks of this thread's first ZI outputs are fetched NOW, with the operands (a load behind a may-alias store would cost a round trip each)
+    float mk[ZI], mkb[ZI];
+#pragma unroll
+    for (int k = 0; k < ZI; k++) {
+        const int z = tid + k * 256, n = z / CW, c = z - n * CW;
+        const bool ok = DXM && z < N * CW && c < cw;
+        const long o = (long)n * E1 + c0 + c;
+        mk[k] = ok ? MASK[o] : 0.f; mkb[k] = (ok && DXMB) ? MASKB[o] : 0.f;
+    }
+    for (int i = tid; i < N * E0; i += 256) dys[i] = DY[i] - (TGT ? TGT[i] : 0.f);
+    for (int i = tid; i < E0 * CW; i += 256) { const int e0 = i / CW, c = i - e0 * CW; Ws[i] = c < cw ? W[(long)e0 * E1 + c0 + c] : 0.f; }
+    if (train)
+        for (int i = tid; i < N * CW; i += 256) { const int n = i / CW, c = i - n * CW; Xs[i] = c < cw ? X[(long)n * E1 + c0 + c] : 0.f; }
+    __syncthreads();
+    if (TGT && tid == 0) __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // dY (and the target) staged here
+    const int nout = E0 * CW, G = min(4, 256 / nout);           // thread groups splitting the batch of one dW output (contiguous ranges, summed in order)
+    float dwacc = 0.f;
+    if (train && tid < nout * G) {
+        const int g = tid / nout, t = tid - g * nout, e0 = t / CW, c = t - e0 * CW;
+        const int nb = (N + G - 1) / G, n0 = g * nb, n1 = min(N, n0 + nb);
+#pragma unroll 8
+        for (int n = n0; n < n1; n++) dwacc = fmaf(dys[n * E0 + e0], Xs[n * CW + c], dwacc);
+        if (G > 1) red[g * nout + t] = dwacc;
+    }
+    if (DX) {
+#pragma unroll
+        for (int k = 0; k < ZI; k++) {                           // dX[n, c0 + c]: fmaf chain ascending e0 (the oracle's order)
+            const int z = tid + k * 256, n = z / CW, c = z - n * CW;
+            if (z >= N * CW || c >= cw) continue;
+            float acc = 0.f;
+            for (int e0 = 0; e0 < E0; e0++) acc = fmaf(dys[n * E0 + e0], Ws[e0 * CW + c], acc);
+            const long o = (long)n * E1 + c0 + c;
+            DX[o] = acc;                                         // may be X itself: this workgroup staged these columns before the barrier, nobody else reads them
+            if (DXM) { const float g1 = acc * mk[k]; DXM[o] = g1; if (DXMB) DXMB[o] = g1 * mkb[k]; }
+        }
+        for (int z = tid + ZI * 256; z < N * CW; z += 256) {     // batches beyond ZI x 256 / CW rows
+            const int n = z / CW, c = z - n * CW;
+            if (c >= cw) continue;
+            float acc = 0.f;
+            for (int e0 = 0; e0 < E0; e0++) acc = fmaf(dys[n * E0 + e0], Ws[e0 * CW + c], acc);
+            const long o = (long)n * E1 + c0 + c;
+            DX[o] = acc;
+            if (DXM) { const float g1 = acc * MASK[o]; DXM[o] = g1; if (DXMB) DXMB[o] = g1 * MASKB[o]; }
+        }
+    }
+    if (train) {
+        if (G > 1) __syncthreads();
+        if (tid < nout) {
+            const int e0 = tid / CW, c = tid - e0 * CW;
+            float a = dwacc;
+            for (int g = 1; g < G; g++) a += red[g * nout + tid];
+            if (c < cw) DW[(long)e0 * E1 + c0 + c] += a;
+        } else if (blockIdx.x == 0 && tid - nout < E0) {         // dB[e0] = sum_n dY[n, e0] (k_dlinear_db nmath.cu:274-280), spare threads of workgroup 0
+            const int e0 = tid - nout;
+            float b = 0.f;
+            for (int n = 0; n < N; n++) b += dys[n * E0 + e0];
+            DB[e0] += b;
+        }
+    }
+    if (TGT && blockIdx.x == 0) {                                // `out -= target` in place, once every workgroup has read out / target
+        if (tid == 0) {
+            T4K_SPIN_WAIT(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x, 6);
+            __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // re-armed for the next launch on this stream
+        }
+        __syncthreads();
+        for (int i = tid; i < N * E0; i += 256) { DYW[i] = dys[i]; if (DY2) DY2[i] = dys[i]; }
+    }
+}
+
 } // namespace
 
 namespace t4k {
@@ -282,6 +369,20 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
                       int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM, const float *TGT, float *DY2,
                       const float *MASKB, float *DXMB) {
+    {   // column-sliced kernel: batches that fit LDS whole (N x (E0 + 16) floats), every output of dW in one thread (E0 x 16 <= 256)
+        static int cols_on = -1; if (cols_on < 0) { const char *e = getenv("T4K_LINSMALL_COLS"); cols_on = e ? atoi(e) : 1; }
+        const size_t ldsc = sizeof(float) * ((size_t)N * E0 + (size_t)E0 * LSC_CW + (size_t)N * LSC_CW + 256);
+        int *gatec = TGT ? gate_for(hs, 0) : nullptr;            // the one shared counter (ints 0.. of the stream's gate block; zero between launches)
+        const int nwg = (E1 + LSC_CW - 1) / LSC_CW;
+        if (cols_on && E0 * LSC_CW + E0 <= 256 && N >= 1 && N <= 512 && ldsc <= (size_t)LS_MAX_FLOATS * 4 && (DX || (train && DW)) && (!train || (DW && DB)) &&
+            (!TGT || (gatec && st().d_sync && nwg <= st().cu_count)) && (cols_on >= 2 || N * E1 <= 32768)) {
+            static bool attrc = false;
+            if (!attrc) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd_cols), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attrc = true; }
+            hipLaunchKernelGGL(k_linsmall_bwd_cols, dim3(nwg), dim3(256), ldsc, hs, X, W, DY, DX, DW, DB, N, E0, E1, (train && DW) ? 1 : 0, gatec,
+                               MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
+            return true;
+        }
+    }
     // dW: one workgroup per output row walks the batch in trips of (256 / CL) x 64 rows; when that takes more than one trip, the row's
     // columns are split over workgroups of 64 columns x 4 batch groups instead (a 256 -> 1 head: 1 workgroup x 4 trips -> 4 x 1)
     int CLh = 32; while (CLh < E1 && CLh < 256) CLh <<= 1;
