@@ -326,6 +326,19 @@ typedef struct t4k_conv_stage {
 int t4k_conv_stack_ok(const t4k_conv_stage *st, int n_stage, int N);           /* 1 when the stack qualifies (shapes, layers, LDS) and its kernels are built */
 int t4k_conv_stack_selftest(void);   /* the stack kernels are compiled at run time (hipRTC) for the model's shapes: this compiles two reference
                                       * shape sets for gfx950 - no device needed - and returns 0, or an error with the compiler log in t4k_last_error() */
+/* The stack AND the classifier head behind its flatten in ONE launch: [conv + run] x n, flatten, linear E1 -> E0a, one element-wise layer
+ * (dropout / activation, or 0), linear E0a -> E0b, softmax - the layers t4k_conv_stack_fwd + t4k_mlp_head_fwd run (forward.cu:28-113,
+ * 157-198, 231-243), every layer tensor stored, Philox positions as the separate layers.  t4k_conv_stack_head_ok() tells whether the shapes
+ * qualify; the backward is unchanged (t4k_conv_stack_bwd reads what this forward saved, like t4k_conv_stack_fwd's). */
+typedef struct t4k_stack_head {
+    const float *W1, *B1; float *Y1;            /* first linear layer: W1[E0a][E1], bias, output [N][E0a]                     */
+    int mid_layer; float mid_alpha;             /* element-wise layer behind it (t4k_layer; 0: none), its parameter          */
+    float *mid_mask, *mid_out;                  /* derivative mask and output [N][E0a]                                      */
+    const float *W2, *B2; float *Y2, *P;        /* second linear layer W2[E0b][E0a], bias, output [N][E0b]; softmax output  */
+    int E1, E0a, E0b;
+} t4k_stack_head;
+int t4k_conv_stack_head_ok(const t4k_conv_stage *st, int n_stage, int N, const t4k_stack_head *h);
+int t4k_conv_stack_head_fwd(const float *X, float *X0, const t4k_conv_stage *st, int n_stage, int N, const t4k_stack_head *h, t4k_stream_t s);
 int t4k_conv_stack_fwd(const float *X, float *XCOPY, const t4k_conv_stage *st, int n_stage, int N, t4k_stream_t s);
 int t4k_conv_stack_bwd(const float *DY, const t4k_conv_stage *st, int n_stage, int N, int train, t4k_stream_t s);
 /* backward of the same run (_bactivate backprop.cu:256-263, _bpool, flatten `in = out`): DY is the gradient

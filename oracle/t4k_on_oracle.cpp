@@ -269,5 +269,7 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab, int nt, int, float lr, f
 int t4k_conv_stack_ok(const t4k_conv_stage *, int, int) { return 0; }
 int t4k_conv_stack_fwd(const float *, float *, const t4k_conv_stage *, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
 int t4k_conv_stack_bwd(const float *, const t4k_conv_stage *, int, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
+int t4k_conv_stack_head_ok(const t4k_conv_stage *, int, int, const t4k_stack_head *) { return 0; }
+int t4k_conv_stack_head_fwd(const float *, float *, const t4k_conv_stage *, int, int, const t4k_stack_head *, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
 
 } // extern "C"

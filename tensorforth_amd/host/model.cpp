@@ -101,6 +101,7 @@ void (*Model::grad_hook)(int, long, long, void *) = nullptr;
 void *Model::grad_hook_user = nullptr;
 bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
 bool Model::use_stack  = getenv("T4_STACK") ? atoi(getenv("T4_STACK")) != 0 : true;
+bool Model::use_stack_head = getenv("T4_STACK_HEAD") ? atoi(getenv("T4_STACK_HEAD")) != 0 : true;   // T4_STACK_HEAD=0: the classifier head behind a conv stack keeps its own launches
 bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
 
@@ -339,6 +340,21 @@ void Model::run_forward(Tensor &input) {
             t4k_conv_stage stg[3]; int ops = 0;
             const int ns = stack_at(i, stg, ops);
             if (ns >= 2 || (ns == 1 && stack_single_)) {
+                const int j = i + ops;                  // the layer behind the stack: a classifier head [linear + activation] + [linear + softmax]?
+                if (use_stack_head && j + 1 < L && lin_kind(j) == 1) {   // then the whole forward pass is ONE launch
+                    Tensor &l1 = at(j), &y1 = at(j + 1), &act = at(j + 2), &y2 = at(j + 3), &prob = at(j + 4);
+                    t4k_stack_head hd; memset(&hd, 0, sizeof(hd));
+                    hd.W1 = l1.grad[0]->data; hd.B1 = l1.grad[1]->data; hd.Y1 = y1.data;
+                    hd.mid_layer = y1.grad_fn; hd.mid_alpha = y1.xparm; hd.mid_mask = y1.grad[4]->data; hd.mid_out = act.data;
+                    hd.W2 = act.grad[0]->data; hd.B2 = act.grad[1]->data; hd.Y2 = y2.data; hd.P = prob.data;
+                    hd.E1 = (int)l1.HWC(); hd.E0a = (int)y1.HWC(); hd.E0b = (int)y2.HWC();
+                    if (t4k_conv_stack_head_ok(stg, ns, in.N(), &hd)) {
+                        chk(t4k_conv_stack_head_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, stg, ns, in.N(), &hd, stream()), "nn#fstack+head");
+                        stack_fresh_[i] = 1;
+                        x = prob.data; i = j + 3;
+                        continue;
+                    }
+                }
                 chk(t4k_conv_stack_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, stg, ns, in.N(), stream()), "nn#fstack");
                 stack_fresh_[i] = 1;
                 x = at(i + ops).data; i += ops - 1;

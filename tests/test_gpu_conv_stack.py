@@ -307,3 +307,66 @@ def test_backprop_after_a_traced_forward_ignores_what_an_earlier_stack_forward_s
     for n_ in got[False]:
         e = rel_err(got[True][n_], got[False][n_])
         assert e <= TOL, "%s after a traced forward: %.3g" % (n_, e)
+
+
+class StackHead(ctypes.Structure):
+    _fields_ = [("W1", ctypes.c_void_p), ("B1", ctypes.c_void_p), ("Y1", ctypes.c_void_p), ("mid_layer", ctypes.c_int), ("mid_alpha", ctypes.c_float),
+                ("mid_mask", ctypes.c_void_p), ("mid_out", ctypes.c_void_p), ("W2", ctypes.c_void_p), ("B2", ctypes.c_void_p), ("Y2", ctypes.c_void_p),
+                ("P", ctypes.c_void_p), ("E1", ctypes.c_int), ("E0a", ctypes.c_int), ("E0b", ctypes.c_int)]
+
+
+@pytest.mark.parametrize("case,EA,EB,mid", [(0, 100, 10, "dropout"), (0, 100, 10, "relu"), (2, 37, 5, "dropout"), (3, 64, 16, None), (2, 130, 3, "tanh")])
+def test_conv_stack_with_classifier_head_in_one_launch(t4k, dev, oracle, case, EA, EB, mid):
+    """t4k_conv_stack_head_fwd == the oracle's separate layers: the stack (every tensor, as above), then linear E1 -> EA, the element-wise
+    layer (dropout mask bit-exact: same Philox slice behind the stack's own draws), linear EA -> EB, softmax - at 1e-4 relative; run twice
+    (the accumulators / tickets the bands share must be left clean) and the Philox stream ends where the separate layers' ends."""
+    N, H, W, Cin, stages, flat = CASES[case]
+    assert flat
+    o = oracle.lib(); P = oracle.P; LAY = _lay(oracle)
+    rng = np.random.default_rng(500 + case + EA)
+    X = rng.standard_normal((N, H, W, Cin)).astype(np.float32)
+    params = _params(rng, Cin, stages)
+    seed, off = 4321 + case, 8192
+    ref, _ = _oracle_forward(oracle, X, stages, flat, params, seed, off)
+    xf = ref[-1]["last"].reshape(N, -1); E1 = xf.shape[1]
+    W1 = (rng.standard_normal((EA, E1)) * 0.1).astype(np.float32); B1 = rng.standard_normal(EA).astype(np.float32)
+    W2 = (rng.standard_normal((EB, EA)) * 0.3).astype(np.float32); B2 = rng.standard_normal(EB).astype(np.float32)
+    Y1 = np.zeros((N, EA), np.float32); assert o.t4o_linear_fwd(P(np.ascontiguousarray(xf)), P(W1), P(B1), P(Y1), N, EA, E1) == 0
+    cur = Y1; Fm = Am = None
+    if mid:
+        L, a = LAY[mid]; Fm = np.zeros(Y1.size, np.float32); Am = np.zeros_like(Y1)
+        if mid == "dropout":
+            o.t4o_rand(P(Fm), Fm.size, 0, 0.0, 1.0)               # continues the stream behind the stack's draws
+        o.t4o_activate(L, P(Y1), P(Am), P(Fm), a, Y1.size); Fm = Fm.reshape(Y1.shape); cur = Am
+    Y2 = np.zeros((N, EB), np.float32); assert o.t4o_linear_fwd(P(np.ascontiguousarray(cur)), P(W2), P(B2), P(Y2), N, EB, EA) == 0
+    Pr = np.zeros_like(Y2); o.t4o_softmax(P(Y2), P(Pr), N, EB)
+    end = o.t4o_rand_offset()
+    arr, bufs = _build(dev, oracle, X, stages, flat, params, ref)
+    hd = StackHead()
+    d = {"W1": dev.up(W1), "B1": dev.up(B1), "Y1": dev.zeros(Y1.shape), "Fm": dev.zeros(Y1.shape), "Am": dev.zeros(Y1.shape),
+         "W2": dev.up(W2), "B2": dev.up(B2), "Y2": dev.zeros(Y2.shape), "P": dev.zeros(Y2.shape)}
+    hd.W1, hd.B1, hd.Y1, hd.W2, hd.B2, hd.Y2, hd.P = p(d["W1"]), p(d["B1"]), p(d["Y1"]), p(d["W2"]), p(d["B2"]), p(d["Y2"]), p(d["P"])
+    if mid:
+        hd.mid_layer, hd.mid_alpha = LAY[mid]; hd.mid_mask, hd.mid_out = p(d["Fm"]), p(d["Am"])
+    hd.E1, hd.E0a, hd.E0b = E1, EA, EB
+    assert t4k.lib.t4k_conv_stack_head_ok(arr, len(stages), N, ctypes.byref(hd)) == 1
+    dX = dev.up(X)
+    for rep in range(2):
+        t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+        for k_ in ("Y1", "Fm", "Am", "Y2", "P"):
+            d[k_].fill_(-7.0)
+        t4k.call("t4k_conv_stack_head_fwd", p(dX), None, arr, len(stages), N, ctypes.byref(hd), None)
+        assert t4k.lib.t4k_rand_offset() == end
+        for si in range(len(stages)):                              # the stack's own tensors, as in the forward test
+            for k_ in ("O", "pool_out", "post_out", "copy_out"):
+                if k_ in ref[si]:
+                    assert rel(dev.down(bufs[si][k_]).reshape(ref[si][k_].shape), ref[si][k_]) < RTOL, "rep %d stage %d %s" % (rep, si, k_)
+        assert rel(dev.down(d["Y1"]), Y1) < RTOL, "rep %d linear 1: %.3g" % (rep, rel(dev.down(d["Y1"]), Y1))
+        if mid == "dropout":
+            assert np.array_equal(dev.down(d["Fm"]), Fm), "rep %d dropout mask" % rep
+        elif mid:
+            assert np.mean(np.abs(dev.down(d["Fm"]) - Fm) > 1e-3) < 1e-3, "rep %d mask" % rep
+        if mid:
+            assert rel(dev.down(d["Am"]), Am) < RTOL, "rep %d activation" % rep
+        assert rel(dev.down(d["Y2"]), Y2) < RTOL, "rep %d linear 2: %.3g" % (rep, rel(dev.down(d["Y2"]), Y2))
+        assert rel(dev.down(d["P"]), Pr) < RTOL, "rep %d softmax: %.3g" % (rep, rel(dev.down(d["P"]), Pr))
