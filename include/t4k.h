@@ -359,6 +359,13 @@ int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const flo
  * (t4k_poolblock_bwd(DX, XRUN, blk): the post stage's input buffer = DX * post_mask, XRUN = that * pre_mask; _bactivate
  * backprop.cu:256-263).  TGT != NULL: DY -= TGT first (backprop's start, backprop.cu:43-53), the difference also stored in DY2 when
  * that is not NULL.  DX may alias X (the reference's in-place convention). */
+/* Classifier-head backward + the backward of the linear layer in front of it in ONE launch: the two calls
+ *   t4k_loss_linear_bwd(X2, W2, P, TGT, Y2, X2, MASK, Y1, DW2, DB2, N, E0b, E0a, 1);   t4k_linear_bwd(X1, W1, Y1, X1, DW1, DB1, N, E0a, E1, 1)
+ * (backprop.cu:103-121, 226-254: out -= target, dW2 | dB2, dX2 in place, the mask multiply of the layer between them -> Y1, dW1 | dB1, dX1 over X1),
+ * training passes only.  t4k_mlp_head_bwd_ok() says whether the shapes qualify. */
+int t4k_mlp_head_bwd_ok(int N, int E1, int E0a, int E0b);
+int t4k_mlp_head_bwd(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const float *MASK, float *Y1, float *DW2, float *DB2,
+                     float *X1, const float *W1, float *DW1, float *DB1, int N, int E1, int E0a, int E0b, t4k_stream_t s);
 int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float *TGT, float *DY2, float *DX, const t4k_poolblock *blk, float *XRUN,
                          float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
 /* classifier head in one call: [linear E1 -> H + element-wise layer] + [linear H -> E2 (+ softmax when P2 != NULL)] =

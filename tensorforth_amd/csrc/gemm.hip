@@ -395,16 +395,28 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 // kernels, each with 1/16 of the matrix work per wave.
 // Operand layout of v_mfma_f32_32x32x2_f32: lane (l31, h) supplies A[row = l31][k] and B[k][col = l31] for one k per instruction;
 // chunk c covers k = 8c + 4h + {0..3}, as in the LDS kernels above.
-template <bool AKC, bool BKC, int CB>
+template <bool AKC, bool BKC, int CB, bool ALDS = false>       // ALDS: A points into LDS (ds_read instead of flat loads)
 __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const float *__restrict__ B, int M, int N, int ldk, int K, int arow, int bcol,
-                                          int cbeg, int cend, int h, float (&fa)[CB][4], float (&fb)[CB][4], int kbeg) {
+                                          int cbeg, int cend, int h, float (&fa)[CB][4], float (&fb)[CB][4], int kbeg, int lda = -1) {
+    if (lda < 0) lda = ldk;                                         // A's row pitch when it is K-contiguous (an operand tile prepared in LDS has its own)
 #pragma unroll
     for (int c = 0; c < CB; c++) {
         const int ch = cbeg + c, k0 = kbeg + ch * 8 + 4 * h;       // K here is the END of this workgroup's k range, kbeg its start
         const bool ok = ch < cend && k0 < K;
+        if (ALDS) {
+            typedef __attribute__((address_space(3))) const float lds_f;
+            typedef __attribute__((address_space(3))) const v4f lds_v4;
+            lds_f *Al = (lds_f *)A;
+            if (AKC) { const v4f z = {0.f, 0.f, 0.f, 0.f}; const v4f t = ok ? *(lds_v4 *)(Al + arow * lda + k0) : z;
+                       fa[c][0] = t[0]; fa[c][1] = t[1]; fa[c][2] = t[2]; fa[c][3] = t[3]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) fa[c][j] = (ok && k0 + j < K) ? Al[(k0 + j) * M + arow] : 0.f;
+            }
+        } else
         if (AKC) {                                                  // A stored [M][K], K % 4 == 0: one 16-byte load
             const v4f z = {0.f, 0.f, 0.f, 0.f};
-            const v4f t = ok ? *reinterpret_cast<const v4f *>(A + (long)arow * ldk + k0) : z;
+            const v4f t = ok ? *reinterpret_cast<const v4f *>(A + (long)arow * lda + k0) : z;
             fa[c][0] = t[0]; fa[c][1] = t[1]; fa[c][2] = t[2]; fa[c][3] = t[3];
         } else {                                                    // A stored [K][M]: the 32 lanes of a half wave read one 128-byte run per k
 #pragma unroll
@@ -420,11 +432,12 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
         }
     }
 }
-template <bool AKC, bool BKC, int CB, int NW = 4>   // NW waves = NW k-groups per 32x32 tile
+template <bool AKC, bool BKC, int CB, int NW = 4, bool ALDS = false>   // NW waves = NW k-groups per 32x32 tile; ALDS: the A tile was prepared in LDS
 __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, float *red,
                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
                                               const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0,
-                                              const int by = 0, const FoldRider *fe = nullptr, const ActEpi *ep1 = nullptr) {
+                                              const int by = 0, const FoldRider *fe = nullptr, const ActEpi *ep1 = nullptr,
+                                              const float *Alds = nullptr, const int Ald = 0) {      // Alds: this tile's 32 rows of A, prepared in LDS by the caller ([k][32] or [32][Ald])
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int M = p.M, N = p.N, K = p.K;
     const int kbeg = by * p.kchunk, kend = min(K, kbeg + p.kchunk);      // this workgroup's k range (split-K: slab `by`)
@@ -443,7 +456,8 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     }
     const int tm = bx / p.tiles_n, tn = bx - tm * p.tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
-    const int arow = min(m0 + l31, M - 1), bcol = min(n0 + l31, N - 1);      // clamped: rows / columns past the edge are never stored
+    const int arow = Alds ? l31 : min(m0 + l31, M - 1), bcol = min(n0 + l31, N - 1);      // clamped: rows / columns past the edge are never stored
+    const float *Ap = Alds ? Alds : p.A; const int Am = Alds ? 32 : M, Ald_ = Alds ? Ald : K;
     // this wave's share of the 8-deep k chunks
     const int nch = (kend - kbeg + 7) >> 3, cpw = (nch + NW - 1) / NW;
     const int c0 = w * cpw, c1 = min(nch, c0 + cpw);
@@ -479,13 +493,13 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         if (lane == 0) __hip_atomic_store(slots + 4 * bx + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (c0 < c1) {
-        s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg);
+        s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
         for (int cb = c0; cb < c1; cb += 2 * CB) {
-            if (cb + CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, kend, arow, bcol, cb + CB, c1, h, fa1, fb1, kbeg);
+            if (cb + CB < c1) s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, cb + CB, c1, h, fa1, fb1, kbeg, Ald_);
             else arrive();
             mma(fa0, fb0);
             if (cb + CB < c1) {
-                if (cb + 2 * CB < c1) s32_fetch<AKC, BKC, CB>(p.A, p.B, M, N, K, kend, arow, bcol, cb + 2 * CB, c1, h, fa0, fb0, kbeg);
+                if (cb + 2 * CB < c1) s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, cb + 2 * CB, c1, h, fa0, fb0, kbeg, Ald_);
                 else arrive();
                 mma(fa1, fb1);
             }
@@ -572,6 +586,126 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 
     __shared__ float red[4 * 16 * 64];
     if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, CB>(p1, blockIdx.x, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
     else                       gemm_s32_body<true, false, CB>(p2, (int)blockIdx.x - nb1, red, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
+}
+
+// ---- classifier-head backward + the backward of the linear layer in front of it, ONE launch (t4k_mlp_head_bwd).
+// The head backward (loss preparation out -= target, dW2 | dB2, dX2 = dY2 W2 in place, mask multiply -> dY1) and the big layer's dW1 += dY1^T X1,
+// dX1 = dY1 W1 are dependent: the second needs dY1 [N][EA].  But dY1 is CHEAP to recompute - dY1[n, e] = mask[n, e] sum_j (P - T)[n, j] W2[j, e], EB = 10
+// terms - so every GEMM tile prepares the 32 rows of dY1 it multiplies with in LDS from P, T, W2 and the mask (all there before the launch) and the
+// two kernels stop depending on each other: the GEMM tiles (k_gemm_dual32's, A operand from LDS) and the column-sliced head workgroups
+// (linear_small.hip k_linsmall_bwd_cols, here as riders) run side by side.  The head riders still store dY1, dX2, dW2, dB2 - and dB1, the column sums of
+// the dY1 slice they have in hand.  The only shared write is `out -= target` over P: rider 0 stores it once EVERY workgroup has staged P and T (counter).
+struct HeadBwd {
+    const float *P, *T, *W2, *MASK;     // softmax output [N][EB], target, W2 [EB][EA], derivative mask of the layer between the linear layers [N][EA]
+    float *X2, *DW2, *DB2, *Y1, *Y2;    // head input [N][EA] (receives dX2), gradients, dY1 tensor (= dX2 * mask), second copy of out - target
+    float *DB1;
+    int N, EA, EB, train, nwg; int *sync;
+};
+template <int CB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_head_bwd_dual32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, HeadBwd hb) {
+    __shared__ float red[4 * 16 * 64];
+    extern __shared__ __attribute__((aligned(16))) float dyn[];       // tiles: d2 [N][EB] | w2 [EB][EA] | Ad (16-byte aligned offsets); riders: the cols layout
+    const int tid = threadIdx.x, N = hb.N, EA = hb.EA, EB = hb.EB, bx = blockIdx.x;
+    const int ntile = nb1 + t2;
+    if (bx < ntile) {
+        float *d2 = dyn, *w2 = d2 + ((N * EB + 3) & ~3), *Ad = w2 + ((EB * EA + 3) & ~3);
+        const bool first = bx < nb1;                                 // dW1 tile: rows e0..e0+31 of dY1^T, all n;  dX1 tile: rows n0..n0+31 of dY1, all e
+        const int tb = first ? bx : bx - nb1;
+        const int r0 = (first ? tb / p1.tiles_n : tb / p2.tiles_n) * 32;
+        const int EAp = (EA + 3) & ~3, nel = first ? N * 32 : 32 * EAp;
+        constexpr int MQ = 16;                                       // mask values per thread fetched with the operands (N <= 128 rows or EAp <= 128 columns per pass; the rest in a second pass)
+        for (int i = tid; i < N * EB; i += 256) d2[i] = hb.P[i] - hb.T[i];
+        for (int i = tid; i < EB * EA; i += 256) w2[i] = hb.W2[i];
+        for (int base = 0; base < nel; base += MQ * 256) {
+            float mk[MQ];
+#pragma unroll
+            for (int q = 0; q < MQ; q++) {                           // the masks travel with P, T and W2: one memory round trip in front of the GEMM
+                const int i = base + tid + q * 256;
+                int n, e;
+                if (first) { n = i >> 5; e = min(r0 + (i & 31), EA - 1); } else { const int r = i / EAp; e = min(i - r * EAp, EA - 1); n = min(r0 + r, N - 1); }
+                mk[q] = i < nel ? hb.MASK[(long)min(n, N - 1) * EA + e] : 0.f;
+            }
+            if (base == 0) {
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(hb.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // P and T are in LDS: `out -= target` may land as far as this workgroup is concerned
+            }
+#pragma unroll
+            for (int q = 0; q < MQ; q++) {
+                const int i = base + tid + q * 256;
+                if (i < nel) {
+                    int n, e; bool live = true;
+                    if (first) { n = i >> 5; e = min(r0 + (i & 31), EA - 1); }               // Ad[n][32]: k-major, as the [K][M] operand it replaces
+                    else { const int r = i / EAp; e = i - r * EAp; live = e < EA; e = min(e, EA - 1); n = min(r0 + r, N - 1); }   // Ad[32][EAp]: K-contiguous rows
+                    float a = 0.f;
+                    for (int j = 0; j < EB; j++) a = fmaf(d2[n * EB + j], w2[j * EA + e], a);
+                    Ad[i] = live ? a * mk[q] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (first) gemm_s32_body<false, false, CB, 4, true>(p1, bx, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, 32);
+        else       gemm_s32_body<true, false, CB, 4, true>(p2, bx - nb1, red, nullptr, slots ? 2 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, (EA + 3) & ~3);
+        return;
+    }
+    // ---- head riders: column slices of the head's input (see k_linsmall_bwd_cols)
+    constexpr int CW = 8;
+    const int cb = bx - ntile, c0 = cb * CW, cw = min(CW, EA - c0);
+    float *dys = dyn, *Ws = dys + N * EB, *Xs = Ws + EB * CW, *rd2 = Xs + N * CW;       // dY2 [N][EB], W2 slice [EB][CW], X2 slice [N][CW] (then dY1 slice), partial sums
+    for (int i = tid; i < N * EB; i += 256) dys[i] = hb.P[i] - hb.T[i];
+    for (int i = tid; i < EB * CW; i += 256) { const int j = i / CW, c = i - j * CW; Ws[i] = c < cw ? hb.W2[(long)j * EA + c0 + c] : 0.f; }
+    for (int i = tid; i < N * CW; i += 256) { const int n = i / CW, c = i - n * CW; Xs[i] = c < cw ? hb.X2[(long)n * EA + c0 + c] : 0.f; }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(hb.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nout = EB * CW, G = min(4, 256 / nout);
+    float dwacc = 0.f;
+    if (hb.train && tid < nout * G) {                               // dW2[j, c0 + c]
+        const int g = tid / nout, t = tid - g * nout, j = t / CW, c = t - j * CW;
+        const int nb = (N + G - 1) / G, n0 = g * nb, n1 = min(N, n0 + nb);
+#pragma unroll 8
+        for (int n = n0; n < n1; n++) dwacc = fmaf(dys[n * EB + j], Xs[n * CW + c], dwacc);
+        if (G > 1) rd2[g * nout + t] = dwacc;
+    }
+    __syncthreads();                                                 // X2 slice consumed: its place takes the dY1 slice
+    for (int z = tid; z < N * CW; z += 256) {                        // dX2[n, c0 + c] over X2 in place, dY1 = dX2 * mask
+        const int n = z / CW, c = z - n * CW;
+        float g1 = 0.f;
+        if (c < cw) {
+            float acc = 0.f;
+            for (int j = 0; j < EB; j++) acc = fmaf(dys[n * EB + j], Ws[j * CW + c], acc);
+            const long o = (long)n * EA + c0 + c;
+            hb.X2[o] = acc;
+            g1 = acc * hb.MASK[o]; hb.Y1[o] = g1;
+        }
+        Xs[z] = g1;
+    }
+    __syncthreads();
+    if (hb.train) {
+        if (tid < nout) {
+            const int j = tid / CW, c = tid - j * CW;
+            float a = dwacc;
+            for (int g = 1; g < G; g++) a += rd2[g * nout + tid];
+            if (c < cw) hb.DW2[(long)j * EA + c0 + c] += a;
+        } else if (tid < nout + CW) {                                // dB1[c0 + c] = sum_n dY1[n, c0 + c] (k_dlinear_db nmath.cu:274-280)
+            const int c = tid - nout;
+            float b = 0.f;
+            for (int n = 0; n < N; n++) b += Xs[n * CW + c];
+            if (c < cw) hb.DB1[c0 + c] += b;
+        } else if (cb == 0 && tid - nout - CW < EB) {                // dB2[j] = sum_n dY2[n, j]
+            const int j = tid - nout - CW;
+            float b = 0.f;
+            for (int n = 0; n < N; n++) b += dys[n * EB + j];
+            hb.DB2[j] += b;
+        }
+    }
+    if (cb == 0) {                                                   // `out -= target` in place (+ its copy), once every workgroup has read out / target
+        if (tid == 0) {
+            T4K_SPIN_WAIT(__hip_atomic_load(hb.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hb.nwg, 8);
+            __hip_atomic_store(hb.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        float *Pw = const_cast<float *>(hb.P);
+        for (int i = tid; i < N * EB; i += 256) { Pw[i] = dys[i]; if (hb.Y2) hb.Y2[i] = dys[i]; }
+    }
 }
 
 // Two independent 64x64-tiled GEMMs in ONE launch (a linear layer's dW += dY^T X and dX = dY W): workgroups [0, nb1) run the
@@ -2056,6 +2190,59 @@ int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float 
     }
     int rc = t4k_linear_bwd2(X, W, DY, DX, nullptr, nullptr, DW, DB, N, E0, E1, train, s); if (rc) return rc;
     return t4k_poolblock_bwd(DX, XRUN, blk, N, 1, 1, 1, 1, E1, s);
+}
+
+// Classifier-head backward AND the backward of the linear layer in front of it in ONE launch (k_head_bwd_dual32): what
+// t4k_loss_linear_bwd(X2, W2, P, TGT, Y2, X2, MASK, Y1, DW2, DB2, N, EB, EA, 1) followed by t4k_linear_bwd(X1, W1, Y1, X1, DW1, DB1, N, EA, E1, 1)
+// compute (backprop.cu:103-121, 226-254; gradients accumulate), for a training pass with the in-place convention.  T4K_ERR_UNSUPPORTED when the shapes
+// do not qualify - the caller then makes the two calls.
+int t4k_mlp_head_bwd_ok(int N, int E1, int EA, int EB) {
+    if (!st().ready) return 0;
+    static int on = -1; if (on < 0) { const char *e = getenv("T4K_HEAD_BWD"); on = e ? atoi(e) : 1; }
+    if (!on || capturing(nullptr) || st().capturing || !st().d_sync || !dual_on()) return 0;
+    if (N < 1 || N > 256 || EA < 4 || EA > 256 || (EA & 3) || EB < 1 || EB > 16 || E1 < 4 || (E1 & 3)) return 0;
+    auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
+    const long a1 = t32(EA, E1), a2 = t32(N, E1), nc = (EA + 7) / 8;
+    static int per_cu = -1;                                       // resident workgroups per CU at the largest LDS request (48 KiB dynamic + 16 KiB static)
+    if (per_cu < 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_head_bwd_dual32<8>, 256, 48 * 1024) != hipSuccess || nb < 1) nb = 1; per_cu = nb; }
+    return (a1 + a2 + nc <= (long)per_cu * st().cu_count - 32 && a1 <= 512) ? 1 : 0;      // every workgroup resident (the in-place gate and the target store spin)
+}
+int t4k_mlp_head_bwd(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const float *MASK, float *Y1, float *DW2, float *DB2,
+                     float *X1, const float *W1, float *DW1, float *DB1, int N, int E1, int EA, int EB, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X2 || !W2 || !P || !TGT || !MASK || !Y1 || !DW2 || !DB2 || !X1 || !W1 || !DW1 || !DB1) return fail(T4K_ERR_ARG, "t4k_mlp_head_bwd: null argument");
+    hipStream_t hs = S(s);
+    int *gate = gate_for(hs, 0);
+    if (!t4k_mlp_head_bwd_ok(N, E1, EA, EB) || !gate || capturing(hs) || !aligned16(X1) || !aligned16(W1) || !aligned16(Y1))
+        return fail(T4K_ERR_UNSUPPORTED, "t4k_mlp_head_bwd: shapes do not qualify (t4k_mlp_head_bwd_ok)");
+    State &g = st();
+    auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
+    const long a1 = t32(EA, E1), a2 = t32(N, E1), nc = (EA + 7) / 8;
+    GemmP q1, q2;
+    auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
+        p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
+        p.tiles_m = (M + 31) / 32; p.tiles_n = (Nn + 31) / 32; p.kchunk = K; p.nsplit = 1;
+        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+    };
+    fill32(q1, Y1, X1, DW1, EA, E1, N, 1.0f);                     // dW1 += dY1^T X1   (A comes from LDS: the pointer is not read)
+    fill32(q2, Y1, W1, X1, N, E1, EA, 0.0f);                      // dX1 = dY1 W1, over X1 (backprop.cu:240)
+    unsigned *slots = reinterpret_cast<unsigned *>(gate) + 512;   // arrival slots of the in-place dX (as linear_bwd_dual)
+    static unsigned epochs[64];
+    const int li = lane_of(hs);
+    unsigned epoch = ++epochs[li < 63 ? li : 63];
+    if (epoch == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); epoch = ++epochs[li < 63 ? li : 63]; }
+    HeadBwd hb = { P, TGT, W2, MASK, X2, DW2, DB2, Y1, Y2, DB1, N, EA, EB, 1, (int)(a1 + a2 + nc), gate };
+    const int EAp = (EA + 3) & ~3;
+    const size_t lt = (size_t)((N * EB + 3) & ~3) + (size_t)((EB * EA + 3) & ~3) + (size_t)std::max(N * 32, 32 * EAp);
+    const size_t lr = (size_t)N * EB + (size_t)EB * 8 + (size_t)N * 8 + 256;
+    const size_t lds = sizeof(float) * std::max(lt, lr);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_dual32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
+                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_dual32<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); attr = true; }
+    if (lds > 48 * 1024) return fail(T4K_ERR_UNSUPPORTED, "t4k_mlp_head_bwd: %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(k_head_bwd_dual32<8>, dim3((unsigned)(a1 + a2 + nc)), dim3(256), lds, hs, q1, q2, (int)a1, (int)a1, (int)a2, slots, epoch, hb);
+    T4K_LAUNCH_CHECK();
+    return T4K_OK;
 }
 
 int t4k_gemm_f64acc(const float *A, const float *B, float *O, float alpha, float beta,

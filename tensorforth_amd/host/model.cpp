@@ -101,6 +101,7 @@ void (*Model::grad_hook)(int, long, long, void *) = nullptr;
 void *Model::grad_hook_user = nullptr;
 bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
 bool Model::use_stack  = getenv("T4_STACK") ? atoi(getenv("T4_STACK")) != 0 : true;
+bool Model::use_head_bwd = getenv("T4_HEAD_BWD") ? atoi(getenv("T4_HEAD_BWD")) != 0 : false;    // T4_HEAD_BWD=1: classifier-head backward and the linear layer in front of it in one launch (measured: no faster than the two)
 bool Model::use_stack_head = getenv("T4_STACK_HEAD") ? atoi(getenv("T4_STACK_HEAD")) != 0 : true;   // T4_STACK_HEAD=0: the classifier head behind a conv stack keeps its own launches
 bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
@@ -639,6 +640,7 @@ void Model::run_backward(Tensor &tgt) {
         if (skip_next_) {                               // bstep also ran the backward of op i-1 (a lone mask-multiply layer)
             skip_next_ = false;
             grads_ready(i, in);
+            if (also_ready_ >= 0) { grads_ready(also_ready_, at(also_ready_)); also_ready_ = -1; }   // a second layer's gradients came out of the same launch
             const int k = skip_cnt_; skip_cnt_ = 1;
             dy = at(i - k).data; i -= k; j += k;
             continue;
@@ -689,6 +691,17 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
             if (fused && i > 0 && run_of_[i - 1] >= 0 && runs_[run_of_[i - 1]].count == 1 && !runs_[run_of_[i - 1]].blk.pool_layer &&
                 runs_[run_of_[i - 1]].blk.pre_layer) {
                 Tensor &prev = at(i - 1);
+                // ... and when the layer in front of THAT is the linear layer behind a conv stack's flatten (the t4_30a/30e classifier), its backward
+                // joins the launch too: every GEMM tile recomputes the rows of dY1 it needs (10 terms each), so nothing waits for the head (t4k_mlp_head_bwd)
+                if (tg && use_head_bwd && train && i >= 3 && at(i - 2).grad_fn == T4K_L_LINEAR && !stack_end_.empty() && stack_end_[i - 3] >= 0 &&
+                    at(i - 2).grad[2] && at(i - 2).grad[3] &&
+                    t4k_mlp_head_bwd_ok(N, (int)at(i - 2).HWC(), E1, E0)) {
+                    Tensor &big = at(i - 2);
+                    chk(t4k_mlp_head_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, prev.grad[4]->data, prev.data, in.grad[2]->data, in.grad[3]->data,
+                                         big.data, big.grad[0]->data, big.grad[2]->data, big.grad[3]->data, N, (int)big.HWC(), E1, E0, s), "nn#bhead+blinear");
+                    skip_next_ = true; skip_cnt_ = 2; also_ready_ = i - 2;
+                    return big.data;
+                }
                 if (tg) chk(t4k_loss_linear_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, in.data, prev.grad[4]->data, prev.data,
                                             train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#bprep+blinear+act");
                 else

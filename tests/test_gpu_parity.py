@@ -688,6 +688,43 @@ def test_loss_prep_folded_into_linear_backward(t4k, dev, oracle, N, E0, E1, mask
         if train: assert rel(dev.down(dDW), DWr) < RTOL and rel(dev.down(dDB), DBr) < RTOL
 
 
+@pytest.mark.parametrize("N,E1,EA,EB", [(128, 980, 100, 10), (64, 512, 64, 16), (37, 260, 52, 3), (256, 1024, 128, 10)])
+def test_head_backward_and_the_linear_layer_in_front_in_one_launch(t4k, dev, oracle, N, E1, EA, EB):
+    """t4k_mlp_head_bwd == t4k_loss_linear_bwd (head: out -= target, dW2 | dB2, dX2 in place, mask multiply -> dY1) followed by t4k_linear_bwd
+    (dW1 | dB1, dX1 in place) of the oracle: the GEMM tiles recompute their rows of dY1 instead of waiting for the head, so every tensor both
+    kernels write is compared (1e-4 relative; `out - target` and its copy bit-exact), twice in a row (gate counter and epoch slots re-arm),
+    gradients ACCUMULATE onto what the tensors held."""
+    if t4k.lib.t4k_mlp_head_bwd_ok(N, E1, EA, EB) != 1:
+        pytest.skip("shape does not qualify on this device")
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N + E1 + EA)
+    X1 = rng.standard_normal((N, E1)).astype(np.float32); W1 = (rng.standard_normal((EA, E1)) * 0.1).astype(np.float32)
+    X2 = rng.standard_normal((N, EA)).astype(np.float32); W2 = (rng.standard_normal((EB, EA)) * 0.3).astype(np.float32)
+    Pr = rng.random((N, EB)).astype(np.float32); T = (rng.random((N, EB)) > 0.9).astype(np.float32)
+    M = ((rng.random((N, EA)) > 0.5) * 1.0).astype(np.float32)
+    DW1 = rng.standard_normal((EA, E1)).astype(np.float32); DB1 = rng.standard_normal(EA).astype(np.float32)
+    DW2 = rng.standard_normal((EB, EA)).astype(np.float32); DB2 = rng.standard_normal(EB).astype(np.float32)
+    G2 = Pr - T
+    DX2 = np.zeros_like(X2); DW2r, DB2r = DW2.copy(), DB2.copy()
+    assert o.t4o_linear_bwd(P(X2), P(W2), P(G2), P(DX2), P(DW2r), P(DB2r), N, EB, EA, 1) == 0
+    G1 = (DX2 * M).astype(np.float32)
+    DX1 = np.zeros_like(X1); DW1r, DB1r = DW1.copy(), DB1.copy()
+    assert o.t4o_linear_bwd(P(X1), P(W1), P(np.ascontiguousarray(G1)), P(DX1), P(DW1r), P(DB1r), N, EA, E1, 1) == 0
+    for rep_ in range(2):
+        d = {k: dev.up(v) for k, v in dict(X1=X1, W1=W1, X2=X2, W2=W2, P=Pr, T=T, M=M, DW1=DW1, DB1=DB1, DW2=DW2, DB2=DB2).items()}
+        d["Y1"] = dev.zeros((N, EA)); d["Y2"] = dev.zeros((N, EB))
+        t4k.call("t4k_mlp_head_bwd", p(d["X2"]), p(d["W2"]), p(d["P"]), p(d["T"]), p(d["Y2"]), p(d["M"]), p(d["Y1"]), p(d["DW2"]), p(d["DB2"]),
+                 p(d["X1"]), p(d["W1"]), p(d["DW1"]), p(d["DB1"]), N, E1, EA, EB, None)
+        assert t4k.lib.t4k_sync(None) == 0
+        assert np.array_equal(dev.down(d["P"]), G2) and np.array_equal(dev.down(d["Y2"]), G2), "rep %d: out -= target" % rep_
+        assert np.array_equal(dev.down(d["X2"]), DX2), "rep %d: dX2 (fmaf chain in the oracle's order)" % rep_
+        assert rel(dev.down(d["Y1"]), G1) < 1e-6, "rep %d: dY1" % rep_
+        assert rel(dev.down(d["DW2"]), DW2r) < RTOL and rel(dev.down(d["DB2"]), DB2r) < RTOL, "rep %d: head gradients" % rep_
+        assert rel(dev.down(d["DW1"]), DW1r) < RTOL, "rep %d: dW1 %.3g" % (rep_, rel(dev.down(d["DW1"]), DW1r))
+        assert rel(dev.down(d["DB1"]), DB1r) < RTOL, "rep %d: dB1 %.3g" % (rep_, rel(dev.down(d["DB1"]), DB1r))
+        assert rel(dev.down(d["X1"]), DX1) < RTOL, "rep %d: dX1 (in place) %.3g" % (rep_, rel(dev.down(d["X1"]), DX1))
+
+
 def test_plu_and_second_destination_entries(t4k, dev, oracle):
     """t4k_plu (packed L\\U + pivots + permutation applied to I), t4k_tt_op2 (second destination) and t4k_conv2d_fwd2 (layer-0 copy)."""
     o = oracle.lib(); P = oracle.P
