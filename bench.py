@@ -305,7 +305,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
-                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": 6, "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
+                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": 5, "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
                        "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None,
                        "final_loss_note": "random images and labels, batch-SUM gradients (reference semantics): a throughput run, not a convergence test; training parity vs the oracle is in tests/"},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,

@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 // kernels, each with 1/16 of the matrix work per wave.
 // Operand layout of v_mfma_f32_32x32x2_f32: lane (l31, h) supplies A[row = l31][k] and B[k][col = l31] for one k per instruction;
 // chunk c covers k = 8c + 4h + {0..3}, as in the LDS kernels above.
-template <bool AKC, bool BKC, int CB, bool ALDS = false>       // ALDS: A points into LDS (ds_read instead of flat loads)
+template <bool AKC, bool BKC, int CB, bool ALDS = false, bool DOA = true, bool DOB = true>       // ALDS: A points into LDS (ds_read instead of flat loads); DOA / DOB: fetch that operand
 __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const float *__restrict__ B, int M, int N, int ldk, int K, int arow, int bcol,
                                           int cbeg, int cend, int h, float (&fa)[CB][4], float (&fb)[CB][4], int kbeg, int lda = -1) {
     if (lda < 0) lda = ldk;                                         // A's row pitch when it is K-contiguous (an operand tile prepared in LDS has its own)
@@ -403,7 +403,8 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
     for (int c = 0; c < CB; c++) {
         const int ch = cbeg + c, k0 = kbeg + ch * 8 + 4 * h;       // K here is the END of this workgroup's k range, kbeg its start
         const bool ok = ch < cend && k0 < K;
-        if (ALDS) {
+        if (!DOA) {}
+        else if (ALDS) {
             typedef __attribute__((address_space(3))) const float lds_f;
             typedef __attribute__((address_space(3))) const v4f lds_v4;
             lds_f *Al = (lds_f *)A;
@@ -422,7 +423,8 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
 #pragma unroll
             for (int j = 0; j < 4; j++) fa[c][j] = (ok && k0 + j < K) ? A[(long)(k0 + j) * M + arow] : 0.f;
         }
-        if (BKC) {                                                  // B stored [N][K]
+        if (!DOB) {}
+        else if (BKC) {                                                  // B stored [N][K]
             const v4f z = {0.f, 0.f, 0.f, 0.f};
             const v4f t = ok ? *reinterpret_cast<const v4f *>(B + (long)bcol * ldk + k0) : z;
             fb[c][0] = t[0]; fb[c][1] = t[1]; fb[c][2] = t[2]; fb[c][3] = t[3];
@@ -432,12 +434,13 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
         }
     }
 }
-template <bool AKC, bool BKC, int CB, int NW = 4, bool ALDS = false>   // NW waves = NW k-groups per 32x32 tile; ALDS: the A tile was prepared in LDS
+struct NoPro { __device__ void operator()() const {} };
+template <bool AKC, bool BKC, int CB, int NW = 4, bool ALDS = false, typename PRO = NoPro>   // NW waves = NW k-groups per 32x32 tile; ALDS: the A tile is prepared in LDS by `pro`, which runs while the first B fragments are in flight
 __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, float *red,
                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
                                               const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0,
                                               const int by = 0, const FoldRider *fe = nullptr, const ActEpi *ep1 = nullptr,
-                                              const float *Alds = nullptr, const int Ald = 0) {      // Alds: this tile's 32 rows of A, prepared in LDS by the caller ([k][32] or [32][Ald])
+                                              const float *Alds = nullptr, const int Ald = 0, PRO pro = PRO()) {      // Alds: this tile's 32 rows of A in LDS ([k][32] or [32][Ald]), filled by pro()
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int M = p.M, N = p.N, K = p.K;
     const int kbeg = by * p.kchunk, kend = min(K, kbeg + p.kchunk);      // this workgroup's k range (split-K: slab `by`)
@@ -492,8 +495,13 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(slots + 4 * bx + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    if (ALDS) {                                                   // the first B fragments fly while the workgroup prepares its A tile (barriers inside: every thread calls pro)
+        if (c0 < c1) s32_fetch<AKC, BKC, CB, ALDS, false, true>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
+        pro();
+    }
     if (c0 < c1) {
-        s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
+        if (ALDS) s32_fetch<AKC, BKC, CB, ALDS, true, false>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
+        else      s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
         for (int cb = c0; cb < c1; cb += 2 * CB) {
             if (cb + CB < c1) s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, cb + CB, c1, h, fa1, fb1, kbeg, Ald_);
             else arrive();
@@ -612,6 +620,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         const bool first = bx < nb1;                                 // dW1 tile: rows e0..e0+31 of dY1^T, all n;  dX1 tile: rows n0..n0+31 of dY1, all e
         const int tb = first ? bx : bx - nb1;
         const int r0 = (first ? tb / p1.tiles_n : tb / p2.tiles_n) * 32;
+        auto pro = [&]() __attribute__((always_inline)) {
         const int EAp = (EA + 3) & ~3, nel = first ? N * 32 : 32 * EAp;
         constexpr int MQ = 16;                                       // mask values per thread fetched with the operands (N <= 128 rows or EAp <= 128 columns per pass; the rest in a second pass)
         for (int i = tid; i < N * EB; i += 256) d2[i] = hb.P[i] - hb.T[i];
@@ -642,9 +651,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                 }
             }
         }
-        __syncthreads();
-        if (first) gemm_s32_body<false, false, CB, 4, true>(p1, bx, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, 32);
-        else       gemm_s32_body<true, false, CB, 4, true>(p2, bx - nb1, red, nullptr, slots ? 2 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, (EA + 3) & ~3);
+            __syncthreads();
+        };
+        if (first) gemm_s32_body<false, false, CB, 4, true>(p1, bx, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, 32, pro);
+        else       gemm_s32_body<true, false, CB, 4, true>(p2, bx - nb1, red, nullptr, slots ? 2 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, (EA + 3) & ~3, pro);
         return;
     }
     // ---- head riders: column slices of the head's input (see k_linsmall_bwd_cols)

@@ -101,7 +101,7 @@ void (*Model::grad_hook)(int, long, long, void *) = nullptr;
 void *Model::grad_hook_user = nullptr;
 bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
 bool Model::use_stack  = getenv("T4_STACK") ? atoi(getenv("T4_STACK")) != 0 : true;
-bool Model::use_head_bwd = getenv("T4_HEAD_BWD") ? atoi(getenv("T4_HEAD_BWD")) != 0 : false;    // T4_HEAD_BWD=1: classifier-head backward and the linear layer in front of it in one launch (measured: no faster than the two)
+bool Model::use_head_bwd = getenv("T4_HEAD_BWD") ? atoi(getenv("T4_HEAD_BWD")) != 0 : true;     // T4_HEAD_BWD=0: classifier-head backward and the linear layer in front of it as separate launches
 bool Model::use_stack_head = getenv("T4_STACK_HEAD") ? atoi(getenv("T4_STACK_HEAD")) != 0 : true;   // T4_STACK_HEAD=0: the classifier head behind a conv stack keeps its own launches
 bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;

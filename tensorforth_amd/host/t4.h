@@ -284,7 +284,7 @@ private:
     std::vector<char> stack_fresh_;            // per first-op index: the latest forward took the stack kernel (so what it saved for the backward is current)
     std::vector<int> stack_end_;              // last op of a conv stack -> its first op (run_backward), rebuilt after finalize
     bool stack_single_ = false;                // single-stage stacks too (measured: off)
-    static bool use_head_bwd;                  // T4_HEAD_BWD=1: head backward and the linear layer in front of it in one launch (off by default)
+    static bool use_head_bwd;                  // T4_HEAD_BWD=0: head backward and the linear layer in front of it as separate launches
     int also_ready_ = -1;                      // a second layer whose gradients the last bstep launch produced (run_backward reports it)
     static bool use_stack_head;                // T4_STACK_HEAD=0: conv stack and classifier head as separate launches
     static bool use_stack;                     // T4_STACK=0: no sample-resident conv stacks (csrc/conv_stack.hip)
