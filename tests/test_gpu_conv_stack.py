@@ -370,3 +370,35 @@ def test_conv_stack_with_classifier_head_in_one_launch(t4k, dev, oracle, case, E
             assert rel(dev.down(d["Am"]), Am) < RTOL, "rep %d activation" % rep
         assert rel(dev.down(d["Y2"]), Y2) < RTOL, "rep %d linear 2: %.3g" % (rep, rel(dev.down(d["Y2"]), Y2))
         assert rel(dev.down(d["P"]), Pr) < RTOL, "rep %d softmax: %.3g" % (rep, rel(dev.down(d["P"]), Pr))
+
+
+def test_lenet_steps_while_another_stream_hogs_the_device_are_deterministic():
+    """The one-launch forward (bands meet through epoch-tagged words, the last band polls) and the fused head backward (a counter in front of the
+    in-place `out -= target`) hold inter-workgroup waits.  Forty training steps of the LeNet net at batch 128 run twice from the same seed -
+    once on an idle device, once while a bandwidth-hogging kernel chain occupies it on another stream (what a concurrent RCCL kernel does):
+    no bounded wait may give up (t4k_sync reports that) and every parameter must come out bit-identical."""
+    import torch
+    from lenet_parity import PARAMS, _get, _setup
+    from tensorforth_amd import lib as t4lib
+    from tensorforth_amd.vm import VM
+    k = t4lib.load()
+    res = []
+    for hog in (False, True):
+        vm = VM(device=0, seed=4242)
+        try:
+            _setup(vm, 128, 0, 128)
+            side = torch.cuda.Stream(); big = torch.zeros(256 << 20 >> 2, device="cuda")
+            for _ in range(4):
+                if hog:
+                    with torch.cuda.stream(side):
+                        for _ in range(30):
+                            big.mul_(1.0001).add_(1.0)
+                vm.eval("net fw bw opt fw bw opt fw bw opt fw bw opt fw bw opt fw bw opt fw bw opt fw bw opt fw bw opt fw bw opt drop\n")
+            assert k.lib.t4k_sync(None) == 0, k.lib.t4k_last_error()
+            torch.cuda.synchronize()
+            res.append({n_: _get(vm, e) for n_, e in PARAMS})
+        finally:
+            vm.close()
+    for n_ in res[0]:
+        assert np.isfinite(res[0][n_]).all()
+        assert np.array_equal(res[0][n_], res[1][n_]), "%s differs between the idle and the busy device" % n_
