@@ -366,6 +366,11 @@ int t4k_linear_block_fwd(const float *X, float *XCOPY, const float *W, const flo
 int t4k_mlp_head_bwd_ok(int N, int E1, int E0a, int E0b);
 int t4k_mlp_head_bwd(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const float *MASK, float *Y1, float *DW2, float *DB2,
                      float *X1, const float *W1, float *DW1, float *DB1, int N, int E1, int E0a, int E0b, t4k_stream_t s);
+/* t4k_mlp_head_bwd with element-wise RUNS of one or two mask-multiply layers (t4k_poolblock, no pool / flatten) instead of the single mask layer:
+ * run2 in front of the head layer (XRUN2 = the run's input tensor = the big layer's output), run1 in front of the big layer (NULL: none).
+ * train = 0: a frozen net, dX only (gradient tensors may be NULL). */
+int t4k_mlp_block_bwd(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const t4k_poolblock *run2, float *XRUN2, float *DW2, float *DB2,
+                      float *X1, const float *W1, const t4k_poolblock *run1, float *XRUN1, float *DW1, float *DB1, int N, int E1, int E0a, int E0b, int train, t4k_stream_t s);
 int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float *TGT, float *DY2, float *DX, const t4k_poolblock *blk, float *XRUN,
                          float *DW, float *DB, int N, int E0, int E1, int train, t4k_stream_t s);
 /* classifier head in one call: [linear E1 -> H + element-wise layer] + [linear H -> E2 (+ softmax when P2 != NULL)] =

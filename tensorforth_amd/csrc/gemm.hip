@@ -608,6 +608,8 @@ struct HeadBwd {
     float *X2, *DW2, *DB2, *Y1, *Y2;    // head input [N][EA] (receives dX2), gradients, dY1 tensor (= dX2 * mask), second copy of out - target
     float *DB1;
     int N, EA, EB, train, nwg; int *sync;
+    const float *MSKB; float *Y1B;     // a second mask layer between the linear layers (`leakyrelu dropout`): dY1 = dX2 * MASK * MSKB, Y1 keeps the first product, Y1B the second
+    MaskChain mc1;                      // mask multiplies behind the big layer's dX1 (the run in front of it), as linear_bwd_dual
 };
 template <int CB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_head_bwd_dual32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, HeadBwd hb) {
@@ -632,7 +634,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                 const int i = base + tid + q * 256;
                 int n, e;
                 if (first) { n = i >> 5; e = min(r0 + (i & 31), EA - 1); } else { const int r = i / EAp; e = min(i - r * EAp, EA - 1); n = min(r0 + r, N - 1); }
-                mk[q] = i < nel ? hb.MASK[(long)min(n, N - 1) * EA + e] : 0.f;
+                const long zo = (long)min(n, N - 1) * EA + e;
+                mk[q] = i < nel ? (hb.MSKB ? hb.MASK[zo] * hb.MSKB[zo] : hb.MASK[zo]) : 0.f;
             }
             if (base == 0) {
                 __syncthreads();
@@ -654,7 +657,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             __syncthreads();
         };
         if (first) gemm_s32_body<false, false, CB, 4, true>(p1, bx, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, 32, pro);
-        else       gemm_s32_body<true, false, CB, 4, true>(p2, bx - nb1, red, nullptr, slots ? 2 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, (EA + 3) & ~3, pro);
+        else       gemm_s32_body<true, false, CB, 4, true>(p2, bx - nb1, red, nullptr, slots ? 2 : 0, t1, t2, hb.mc1.d1 ? &hb.mc1 : nullptr, slots, epoch, 0, nullptr, nullptr, Ad, (EA + 3) & ~3, pro);
         return;
     }
     // ---- head riders: column slices of the head's input (see k_linsmall_bwd_cols)
@@ -685,6 +688,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             const long o = (long)n * EA + c0 + c;
             hb.X2[o] = acc;
             g1 = acc * hb.MASK[o]; hb.Y1[o] = g1;
+            if (hb.MSKB) { g1 *= hb.MSKB[o]; hb.Y1B[o] = g1; }
         }
         Xs[z] = g1;
     }
@@ -695,16 +699,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             float a = dwacc;
             for (int g = 1; g < G; g++) a += rd2[g * nout + tid];
             if (c < cw) hb.DW2[(long)j * EA + c0 + c] += a;
-        } else if (tid < nout + CW) {                                // dB1[c0 + c] = sum_n dY1[n, c0 + c] (k_dlinear_db nmath.cu:274-280)
-            const int c = tid - nout;
+        }
+        __syncthreads();                                             // rd2 is free again
+        {   // dB1[c0 + c] = sum_n dY1[n, c0 + c] (k_dlinear_db nmath.cu:274-280): 32 row groups per column, then the groups in order
+            const int c = tid & (CW - 1), g = tid >> 3;
             float b = 0.f;
-            for (int n = 0; n < N; n++) b += Xs[n * CW + c];
-            if (c < cw) hb.DB1[c0 + c] += b;
-        } else if (cb == 0 && tid - nout - CW < EB) {                // dB2[j] = sum_n dY2[n, j]
-            const int j = tid - nout - CW;
+#pragma unroll 4
+            for (int n = g; n < N; n += 32) b += Xs[n * CW + c];
+            rd2[g * CW + c] = b;
+        }
+        __syncthreads();
+        if (tid < CW) {
             float b = 0.f;
-            for (int n = 0; n < N; n++) b += dys[n * EB + j];
-            hb.DB2[j] += b;
+#pragma unroll
+            for (int g = 0; g < 32; g++) b += rd2[g * CW + tid];
+            if (tid < cw) hb.DB1[c0 + tid] += b;
+        }
+        if (cb == 0) {                                               // dB2[j] = sum_n dY2[n, j]: 16 row groups per output
+            __syncthreads();
+            const int j = tid & 15, g = tid >> 4;
+            float b = 0.f;
+            if (j < EB) {
+#pragma unroll 4
+                for (int n = g; n < N; n += 16) b += dys[n * EB + j];
+            }
+            rd2[g * 16 + j] = b;
+            __syncthreads();
+            if (tid < EB) {
+                float t = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < 16; g2++) t += rd2[g2 * 16 + tid];
+                hb.DB2[tid] += t;
+            }
         }
     }
     if (cb == 0) {                                                   // `out -= target` in place (+ its copy), once every workgroup has read out / target
@@ -2217,42 +2243,70 @@ int t4k_mlp_head_bwd_ok(int N, int E1, int EA, int EB) {
     if (per_cu < 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_head_bwd_dual32<8>, 256, 48 * 1024) != hipSuccess || nb < 1) nb = 1; per_cu = nb; }
     return (a1 + a2 + nc <= (long)per_cu * st().cu_count - 32 && a1 <= 512) ? 1 : 0;      // every workgroup resident (the in-place gate and the target store spin)
 }
-int t4k_mlp_head_bwd(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const float *MASK, float *Y1, float *DW2, float *DB2,
-                     float *X1, const float *W1, float *DW1, float *DB1, int N, int E1, int EA, int EB, t4k_stream_t s) {
-    T4K_REQUIRE_INIT();
-    if (!X2 || !W2 || !P || !TGT || !MASK || !Y1 || !DW2 || !DB2 || !X1 || !W1 || !DW1 || !DB1) return fail(T4K_ERR_ARG, "t4k_mlp_head_bwd: null argument");
-    hipStream_t hs = S(s);
+static int head_bwd_launch(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const MaskChain &mc2, float *DW2, float *DB2,
+                           float *X1, const float *W1, const MaskChain &mc1, float *DW1, float *DB1, int N, int E1, int EA, int EB, bool train, hipStream_t hs, const char *who) {
     int *gate = gate_for(hs, 0);
-    if (!t4k_mlp_head_bwd_ok(N, E1, EA, EB) || !gate || capturing(hs) || !aligned16(X1) || !aligned16(W1) || !aligned16(Y1))
-        return fail(T4K_ERR_UNSUPPORTED, "t4k_mlp_head_bwd: shapes do not qualify (t4k_mlp_head_bwd_ok)");
+    float *DY1 = mc2.d2 ? mc2.d2 : mc2.d1;                        // what the big layer differentiates against: the product of all masks
+    if (!t4k_mlp_head_bwd_ok(N, E1, EA, EB) || !gate || capturing(hs) || !aligned16(X1) || !aligned16(W1) || !aligned16(DY1))
+        return fail(T4K_ERR_UNSUPPORTED, "%s: shapes do not qualify (t4k_mlp_head_bwd_ok)", who);
     State &g = st();
     auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
-    const long a1 = t32(EA, E1), a2 = t32(N, E1), nc = (EA + 7) / 8;
+    const long a1 = train ? t32(EA, E1) : 0, a2 = t32(N, E1), nc = (EA + 7) / 8;
     GemmP q1, q2;
     auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
         p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
         p.tiles_m = (M + 31) / 32; p.tiles_n = (Nn + 31) / 32; p.kchunk = K; p.nsplit = 1;
         p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
     };
-    fill32(q1, Y1, X1, DW1, EA, E1, N, 1.0f);                     // dW1 += dY1^T X1   (A comes from LDS: the pointer is not read)
-    fill32(q2, Y1, W1, X1, N, E1, EA, 0.0f);                      // dX1 = dY1 W1, over X1 (backprop.cu:240)
-    unsigned *slots = reinterpret_cast<unsigned *>(gate) + 512;   // arrival slots of the in-place dX (as linear_bwd_dual)
-    static unsigned epochs[64];
-    const int li = lane_of(hs);
-    unsigned epoch = ++epochs[li < 63 ? li : 63];
-    if (epoch == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); epoch = ++epochs[li < 63 ? li : 63]; }
-    HeadBwd hb = { P, TGT, W2, MASK, X2, DW2, DB2, Y1, Y2, DB1, N, EA, EB, 1, (int)(a1 + a2 + nc), gate };
+    fill32(q1, DY1, X1, DW1, EA, E1, N, 1.0f);                    // dW1 += dY1^T X1   (A comes from LDS: the pointer is not read)
+    fill32(q2, DY1, W1, X1, N, E1, EA, 0.0f);                     // dX1 = dY1 W1, over X1 (backprop.cu:240)
+    unsigned *slots = nullptr; unsigned epoch = 0;
+    if (train) {                                                  // arrival slots of the in-place dX (as linear_bwd_dual); a frozen layer has no dW readers to wait for
+        slots = reinterpret_cast<unsigned *>(gate) + 512;
+        static unsigned epochs[64];
+        const int li = lane_of(hs);
+        epoch = ++epochs[li < 63 ? li : 63];
+        if (epoch == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); epoch = ++epochs[li < 63 ? li : 63]; }
+    }
+    HeadBwd hb = { P, TGT, W2, mc2.m1, X2, DW2, DB2, mc2.d1, Y2, DB1, N, EA, EB, train ? 1 : 0, (int)(a1 + a2 + nc), gate, mc2.m2, mc2.d2, mc1 };
     const int EAp = (EA + 3) & ~3;
     const size_t lt = (size_t)((N * EB + 3) & ~3) + (size_t)((EB * EA + 3) & ~3) + (size_t)std::max(N * 32, 32 * EAp);
     const size_t lr = (size_t)N * EB + (size_t)EB * 8 + (size_t)N * 8 + 256;
     const size_t lds = sizeof(float) * std::max(lt, lr);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_dual32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
-                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_dual32<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); attr = true; }
-    if (lds > 48 * 1024) return fail(T4K_ERR_UNSUPPORTED, "t4k_mlp_head_bwd: %zu bytes of LDS", lds);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_dual32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); attr = true; }
+    if (lds > 48 * 1024) return fail(T4K_ERR_UNSUPPORTED, "%s: %zu bytes of LDS", who, lds);
     hipLaunchKernelGGL(k_head_bwd_dual32<8>, dim3((unsigned)(a1 + a2 + nc)), dim3(256), lds, hs, q1, q2, (int)a1, (int)a1, (int)a2, slots, epoch, hb);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
+}
+int t4k_mlp_head_bwd(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const float *MASK, float *Y1, float *DW2, float *DB2,
+                     float *X1, const float *W1, float *DW1, float *DB1, int N, int E1, int EA, int EB, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X2 || !W2 || !P || !TGT || !MASK || !Y1 || !DW2 || !DB2 || !X1 || !W1 || !DW1 || !DB1) return fail(T4K_ERR_ARG, "t4k_mlp_head_bwd: null argument");
+    const MaskChain mc2 = { MASK, Y1, nullptr, nullptr }, none = { nullptr, nullptr, nullptr, nullptr };
+    return head_bwd_launch(X2, W2, P, TGT, Y2, mc2, DW2, DB2, X1, W1, none, DW1, DB1, N, E1, EA, EB, true, S(s), "t4k_mlp_head_bwd");
+}
+// The same with element-wise RUNS instead of a single mask layer (the GAN nets: `leakyrelu dropout` between the linear layers): run2 stands in front of the
+// head layer (it produced X2; its backward lands in its own tensors, the run's input tensor XRUN2 = the big layer's output receives dY1), run1 in front of
+// the big layer (NULL: none; its mask multiplies ride in the dX1 epilogue into run1's tensors / XRUN1).  train = 0: a frozen net (no dW / dB, DW* may be NULL).
+int t4k_mlp_block_bwd(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const t4k_poolblock *run2, float *XRUN2, float *DW2, float *DB2,
+                      float *X1, const float *W1, const t4k_poolblock *run1, float *XRUN1, float *DW1, float *DB1, int N, int E1, int EA, int EB, int train, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!X2 || !W2 || !P || !TGT || !run2 || !XRUN2 || !X1 || !W1) return fail(T4K_ERR_ARG, "t4k_mlp_block_bwd: null argument");
+    if (train && (!DW2 || !DB2 || !DW1 || !DB1)) return fail(T4K_ERR_ARG, "t4k_mlp_block_bwd: a training pass needs the gradient tensors");
+    auto chain = [&](const t4k_poolblock *b, float *xrun, MaskChain &mc) -> bool {
+        mc = MaskChain{nullptr, nullptr, nullptr, nullptr};
+        if (!b) return true;
+        if (b->pool_layer || b->copy_out || b->KS != 1 || (!b->pre_layer && !b->post_layer) || !xrun) return false;
+        if ((b->pre_layer && (!b->pre_mask || (b->post_layer && !b->pre_out))) || (b->post_layer && !b->post_mask)) return false;
+        if (b->post_layer) { mc.m1 = b->post_mask; mc.d1 = b->pre_layer ? b->pre_out : xrun; if (b->pre_layer) { mc.m2 = b->pre_mask; mc.d2 = xrun; } }
+        else               { mc.m1 = b->pre_mask; mc.d1 = xrun; }
+        return true;
+    };
+    MaskChain mc2, mc1;
+    if (!chain(run2, XRUN2, mc2) || !mc2.d1 || !chain(run1, XRUN1, mc1)) return fail(T4K_ERR_UNSUPPORTED, "t4k_mlp_block_bwd: the runs must be one or two mask-multiply layers without pool / flatten");
+    return head_bwd_launch(X2, W2, P, TGT, Y2, mc2, DW2, DB2, X1, W1, mc1, DW1, DB1, N, E1, EA, EB, train != 0, S(s), "t4k_mlp_block_bwd");
 }
 
 int t4k_gemm_f64acc(const float *A, const float *B, float *O, float alpha, float beta,

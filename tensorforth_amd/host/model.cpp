@@ -729,6 +729,24 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
             if (fused && i > 1 && run_of_[i - 2] >= 0 && runs_[run_of_[i - 2]].count == 2 && !runs_[run_of_[i - 2]].blk.pool_layer &&
                 !runs_[run_of_[i - 2]].blk.copy_out) {
                 const Run &r = runs_[run_of_[i - 2]];
+                // the linear layer in front of that run joins the launch when it is the net's first layer or has such a run of its own in front (the GAN
+                // discriminator: linear, leakyrelu, dropout, linear, leakyrelu, dropout, linear, sigmoid) - t4k_mlp_block_bwd, see t4k_mlp_head_bwd
+                // (measured on the GAN nets, N = 256, 256-wide runs: 28.5 us against 9 + 11.7 us apart - re-reading two 256 KB masks per tile costs more than
+                // reading the finished dY1; opt-in with T4_HEAD_BWD=2)
+                static const bool runs_too = getenv("T4_HEAD_BWD") && atoi(getenv("T4_HEAD_BWD")) >= 2;
+                if (tg && use_head_bwd && runs_too && i >= 3 && at(i - 3).grad_fn == T4K_L_LINEAR && (!train || (at(i - 3).grad[2] && at(i - 3).grad[3]))) {
+                    Tensor &big = at(i - 3);
+                    const Run *r1 = nullptr;
+                    if (i >= 5 && run_of_[i - 5] >= 0 && runs_[run_of_[i - 5]].count == 2 && !runs_[run_of_[i - 5]].blk.pool_layer && !runs_[run_of_[i - 5]].blk.copy_out) r1 = &runs_[run_of_[i - 5]];
+                    if ((r1 || i == 3) && t4k_mlp_head_bwd_ok(N, (int)big.HWC(), E1, E0)) {
+                        chk(t4k_mlp_block_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, &r.blk, at(i - 2).data,
+                                              train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr,
+                                              big.data, big.grad[0]->data, r1 ? &r1->blk : nullptr, r1 ? at(i - 5).data : nullptr,
+                                              train ? big.grad[2]->data : nullptr, train ? big.grad[3]->data : nullptr, N, (int)big.HWC(), E1, E0, train, s), "nn#bhead+run+blinear");
+                        skip_next_ = true; skip_cnt_ = r1 ? 5 : 3; also_ready_ = i - 3;
+                        return r1 ? at(i - 5).data : big.data;
+                    }
+                }
                 chk(t4k_linear_block_bwd(in.data, in.grad[0]->data, (float *)dy, tg, tg ? at(-2).data : nullptr, in.data, &r.blk, at(i - 2).data,
                                          train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr, N, E0, E1, train, s), "nn#blinear+run");
                 skip_next_ = true; skip_cnt_ = 2;

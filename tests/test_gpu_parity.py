@@ -725,6 +725,57 @@ def test_head_backward_and_the_linear_layer_in_front_in_one_launch(t4k, dev, ora
         assert rel(dev.down(d["X1"]), DX1) < RTOL, "rep %d: dX1 (in place) %.3g" % (rep_, rel(dev.down(d["X1"]), DX1))
 
 
+@pytest.mark.parametrize("N,E1,EA,EB,run1,train", [(256, 512, 256, 1, True, 1), (256, 512, 256, 1, True, 0), (256, 784, 512 // 2, 1, False, 1), (64, 128, 96, 4, True, 1)])
+def test_head_backward_with_runs_and_the_linear_layer_in_front_in_one_launch(t4k, dev, oracle, N, E1, EA, EB, run1, train):
+    """t4k_mlp_block_bwd: the GAN discriminator's tail - linear, [leakyrelu, dropout], linear, (sigmoid) - differentiated in one launch: head
+    (out -= target, dW2 | dB2, dX2 in place), the run's two mask multiplies (both intermediate tensors stored), the big layer's dW1 | dB1 and
+    dX1 in place, and the mask multiplies of the run in front of THAT layer in its dX epilogue; frozen variant (train = 0: dX only).  Against the
+    oracle's linear backward + numpy mask products, 1e-4 relative, twice in a row."""
+    if t4k.lib.t4k_mlp_head_bwd_ok(N, E1, EA, EB) != 1:
+        pytest.skip("shape does not qualify on this device")
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N + E1 + EA + train)
+    X1 = rng.standard_normal((N, E1)).astype(np.float32); W1 = (rng.standard_normal((EA, E1)) * 0.1).astype(np.float32)
+    X2 = rng.standard_normal((N, EA)).astype(np.float32); W2 = (rng.standard_normal((EB, EA)) * 0.3).astype(np.float32)
+    Pr = rng.random((N, EB)).astype(np.float32); T = (rng.random((N, EB)) > 0.5).astype(np.float32)
+    Mdrop = ((rng.random((N, EA)) > 0.4) * 1.0).astype(np.float32); Mleak = np.where(rng.random((N, EA)) > 0.5, 1.0, 0.2).astype(np.float32)
+    M1d = ((rng.random((N, E1)) > 0.4) * 1.0).astype(np.float32); M1l = np.where(rng.random((N, E1)) > 0.5, 1.0, 0.2).astype(np.float32)
+    DW1 = rng.standard_normal((EA, E1)).astype(np.float32); DB1 = rng.standard_normal(EA).astype(np.float32)
+    DW2 = rng.standard_normal((EB, EA)).astype(np.float32); DB2 = rng.standard_normal(EB).astype(np.float32)
+    G2 = Pr - T
+    DX2 = np.zeros_like(X2); DW2r, DB2r = DW2.copy(), DB2.copy()
+    assert o.t4o_linear_bwd(P(X2), P(W2), P(G2), P(DX2), P(DW2r), P(DB2r), N, EB, EA, train) == 0
+    D1 = (DX2 * Mdrop).astype(np.float32); D2 = (D1 * Mleak).astype(np.float32)          # dropout is the run's second layer: its mask comes first on the way back
+    DX1 = np.zeros_like(X1); DW1r, DB1r = DW1.copy(), DB1.copy()
+    assert o.t4o_linear_bwd(P(X1), P(W1), P(np.ascontiguousarray(D2)), P(DX1), P(DW1r), P(DB1r), N, EA, E1, train) == 0
+    E1d = (DX1 * M1d).astype(np.float32); E2d = (E1d * M1l).astype(np.float32)
+    for rep_ in range(2):
+        d = {k: dev.up(v) for k, v in dict(X1=X1, W1=W1, X2=X2, W2=W2, P=Pr, T=T, Mdrop=Mdrop, Mleak=Mleak, M1d=M1d, M1l=M1l, DW1=DW1, DB1=DB1, DW2=DW2, DB2=DB2).items()}
+        for k_, shp in (("Y2", (N, EB)), ("R2pre", (N, EA)), ("R2in", (N, EA)), ("R1pre", (N, E1)), ("R1in", (N, E1))):
+            d[k_] = dev.zeros(shp)
+        b2 = PoolBlock(); b2.KS = 1
+        b2.pre_layer, b2.pre_alpha, b2.pre_mask, b2.pre_out = oracle.L_LEAKYRL, 0.2, p(d["Mleak"]), p(d["R2pre"])
+        b2.post_layer, b2.post_alpha, b2.post_mask, b2.post_out = oracle.L_DROPOUT, 0.4, p(d["Mdrop"]), p(d["X2"])
+        b1 = PoolBlock(); b1.KS = 1
+        b1.pre_layer, b1.pre_alpha, b1.pre_mask, b1.pre_out = oracle.L_LEAKYRL, 0.2, p(d["M1l"]), p(d["R1pre"])
+        b1.post_layer, b1.post_alpha, b1.post_mask, b1.post_out = oracle.L_DROPOUT, 0.4, p(d["M1d"]), p(d["X1"])
+        t4k.call("t4k_mlp_block_bwd", p(d["X2"]), p(d["W2"]), p(d["P"]), p(d["T"]), p(d["Y2"]), ctypes.byref(b2), p(d["R2in"]),
+                 p(d["DW2"]) if train else None, p(d["DB2"]) if train else None, p(d["X1"]), p(d["W1"]), ctypes.byref(b1) if run1 else None, p(d["R1in"]) if run1 else None,
+                 p(d["DW1"]) if train else None, p(d["DB1"]) if train else None, N, E1, EA, EB, train, None)
+        assert t4k.lib.t4k_sync(None) == 0
+        assert np.array_equal(dev.down(d["P"]), G2) and np.array_equal(dev.down(d["Y2"]), G2), "rep %d: out -= target" % rep_
+        assert np.array_equal(dev.down(d["X2"]), DX2), "rep %d: dX2" % rep_
+        assert rel(dev.down(d["R2pre"]), D1) < 1e-6 and rel(dev.down(d["R2in"]), D2) < 1e-6, "rep %d: the run's two products" % rep_
+        assert rel(dev.down(d["X1"]), DX1) < RTOL, "rep %d: dX1 %.3g" % (rep_, rel(dev.down(d["X1"]), DX1))
+        if run1:
+            assert rel(dev.down(d["R1pre"]), E1d) < RTOL and rel(dev.down(d["R1in"]), E2d) < RTOL, "rep %d: mask chain behind dX1" % rep_
+        if train:
+            assert rel(dev.down(d["DW2"]), DW2r) < RTOL and rel(dev.down(d["DB2"]), DB2r) < RTOL, "rep %d: head gradients" % rep_
+            assert rel(dev.down(d["DW1"]), DW1r) < RTOL and rel(dev.down(d["DB1"]), DB1r) < RTOL, "rep %d: dW1 / dB1" % rep_
+        else:
+            assert np.array_equal(dev.down(d["DW1"]), DW1) and np.array_equal(dev.down(d["DW2"]), DW2), "rep %d: a frozen net's gradients were touched" % rep_
+
+
 def test_plu_and_second_destination_entries(t4k, dev, oracle):
     """t4k_plu (packed L\\U + pivots + permutation applied to I), t4k_tt_op2 (second destination) and t4k_conv2d_fwd2 (layer-0 copy)."""
     o = oracle.lib(); P = oracle.P
