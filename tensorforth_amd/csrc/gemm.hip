@@ -2235,7 +2235,7 @@ int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float 
 int t4k_mlp_head_bwd_ok(int N, int E1, int EA, int EB) {
     if (!st().ready) return 0;
     static int on = -1; if (on < 0) { const char *e = getenv("T4K_HEAD_BWD"); on = e ? atoi(e) : 1; }
-    if (!on || capturing(nullptr) || st().capturing || !st().d_sync || !dual_on()) return 0;
+    if (!on || st().capturing || !st().d_sync || !dual_on()) return 0;
     if (N < 1 || N > 256 || EA < 4 || EA > 256 || (EA & 3) || EB < 1 || EB > 16 || E1 < 4 || (E1 & 3)) return 0;
     auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
     const long a1 = t32(EA, E1), a2 = t32(N, E1), nc = (EA + 7) / 8;
