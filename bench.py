@@ -24,9 +24,9 @@ sys.path.insert(0, ROOT)
 BASELINE_METRIC = 'CNN train images/sec + fp32 GEMM TFLOP/s (% MI355X MFMA peak), 1→8 GPUs'    # BASELINE.json "metric"
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
-STEP_TRAFFIC_BYTES = 58350917    # HBM-side bytes per CNN step: sum over the step's 5 kernels in profiles/r03_bench_pmc_hbm.txt (24.0 MB read, x2-corrected, + 34.4 MB written;
+STEP_TRAFFIC_BYTES = 58377856    # HBM-side bytes per CNN step: sum over the step's 5 kernels in profiles/r03_bench_pmc_hbm.txt (24.0 MB read, x2-corrected, + 34.4 MB written;
                                  # algorithmic 66.15 MB: the activations the backward re-reads come partly out of the Infinity Cache)
-GEMM_TRAFFIC_BYTES = 29425526    # fabric-side bytes per 1024^3 launch from the PMC pass (25.2 MB read + 4.2 MB written; algorithmic minimum 12.6 MB;
+GEMM_TRAFFIC_BYTES = 29425317    # fabric-side bytes per 1024^3 launch from the PMC pass (25.2 MB read + 4.2 MB written; algorithmic minimum 12.6 MB;
                                  # the reads are at the floor of 8 private L2s: every XCD fetches the 1 MB of A rows + 2 MB of B columns of its 4 x 8 tile band)
 # algorithmic bytes per image and parameter count (SURVEY.md 8d / BASELINE.md 3)
 NETS = {"nn_f": dict(bytes_per_img=494720, params=101030, flop_per_img=3134160),
