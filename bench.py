@@ -24,10 +24,24 @@ sys.path.insert(0, ROOT)
 BASELINE_METRIC = 'CNN train images/sec + fp32 GEMM TFLOP/s (% MI355X MFMA peak), 1→8 GPUs'    # BASELINE.json "metric"
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
-STEP_TRAFFIC_BYTES = 58377856    # HBM-side bytes per CNN step: sum over the step's 5 kernels in profiles/r03_bench_pmc_hbm.txt (24.0 MB read, x2-corrected, + 34.4 MB written;
-                                 # algorithmic 66.15 MB: the activations the backward re-reads come partly out of the Infinity Cache)
-GEMM_TRAFFIC_BYTES = 29425317    # fabric-side bytes per 1024^3 launch from the PMC pass (25.2 MB read + 4.2 MB written; algorithmic minimum 12.6 MB;
-                                 # the reads are at the floor of 8 private L2s: every XCD fetches the 1 MB of A rows + 2 MB of B columns of its 4 x 8 tile band)
+
+
+def measured_traffic():
+    """HBM-side bytes per launch / per step from the LATEST counter pass under profiles/ (profiles/rNN_bench_traffic.json, written by
+    tools/profile_bench.sh -> tools/traffic_json.py from the TCC_EA0 request counters of a separate --pmc run of this very command, reads
+    x2-corrected on gfx950).  Nothing is pasted by hand: no file -> `traffic` is null."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_traffic.json")))
+    if not fs:
+        return None, None, None
+    try:
+        with open(fs[-1]) as f:
+            d = json.load(f)
+        return d.get("gemm_bytes_per_launch"), d.get("step_bytes"), "profiles/" + os.path.basename(fs[-1]) + " (" + d.get("source", "") + ")"
+    except Exception:
+        return None, None, None
+
+
 # algorithmic bytes per image and parameter count (SURVEY.md 8d / BASELINE.md 3)
 NETS = {"nn_f": dict(bytes_per_img=494720, params=101030, flop_per_img=3134160),
         "nn_c": dict(bytes_per_img=294800, params=197210, flop_per_img=1605360)}
@@ -163,6 +177,7 @@ def main():
     ap.add_argument("--gemm-iters", type=int, default=200)
     ap.add_argument("--sustain-s", type=float, default=3.0, help="length of the sustained loop behind the timed region (seconds; 0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the GAN / dataset-fed / sustained legs")
+    ap.add_argument("--allow-fallback", action="store_true", help="print the line even when the timed step did not take the conv-stack path (default: exit 4)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction plumbing only (gloo, no GPU work, no metric): CPU test of the N-rank path")
     args = ap.parse_args()
 
@@ -274,10 +289,25 @@ def main():
     if args.warmup > 0:
         run(args.warmup)
     barrier()
+    k.lib.t4k_launch_count.restype = ctypes.c_ulonglong
+    l0 = k.lib.t4k_launch_count()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    launches = (k.lib.t4k_launch_count() - l0) / args.steps          # MEASURED: every launch site of the library counts itself
+    # ---- the timed path must be the one `config.workload` describes: the sample-resident conv stack (forward with the classifier head,
+    # banded backward) and the fold inside the optimizer launch.  A box where hipRTC is missing / a compile failed would silently run the
+    # per-layer kernels (12+ launches): say so and fail instead of printing a line that describes another path.
+    cj, cd, cf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    k.lib.t4k_conv_stack_stats.restype = None
+    k.lib.t4k_conv_stack_stats(ctypes.byref(cj), ctypes.byref(cd), ctypes.byref(cf))
+    stack_mode = "off" if (cj.value + cd.value == 0) else ("jit" if cj.value else "prebuilt")
+    want = {"nn_f": 4, "nn_c": 4}[args.net] + (1 if (dp and native) else 0)     # cs_fwd(+head), head backward + linear, cs_bwd_b, optimizer (+ fold); RCCL between them: the fold keeps its launch
+    if not args.allow_fallback and os.environ.get("T4_STACK", "1") != "0" and (stack_mode == "off" or cf.value or launches > want + 0.01):
+        sys.stderr.write("bench: the timed step is NOT the described path: conv_stack=%s (jit %d, cache %d, failed %d), %.2f launches per step (expected <= %d); "
+                         "%s\n(--allow-fallback prints the line anyway)\n" % (stack_mode, cj.value, cd.value, cf.value, launches, want, k.lib.t4k_last_error().decode(errors="replace")[-600:]))
+        sys.exit(4)
     if dp:
         tmax = torch.tensor([dt], device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.cpu()[0])
     ms_step = dt / args.steps * 1e3
@@ -297,6 +327,9 @@ def main():
     out = None
     if rank == 0:
         net = NETS[args.net]
+        gemm_traffic, step_traffic, traffic_src = measured_traffic()
+        if args.net != "nn_f" or N != 128:
+            step_traffic = None                                # the counter pass is of the default workload
         step_bytes = N * net["bytes_per_img"] + 4 * net["params"] * 7            # k_opt = 7 for SGD
         out = {
             "metric": BASELINE_METRIC,   # `value` = CNN train images/sec; the GEMM TFLOP/s (% of MFMA peak) part is the `roofline` object
@@ -305,12 +338,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
-                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": 5, "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
+                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": round(launches, 2), "launches_source": "t4k_launch_count() around the timed loop", "conv_stack": stack_mode, "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
                        "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None,
                        "final_loss_note": "random images and labels, batch-SUM gradients (reference semantics): a throughput run, not a convergence test; training parity vs the oracle is in tests/"},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-                              "traffic": STEP_TRAFFIC_BYTES, "traffic_source": "profiles/r03_bench_pmc_hbm.txt (sum over the step's kernels, TCC_EA0 request counters, reads x2 on gfx950)" if STEP_TRAFFIC_BYTES else None,
+                              "traffic": step_traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_step": step_bytes},
         }
         if sustained:
@@ -339,7 +372,7 @@ def main():
         tf = flops / (avg_ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": "k_gemm_nn_plain (1024^3 fp32 matmul: 64x64 tiles, 8 waves/WG = 2 k-groups x 2x2 v_mfma_f32_32x32x2_f32 accumulator pairs, LDS-DMA from inline asm, 128-deep double-buffered stages)", "bound": "mfma", "achieved": round(tf, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": GEMM_TRAFFIC_BYTES, "traffic_source": "profiles/r03_bench_pmc_hbm.txt (TCC_EA0_RDREQ*64B x2 gfx950 correction + WRREQ_64B*64B, separate --pmc pass)",
+                           "traffic": gemm_traffic, "traffic_source": traffic_src,
                            "avg_launch_us": round(avg_ms * 1e3, 2), "best_launch_us": round(best * 1e3, 2),
                            "flop_per_launch": flops}
         # ---- the same product through the Forth word, reference idiom `for @ drop next` (examples/t4_20a.4th:20-29): per call an arena

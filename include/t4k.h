@@ -78,6 +78,10 @@ int t4k_memcpy_d2h(void *dst, const void *src, size_t bytes, t4k_stream_t s);
 int t4k_memcpy_d2d(void *dst, const void *src, size_t bytes, t4k_stream_t s);
 int t4k_memset(void *dst, int byte, size_t bytes, t4k_stream_t s);   /* Tensor::zeros tensor.cu:558-563 */
 int t4k_sync(t4k_stream_t s);
+/* Kernels launched by the library since t4k_init (every launch site counts itself): measurement hook - bench.py brackets its timed
+ * loop with it and prints the MEASURED launches per step (the reference issues one launch + cudaDeviceSynchronize per layer,
+ * src/nn/forward.cu:82-113, backprop.cu:111-140; memcpy / memset / collective commands are not kernels and are not counted). */
+unsigned long long t4k_launch_count(void);
 
 /* Library streams own a private workspace, so independent work (e.g. dW beside dX) may be forked
  * onto them and still be captured into one graph through event edges. */
@@ -313,7 +317,9 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
  * partials in the library workspace, folded in image order by a second small launch - deterministic).
  * t4k_conv_stack_fwd also leaves, per stack, a copy of every conv input and the pool arg-max codes in library memory; a backward that
  * follows it (same N) runs BANDED - several workgroups per image - on those instead of on layer tensors a neighbouring band overwrites in
- * place.  A caller whose latest forward did NOT go through t4k_conv_stack_fwd must say so with bit 1 of `train` (train | 2): the
+ * place.  Bit 2 of `train` (train | 4) defers the fold of the dF | dB partials to t4k_opt_step (see there); bit 3 (train | 8) lets the
+ * banded kernel skip the dX of stage 0 (t4k_conv_stack_dx0 below).
+ * A caller whose latest forward did NOT go through t4k_conv_stack_fwd must say so with bit 1 of `train` (train | 2): the
  * whole-image kernel then reads the layer tensors themselves. */
 typedef struct t4k_conv_stage {
     const float *F, *B;       /* filter T4(C1,K,K,C0), bias [C0] */
@@ -337,6 +343,20 @@ typedef struct t4k_stack_head {
     const float *W2, *B2; float *Y2, *P;        /* second linear layer W2[E0b][E0a], bias, output [N][E0b]; softmax output  */
     int E1, E0a, E0b;
 } t4k_stack_head;
+/* t4k_conv_stack_release: frees what the forward left behind for the banded backward of the stack whose first conv output tensor is
+ * `first_conv_out` (the owner of that tensor calls it when the model is freed - Model::~Model in the reference, src/nn/model.h; unknown
+ * keys are ignored).  t4k_conv_stack_stats: how this process got its stack kernels - compiled by hipRTC (*jit), loaded from the
+ * code-object cache on disk (*disk: $T4K_CACHE_DIR, <library dir>/kcache as filled by build(), ~/.cache/tensorforth_amd) or not at
+ * all (*failed: those stacks run the per-layer kernels; the library says so once on stderr). */
+int  t4k_conv_stack_release(const float *first_conv_out);
+/* Lazy dX of the FIRST conv layer.  In a classifier's training loop nobody reads the gradient w.r.t. the input batch, yet `in = dx`
+ * (backprop.cu:185) makes the reference compute and store it twice per step.  t4k_conv_stack_bwd(train | 8) skips it (banded kernel only)
+ * and remembers the filter it belongs to; t4k_conv_stack_dx0_pending() tells the caller whether that happened, t4k_conv_stack_dx0()
+ * produces it on demand - X and DXS of stage 0 then hold what the eager backward would have stored (k_dconv2d's dX, nmath.tcu:304-324).
+ * The host VM keeps a "stale" mark on the two tensors and calls it before any word can read them (host/tensor.cpp du2obj). */
+int  t4k_conv_stack_dx0_pending(const float *first_conv_out);
+int  t4k_conv_stack_dx0(const t4k_conv_stage *st, int N, t4k_stream_t s);
+void t4k_conv_stack_stats(int *jit, int *disk, int *failed);
 int t4k_conv_stack_head_ok(const t4k_conv_stage *st, int n_stage, int N, const t4k_stack_head *h);
 int t4k_conv_stack_head_fwd(const float *X, float *X0, const t4k_conv_stage *st, int n_stage, int N, const t4k_stack_head *h, t4k_stream_t s);
 int t4k_conv_stack_fwd(const float *X, float *XCOPY, const t4k_conv_stage *st, int n_stage, int N, t4k_stream_t s);
@@ -409,6 +429,13 @@ int t4k_opt_multi(int kind /*0 sgd,1 adam,2 adamw*/, const t4k_param_rec *tab_de
  * ceil(n / 1024) over the records before it - and passes the total; one workgroup per chunk. */
 int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n_chunks,
                     float lr, float b1, float b2, float wd, t4k_stream_t s);
+/* Model::sgd / adam / adamw as the host calls them (gradient.cu:63-169): t4k_opt_chunked, plus the work a backward DEFERRED to the
+ * optimizer inside the same launch - t4k_conv_stack_bwd(train | 4) leaves its per-workgroup dF | dB partial rows unfolded, and when
+ * t4k_opt_step is the next entry point the fold rides in the update (one launch instead of two, bit-identical).  Any OTHER entry point
+ * called in between runs the stand-alone fold first, so a caller that reads the gradient tensors, accumulates a second backward or
+ * all-reduces the slab before the optimizer sees what the undeferred path leaves.  tab_host: the caller's host copy of tab_dev. */
+int t4k_opt_step(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
+                 float lr, float b1, float b2, float wd, t4k_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -265,8 +265,15 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab, int nt, int, float lr, f
     return t4k_opt_multi(kind, tab, nt, 0, lr, b1, b2, wd, st);
 }
 
+int t4k_opt_step(int kind, const t4k_param_rec *tab, const t4k_param_rec *, int nt, int, float lr, float b1, float b2, float wd, t4k_stream_t st) {
+    return t4k_opt_multi(kind, tab, nt, 0, lr, b1, b2, wd, st);
+}
+
 // the sample-resident conv stack is a launch-count optimisation of the product: the oracle VM always runs the separate layers
 int t4k_conv_stack_ok(const t4k_conv_stage *, int, int) { return 0; }
+int t4k_conv_stack_release(const float *) { return T4K_OK; }
+int t4k_conv_stack_dx0_pending(const float *) { return 0; }
+int t4k_conv_stack_dx0(const t4k_conv_stage *, int, t4k_stream_t) { return T4K_OK; }
 int t4k_conv_stack_fwd(const float *, float *, const t4k_conv_stage *, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
 int t4k_conv_stack_bwd(const float *, const t4k_conv_stage *, int, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
 int t4k_conv_stack_head_ok(const t4k_conv_stage *, int, int, const t4k_stack_head *) { return 0; }

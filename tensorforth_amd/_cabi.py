@@ -23,6 +23,8 @@ def _ctype(decl):
         if decl.replace(" ", "").startswith("constchar*"):
             return ctypes.c_char_p
         return ctypes.c_void_p
+    if decl.replace("const", "").split()[:3] == ["unsigned", "long", "long"]:
+        return ctypes.c_ulonglong
     toks = [t for t in re.split(r"\s+", decl) if t not in ("const",)]
     # drop the parameter name if present
     base = toks[0]

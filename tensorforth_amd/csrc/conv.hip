@@ -555,8 +555,8 @@ template <bool BWD, int G, int CH, int VW>
 void launch_conv_few3(int K, dim3 g, hipStream_t hs, const float *X, float *Y, float *Y2, float *XC, const float *F, const float *B,
                       int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, int NG) {
     const dim3 b(256);
-    if (K == 3) hipLaunchKernelGGL((k_conv_few<3, 1, 1, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
-    else        hipLaunchKernelGGL((k_conv_few<5, 1, 2, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
+    if (K == 3) T4K_LAUNCH((k_conv_few<3, 1, 1, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
+    else        T4K_LAUNCH((k_conv_few<5, 1, 2, BWD, G, CH, VW>), g, b, 0, hs, X, Y, Y2, XC, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, NG);
 }
 template <bool BWD>
 void launch_conv_few(int K, hipStream_t hs, const float *X, float *Y, float *Y2, float *XC, const float *F, const float *B,
@@ -715,18 +715,18 @@ void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, fl
         static int wpc = -1; if (wpc < 0) { const char *e = getenv("T4K_DX_WIDE_WPC"); wpc = e ? atoi(e) : 8; }
         long gw = (npix + ppb - 1) / ppb; if (gw > (long)st().cu_count * wpc) gw = (long)st().cu_count * wpc;   // the weights are loaded once per workgroup
         const dim3 gg((unsigned)gw + fa.nfold), bb(256);
-        if (C0 == 32)      hipLaunchKernelGGL((k_conv_dx_wide<CO, 8>),  gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
-        else if (C0 == 64) hipLaunchKernelGGL((k_conv_dx_wide<CO, 16>), gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
-        else               hipLaunchKernelGGL((k_conv_dx_wide<CO, 32>), gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
+        if (C0 == 32)      T4K_LAUNCH((k_conv_dx_wide<CO, 8>),  gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
+        else if (C0 == 64) T4K_LAUNCH((k_conv_dx_wide<CO, 16>), gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
+        else               T4K_LAUNCH((k_conv_dx_wide<CO, 32>), gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
         return;
     }
     long gx = (npix + 255) / 256; if (gx > 8192) gx = 8192;
     const dim3 g((unsigned)gx + fa.nfold), b(256);
     switch ((K << 8) | (S << 4) | P) {
-    case 0x110: hipLaunchKernelGGL((k_conv_dx_few<1, 1, 0, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
-    case 0x311: hipLaunchKernelGGL((k_conv_dx_few<3, 1, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
-    case 0x421: hipLaunchKernelGGL((k_conv_dx_few<4, 2, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
-    case 0x512: hipLaunchKernelGGL((k_conv_dx_few<5, 1, 2, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+    case 0x110: T4K_LAUNCH((k_conv_dx_few<1, 1, 0, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+    case 0x311: T4K_LAUNCH((k_conv_dx_few<3, 1, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+    case 0x421: T4K_LAUNCH((k_conv_dx_few<4, 2, 1, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
+    case 0x512: T4K_LAUNCH((k_conv_dx_few<5, 1, 2, CO>), g, b, 0, hs, DO, DX, DX2, F, N, H0, W0, C0, H1, W1, fa); break;
     }
 }
 
@@ -752,10 +752,10 @@ void launch_conv_gemm(int K, int S, int P, dim3 g, hipStream_t hs, const float *
     const int ksplit = conv_gemm_ksplit(npix, Cout, Cin, K);
     g.x = (unsigned)((npix + (128 / ksplit) - 1) / (128 / ksplit));
     switch ((K << 8) | (S << 4) | P) {
-    case 0x110: hipLaunchKernelGGL((k_conv_gemm<1, 1, 0, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
-    case 0x311: hipLaunchKernelGGL((k_conv_gemm<3, 1, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
-    case 0x421: hipLaunchKernelGGL((k_conv_gemm<4, 2, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
-    case 0x512: hipLaunchKernelGGL((k_conv_gemm<5, 1, 2, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
+    case 0x110: T4K_LAUNCH((k_conv_gemm<1, 1, 0, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
+    case 0x311: T4K_LAUNCH((k_conv_gemm<3, 1, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
+    case 0x421: T4K_LAUNCH((k_conv_gemm<4, 2, 1, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
+    case 0x512: T4K_LAUNCH((k_conv_gemm<5, 1, 2, BWD>), g, dim3(256), 0, hs, X, Y, Y2, F, B, N, Hx, Wx, Cin, Hy, Wy, Cout, C0, ppc, ksplit); break;
     }
 }
 
@@ -774,11 +774,11 @@ int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs) {
     float *part = ws_for(hs) + (8 << 20);            // second 32 MiB half of the workspace
     if ((size_t)nchunk * E * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "colsum workspace");
     if (nchunk == 1) {
-        hipLaunchKernelGGL(k_colsum_part, dim3(1, (E + 63) / 64), dim3(BLK), 0, hs, X, part, rows, E, rpc, OUT);
+        T4K_LAUNCH(k_colsum_part, dim3(1, (E + 63) / 64), dim3(BLK), 0, hs, X, part, rows, E, rpc, OUT);
         return T4K_OK;
     }
-    hipLaunchKernelGGL(k_colsum_part, dim3(nchunk, (E + 63) / 64), dim3(BLK), 0, hs, X, part, rows, E, rpc, (float *)nullptr);
-    hipLaunchKernelGGL(k_conv_df_fold, dim3((E + 3) / 4), dim3(256), 0, hs, part, OUT, OUT, nchunk, E, E);   // one wave per output, fixed xor tree
+    T4K_LAUNCH(k_colsum_part, dim3(nchunk, (E + 63) / 64), dim3(BLK), 0, hs, X, part, rows, E, rpc, (float *)nullptr);
+    T4K_LAUNCH(k_conv_df_fold, dim3((E + 3) / 4), dim3(256), 0, hs, part, OUT, OUT, nchunk, E, E);   // one wave per output, fixed xor tree
     return T4K_OK;
 }
 }
@@ -847,8 +847,8 @@ int t4k_conv2d_block_fwd(const float *I, float *ICOPY, float *O, const float *F,
     const int ksplit = conv_gemm_ksplit(npix, C0, C1, K);
     const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);
     const dim3 g((unsigned)((npix + (128 / ksplit) - 1) / (128 / ksplit)), (unsigned)((C0 + 31) / 32));
-    if (K == 3) hipLaunchKernelGGL((k_conv_gemm_pool<3, 1, 1>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe, xc);
-    else        hipLaunchKernelGGL((k_conv_gemm_pool<5, 1, 2>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe, xc);
+    if (K == 3) T4K_LAUNCH((k_conv_gemm_pool<3, 1, 1>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe, xc);
+    else        T4K_LAUNCH((k_conv_gemm_pool<5, 1, 2>), g, dim3(256), 0, hs, I, O, F, B, N, H1, W1, C1, H0, W0, C0, C0, ppc, ksplit, pe, xc);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }
@@ -879,8 +879,8 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
                 const int ntot = ntaps * C0;                      // no bias row in these slabs: dB is a plain column sum of dO
                 // few slices x many outputs: one thread per output walks the slices (coalesced); the wave-per-output fold is
                 // for the opposite shape (hundreds of slices, few outputs) and would run 8 of 64 lanes here
-                if (nbig <= 32) hipLaunchKernelGGL(k_fold_add, dim3((ntot + BLK - 1) / BLK), dim3(BLK), 0, hs, ws_for(s), DF, ntot, nbig);
-                else hipLaunchKernelGGL(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, ws_for(s), DF, DB, nbig, ntot, ntot);
+                if (nbig <= 32) T4K_LAUNCH(k_fold_add, dim3((ntot + BLK - 1) / BLK), dim3(BLK), 0, hs, ws_for(s), DF, ntot, nbig);
+                else T4K_LAUNCH(k_conv_df_fold, dim3((ntot + 3) / 4), dim3(256), 0, hs, ws_for(s), DF, DB, nbig, ntot, ntot);
                 int rc = colsum_add(DO, DB, (long)N * H0 * W0, C0, hs); if (rc) return rc;
             }
         }
@@ -897,10 +897,10 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         if ((size_t)nslice * nrow1 * C0 * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "conv dF workspace");
         dim3 g(nslice, (nrow1 + 31) / 32, (C0 + 31) / 32);
         switch ((K << 8) | (S << 4) | P) {
-        case 0x110: hipLaunchKernelGGL((k_conv_df_mfma<1, 1, 0>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
-        case 0x311: hipLaunchKernelGGL((k_conv_df_mfma<3, 1, 1>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
-        case 0x421: hipLaunchKernelGGL((k_conv_df_mfma<4, 2, 1>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
-        case 0x512: hipLaunchKernelGGL((k_conv_df_mfma<5, 1, 2>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
+        case 0x110: T4K_LAUNCH((k_conv_df_mfma<1, 1, 0>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
+        case 0x311: T4K_LAUNCH((k_conv_df_mfma<3, 1, 1>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
+        case 0x421: T4K_LAUNCH((k_conv_df_mfma<4, 2, 1>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
+        case 0x512: T4K_LAUNCH((k_conv_df_mfma<5, 1, 2>), g, dim3(256), 0, hs, I, DO, part, N, H1, W1, C1, H0, W0, C0, rpw); break;
         }
         const int ntot = nrow1 * C0;
         fa.part = part; fa.DF = DF; fa.DB = DB; fa.nslice = nslice; fa.ndf = ntaps * C0; fa.ntot = ntot; fa.nfold = (ntot + 3) / 4;
@@ -908,7 +908,7 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
     }
     int fG = 0, fNG = 0;
     if (DX && conv_big_on() && conv_big_ok(C0, C1) && aligned16(DO) && aligned16(F)) {  // many channels: LDS-staged GEMM tiling
-        if (fa.nfold) { hipLaunchKernelGGL(k_conv_df_fold, dim3(fa.nfold), dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot); fa.nfold = 0; }
+        if (fa.nfold) { T4K_LAUNCH(k_conv_df_fold, dim3(fa.nfold), dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot); fa.nfold = 0; }
         launch_conv_big<true>(K, S, P, hs, DO, DX, DX2, F, nullptr, N, H0, W0, C0, H1, W1, C1, C0);
         T4K_LAUNCH_CHECK();
         return T4K_OK;
@@ -916,7 +916,7 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
     const bool dx_few = DX && C1 <= 4 && C1 * K * K * C0 <= LDS_FILTER_FLOATS;
     const bool dx_fewch = DX && !dx_few && conv_few_on() && conv_few_ok(K, C0, C1, &fG, &fNG);
     if (fa.nfold && (!DX || dx_fewch)) {                 // no dX kernel to share a launch with: fold on its own
-        hipLaunchKernelGGL(k_conv_df_fold, dim3(fa.nfold), dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot);
+        T4K_LAUNCH(k_conv_df_fold, dim3(fa.nfold), dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot);
         fa.nfold = 0;
     }
     if (dx_few) {                                       // image-input layer: direct kernel, one thread per input pixel (+ the fold)
@@ -935,7 +935,7 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         // dX: gather over dO (Hx=H0,Wx=W0,Cin=C0), output the input grid (Hy=H1,Wy=W1,Cout=C1); the dF fold rides along
         const int ppc = LDS_FILTER_FLOATS / (K * K * 2 * 32);
         const dim3 g((unsigned)(fa.nfold + hx * hy));
-#define DXF(k, s_, p_) hipLaunchKernelGGL((k_conv_dx_and_fold<k, s_, p_>), g, dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot, fa.nfold, \
+#define DXF(k, s_, p_) T4K_LAUNCH((k_conv_dx_and_fold<k, s_, p_>), g, dim3(256), 0, hs, fa.part, fa.DF, fa.DB, fa.nslice, fa.ndf, fa.ntot, fa.nfold, \
                                           DO, DX, DX2, F, N, H1, W1, C1, H0, W0, C0, hx, ppc, ksplit)
         switch ((K << 8) | (S << 4) | P) {
         case 0x110: DXF(1, 1, 0); break;
@@ -955,8 +955,8 @@ int t4k_pool(int layer, const float *I, float *O, int N, int H1, int W1, int H0,
     if (layer != T4K_L_AVGPOOL && layer != T4K_L_MAXPOOL && layer != T4K_L_MINPOOL && layer != T4K_L_USAMPLE)
         return fail(T4K_ERR_UNSUPPORTED, "t4k_pool: layer %d", layer);
     const long total = (long)N * H0 * W0 * C; if (total <= 0) return T4K_OK;
-    if (KS == 2) hipLaunchKernelGGL(k_pool<2>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, O, N, H1, W1, H0, W0, C);
-    else         hipLaunchKernelGGL(k_pool<3>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, O, N, H1, W1, H0, W0, C);
+    if (KS == 2) T4K_LAUNCH(k_pool<2>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, O, N, H1, W1, H0, W0, C);
+    else         T4K_LAUNCH(k_pool<3>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, O, N, H1, W1, H0, W0, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_dpool(int layer, float *I, const float *DY, int N, int H1, int W1, int H0, int W0, int C, int KS, t4k_stream_t s) {
@@ -965,8 +965,8 @@ int t4k_dpool(int layer, float *I, const float *DY, int N, int H1, int W1, int H
     if (layer != T4K_L_AVGPOOL && layer != T4K_L_MAXPOOL && layer != T4K_L_MINPOOL && layer != T4K_L_USAMPLE)
         return fail(T4K_ERR_UNSUPPORTED, "t4k_dpool: layer %d", layer);
     const long total = (long)N * H0 * W0 * C; if (total <= 0) return T4K_OK;
-    if (KS == 2) hipLaunchKernelGGL(k_dpool<2>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, DY, N, H1, W1, H0, W0, C);
-    else         hipLaunchKernelGGL(k_dpool<3>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, DY, N, H1, W1, H0, W0, C);
+    if (KS == 2) T4K_LAUNCH(k_dpool<2>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, DY, N, H1, W1, H0, W0, C);
+    else         T4K_LAUNCH(k_dpool<3>, dim3(grid_for(total)), dim3(BLK), 0, t4k::S(s), layer, I, DY, N, H1, W1, H0, W0, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

@@ -442,8 +442,8 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
     const dim3 g((unsigned)(tiles_m * p.tiles_n)), b(256);
     const size_t lds = sizeof(float) * 2 * (128 + BN) * BK;
 #define CB(k, s, pd) do { if (wide) { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig<k, s, pd, BWD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); a1 = true; } \
-                                       hipLaunchKernelGGL((k_convbig<k, s, pd, BWD, 128>), g, b, lds, hs, p); } \
-                          else hipLaunchKernelGGL((k_convbig<k, s, pd, BWD, 64>), g, b, lds, hs, p); } while (0)
+                                       T4K_LAUNCH((k_convbig<k, s, pd, BWD, 128>), g, b, lds, hs, p); } \
+                          else T4K_LAUNCH((k_convbig<k, s, pd, BWD, 64>), g, b, lds, hs, p); } while (0)
     switch ((K << 8) | (S << 4) | P) {
     case 0x110: CB(1, 1, 0); break;
     case 0x311: CB(3, 1, 1); break;
@@ -493,7 +493,7 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
         const dim3 g8((unsigned)(8 * kks * ((groups + 7) / 8))), b8(512);
 #define DF8_(k, s, pd, bk, ns_) do { static bool a1 = false; const int lb = ns_ * 128 * bk * 4; \
             if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_df8<k, s, pd, bk, ns_>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); a1 = true; } \
-            hipLaunchKernelGGL((k_convbig_df8<k, s, pd, bk, ns_>), g8, b8, lb, hs, q); } while (0)
+            T4K_LAUNCH((k_convbig_df8<k, s, pd, bk, ns_>), g8, b8, lb, hs, q); } while (0)
 #define DF8(k, s, pd) do { if (bkp == 128) DF8_(k, s, pd, 128, 2); else if (bkp == 64 && nstb == 3) DF8_(k, s, pd, 64, 3); else if (bkp == 64) DF8_(k, s, pd, 64, 2); \
                            else if (nstb >= 5) DF8_(k, s, pd, 32, 5); else if (nstb == 4) DF8_(k, s, pd, 32, 4); else DF8_(k, s, pd, 32, 3); } while (0)
         switch ((K << 8) | (S << 4) | P) {
@@ -510,10 +510,10 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
     CdP p = { I, DO, part, N, H1, W1, C1, H0, W0, C0, (int)pps, ci_tiles };
     const dim3 g((unsigned)nslice, (unsigned)(KK * ci_tiles), (unsigned)co_tiles), b(256);
     switch ((K << 8) | (S << 4) | P) {
-    case 0x110: hipLaunchKernelGGL((k_convbig_df<1, 1, 0>), g, b, 0, hs, p); break;
-    case 0x311: hipLaunchKernelGGL((k_convbig_df<3, 1, 1>), g, b, 0, hs, p); break;
-    case 0x421: hipLaunchKernelGGL((k_convbig_df<4, 2, 1>), g, b, 0, hs, p); break;
-    case 0x512: hipLaunchKernelGGL((k_convbig_df<5, 1, 2>), g, b, 0, hs, p); break;
+    case 0x110: T4K_LAUNCH((k_convbig_df<1, 1, 0>), g, b, 0, hs, p); break;
+    case 0x311: T4K_LAUNCH((k_convbig_df<3, 1, 1>), g, b, 0, hs, p); break;
+    case 0x421: T4K_LAUNCH((k_convbig_df<4, 2, 1>), g, b, 0, hs, p); break;
+    case 0x512: T4K_LAUNCH((k_convbig_df<5, 1, 2>), g, b, 0, hs, p); break;
     }
     return (int)nslice;
 }

@@ -148,12 +148,12 @@ __global__ void __launch_bounds__(64) k_conv_img_block(ImgBlk p) {
 template <int CIN, bool NTV>
 bool launch_cout(const ImgBlk &p, int Cout, unsigned grid, hipStream_t hs) {
     switch (Cout) {
-    case 4:  hipLaunchKernelGGL((k_conv_img_block<CIN, 4, NTV>),  dim3(grid), dim3(64), 0, hs, p); return true;
-    case 6:  hipLaunchKernelGGL((k_conv_img_block<CIN, 6, NTV>),  dim3(grid), dim3(64), 0, hs, p); return true;
-    case 8:  hipLaunchKernelGGL((k_conv_img_block<CIN, 8, NTV>),  dim3(grid), dim3(64), 0, hs, p); return true;
-    case 10: hipLaunchKernelGGL((k_conv_img_block<CIN, 10, NTV>), dim3(grid), dim3(64), 0, hs, p); return true;
-    case 12: hipLaunchKernelGGL((k_conv_img_block<CIN, 12, NTV>), dim3(grid), dim3(64), 0, hs, p); return true;
-    case 16: hipLaunchKernelGGL((k_conv_img_block<CIN, 16, NTV>), dim3(grid), dim3(64), 0, hs, p); return true;
+    case 4:  T4K_LAUNCH((k_conv_img_block<CIN, 4, NTV>),  dim3(grid), dim3(64), 0, hs, p); return true;
+    case 6:  T4K_LAUNCH((k_conv_img_block<CIN, 6, NTV>),  dim3(grid), dim3(64), 0, hs, p); return true;
+    case 8:  T4K_LAUNCH((k_conv_img_block<CIN, 8, NTV>),  dim3(grid), dim3(64), 0, hs, p); return true;
+    case 10: T4K_LAUNCH((k_conv_img_block<CIN, 10, NTV>), dim3(grid), dim3(64), 0, hs, p); return true;
+    case 12: T4K_LAUNCH((k_conv_img_block<CIN, 12, NTV>), dim3(grid), dim3(64), 0, hs, p); return true;
+    case 16: T4K_LAUNCH((k_conv_img_block<CIN, 16, NTV>), dim3(grid), dim3(64), 0, hs, p); return true;
     default: return false;
     }
 }

@@ -60,7 +60,7 @@ int t4k_dconv2d_fwd(const float *I, float *O, const float *F, const float *B,
     const size_t nf = (size_t)C1 * K * K * C0;
     float *ft, *unused; int rc = scratch(nf + C1 + 64, &ft, &unused); if (rc) return rc;
     hipStream_t hs = t4k::S(s);
-    hipLaunchKernelGGL(k_filter_xpose<false>, dim3(grid_for((long)nf)), dim3(BLK), 0, hs, F, ft, C1, C0, K, 1);   // flipped: the dX kernel flips back
+    T4K_LAUNCH(k_filter_xpose<false>, dim3(grid_for((long)nf)), dim3(BLK), 0, hs, F, ft, C1, C0, K, 1);   // flipped: the dX kernel flips back
     T4K_LAUNCH_CHECK();
     // virtual conv: input O [N,H0,W0,C0] -> output I [N,H1,W1,C1]; its dX, given "dO" = I, is the transposed convolution
     rc = t4k_conv2d_bwd(O, I, O, ft, nullptr, nullptr, N, H0, W0, C0, H1, W1, C1, K, S, P, 0, s); if (rc) return rc;
@@ -82,12 +82,12 @@ int t4k_dconv2d_bwd(const float *I, const float *DO, float *DX, const float *F, 
         if ((size_t)(dbv - g_buf) + (size_t)C1 > g_cap) return fail(T4K_ERR_NOMEM, "dconv2d scratch (C1 = %d)", C1);
         T4K_HIP(hipMemsetAsync(dbv, 0, (size_t)C1 * sizeof(float), hs));
         rc = t4k_conv2d_bwd(DO, I, nullptr, F /* unused: no dX */, dfv, dbv, N, H0, W0, C0, H1, W1, C1, K, S, P, 1, s); if (rc) return rc;
-        hipLaunchKernelGGL(k_filter_xpose<true>, dim3(grid_for((long)nf)), dim3(BLK), 0, hs, dfv, DF, C0, C1, K, 0);
+        T4K_LAUNCH(k_filter_xpose<true>, dim3(grid_for((long)nf)), dim3(BLK), 0, hs, dfv, DF, C0, C1, K, 0);
         T4K_LAUNCH_CHECK();
         rc = colsum_add(DO, DB, (long)N * H0 * W0, C0, hs); if (rc) return rc;
     }
     if (DX) {
-        hipLaunchKernelGGL(k_filter_xpose<false>, dim3(grid_for((long)nf)), dim3(BLK), 0, hs, F, ft, C1, C0, K, 0);
+        T4K_LAUNCH(k_filter_xpose<false>, dim3(grid_for((long)nf)), dim3(BLK), 0, hs, F, ft, C1, C0, K, 0);
         T4K_LAUNCH_CHECK();
         float *zb = dfv + nf;                            // zero bias for the plain convolution (re-zeroed: dF may have used the slot)
         if ((size_t)(zb - g_buf) + (size_t)C1 > g_cap) return fail(T4K_ERR_NOMEM, "dconv2d scratch (C1 = %d)", C1);

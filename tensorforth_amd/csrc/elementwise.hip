@@ -214,22 +214,22 @@ int t4k_copy(const float *src, float *dst, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!src || !dst) return fail(T4K_ERR_ARG, "t4k_copy: null");
     bool vec = aligned16(src) && aligned16(dst);
-    hipLaunchKernelGGL(k_copy, dim3(grid_for(n, 4)), dim3(BLK), 0, S(s), src, dst, n, vec);
+    T4K_LAUNCH(k_copy, dim3(grid_for(n, 4)), dim3(BLK), 0, S(s), src, dst, n, vec);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_transpose(const float *src, float *dst, int H, int W, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (H <= 0 || W <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_transpose: shape");
     dim3 g((W + 63) / 64, (H + 63) / 64, C);
-    hipLaunchKernelGGL(k_transpose, g, dim3(BLK), 0, S(s), src, dst, H, W, C);
+    T4K_LAUNCH(k_transpose, g, dim3(BLK), 0, S(s), src, dst, H, W, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_identity(float *dst, int H, int W, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (H <= 0 || W <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_identity: shape");
-    hipLaunchKernelGGL(k_identity, dim3(grid_for((long)H * W * C)), dim3(BLK), 0, S(s), dst, H, W, C);
+    T4K_LAUNCH(k_identity, dim3(grid_for((long)H * W * C)), dim3(BLK), 0, S(s), dst, H, W, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
-#define MATH_CASE(OP) case OP: hipLaunchKernelGGL(k_math<OP>, dim3(g), dim3(BLK), 0, S(s), A, v, n, vec); break
+#define MATH_CASE(OP) case OP: T4K_LAUNCH(k_math<OP>, dim3(g), dim3(BLK), 0, S(s), A, v, n, vec); break
 int t4k_math(int op, float *A, float v, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!A) return fail(T4K_ERR_ARG, "t4k_math: null");
@@ -244,7 +244,7 @@ int t4k_math(int op, float *A, float v, long n, t4k_stream_t s) {
     }
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
-#define TS_CASE(OP) case OP: hipLaunchKernelGGL(k_ts<OP>, dim3(g), dim3(BLK), 0, S(s), A, v, O, n, vec); break
+#define TS_CASE(OP) case OP: T4K_LAUNCH(k_ts<OP>, dim3(g), dim3(BLK), 0, S(s), A, v, O, n, vec); break
 int t4k_ts_op(int op, const float *A, float v, float *O, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!A || !O) return fail(T4K_ERR_ARG, "t4k_ts_op: null");
@@ -253,7 +253,7 @@ int t4k_ts_op(int op, const float *A, float v, float *O, long n, t4k_stream_t s)
     default: return fail(T4K_ERR_UNSUPPORTED, "k_ts_op op=%d not supported", op); }
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
-#define TT_CASE(OP) case OP: hipLaunchKernelGGL(k_tt<OP>, dim3(g), dim3(BLK), 0, S(s), A, B, O, O2, n, vec); break
+#define TT_CASE(OP) case OP: T4K_LAUNCH(k_tt<OP>, dim3(g), dim3(BLK), 0, S(s), A, B, O, O2, n, vec); break
 int t4k_tt_op(int op, const float *A, const float *B, float *O, long n, t4k_stream_t s) { return t4k_tt_op2(op, A, B, O, nullptr, n, s); }
 int t4k_tt_op2(int op, const float *A, const float *B, float *O, float *O2, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
@@ -263,7 +263,7 @@ int t4k_tt_op2(int op, const float *A, const float *B, float *O, float *O2, long
     default: return fail(T4K_ERR_UNSUPPORTED, "k_tt_op op=%d not supported", op); }
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
-#define ACT_CASE(L) case L: hipLaunchKernelGGL(k_activate<L>, dim3(g), dim3(BLK), 0, S(s), I, O, F, alpha, n, vec); break
+#define ACT_CASE(L) case L: T4K_LAUNCH(k_activate<L>, dim3(g), dim3(BLK), 0, S(s), I, O, F, alpha, n, vec); break
 int t4k_activate(int layer, const float *I, float *O, float *F, float alpha, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!I || !O || !F) return fail(T4K_ERR_ARG, "t4k_activate: null");
@@ -278,12 +278,12 @@ int t4k_activate(int layer, const float *I, float *O, float *F, float alpha, lon
 int t4k_bias(const float *B, float *O, int N, int E0, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || E0 <= 0) return T4K_OK;
     const long total = (long)N * E0;
-    hipLaunchKernelGGL(k_bias, dim3(grid_for(total)), dim3(BLK), 0, S(s), B, O, total, E0);
+    T4K_LAUNCH(k_bias, dim3(grid_for(total)), dim3(BLK), 0, S(s), B, O, total, E0);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_u8_normalize(const uint8_t *src, float *dst, long n, float mean, float scale, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
-    hipLaunchKernelGGL(k_u8norm, dim3(grid_for(n)), dim3(BLK), 0, S(s), src, dst, n, mean, scale);
+    T4K_LAUNCH(k_u8norm, dim3(grid_for(n)), dim3(BLK), 0, S(s), src, dst, n, mean, scale);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_stage_batch(const uint8_t *src, float *dst, long n, float mean, float scale,
@@ -292,24 +292,24 @@ int t4k_stage_batch(const uint8_t *src, float *dst, long n, float mean, float sc
     if (n < 0 || nlab < 0 || (n > 0 && (!src || !dst)) || (nlab > 0 && (!lab_src || !lab_dst))) return fail(T4K_ERR_ARG, "t4k_stage_batch: bad argument");
     const int vec = ((uintptr_t)src & 3) == 0 && aligned16(dst);
     const long lanes = std::max<long>(vec ? (n + 3) >> 2 : n, nlab);
-    hipLaunchKernelGGL(k_stage_batch, dim3(grid_for(lanes)), dim3(BLK), 0, S(s), src, dst, n, mean, scale, lab_src, lab_dst, nlab, vec);
+    T4K_LAUNCH(k_stage_batch, dim3(grid_for(lanes)), dim3(BLK), 0, S(s), src, dst, n, mean, scale, lab_src, lab_dst, nlab, vec);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_broadcast_rows(const float *T, float *O, int N, int E, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || E <= 0) return T4K_OK;
     if (!T || !O) return fail(T4K_ERR_ARG, "t4k_broadcast_rows: null tensor");
-    hipLaunchKernelGGL(k_broadcast_rows, dim3(grid_for((long)N * E)), dim3(BLK), 0, S(s), T, O, N, E);
+    T4K_LAUNCH(k_broadcast_rows, dim3(grid_for((long)N * E)), dim3(BLK), 0, S(s), T, O, N, E);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_copy_mask(const float *T, const float *MASK, float *OUT, float *IN, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!T || !MASK || !OUT || !IN) return fail(T4K_ERR_ARG, "t4k_copy_mask: null tensor");
-    hipLaunchKernelGGL(k_copy_mask, dim3(grid_for(n)), dim3(BLK), 0, S(s), T, MASK, OUT, IN, n);
+    T4K_LAUNCH(k_copy_mask, dim3(grid_for(n)), dim3(BLK), 0, S(s), T, MASK, OUT, IN, n);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_onehot(const uint32_t *label, float *hot, int N, int E, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || E <= 0) return T4K_OK;
-    hipLaunchKernelGGL(k_onehot, dim3(grid_for((long)N * E)), dim3(BLK), 0, S(s), label, hot, N, E);
+    T4K_LAUNCH(k_onehot, dim3(grid_for((long)N * E)), dim3(BLK), 0, S(s), label, hot, N, E);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

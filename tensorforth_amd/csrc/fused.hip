@@ -218,9 +218,9 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
     const long nthr = total / VW;
     const int bs = (nthr < (long)BLK * 2 * st().cu_count) ? 64 : BLK;      // small runs: one-wave workgroups reach every CU
     const dim3 grid((unsigned)std::min<long>((nthr + bs - 1) / bs, 8192)), blk(bs);
-#define PBF(KS_) do { if (VW == 4) hipLaunchKernelGGL((k_poolblock_fwd<KS_, 4>), grid, blk, 0, S(s), p); \
-                      else if (VW == 2) hipLaunchKernelGGL((k_poolblock_fwd<KS_, 2>), grid, blk, 0, S(s), p); \
-                      else hipLaunchKernelGGL((k_poolblock_fwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
+#define PBF(KS_) do { if (VW == 4) T4K_LAUNCH((k_poolblock_fwd<KS_, 4>), grid, blk, 0, S(s), p); \
+                      else if (VW == 2) T4K_LAUNCH((k_poolblock_fwd<KS_, 2>), grid, blk, 0, S(s), p); \
+                      else T4K_LAUNCH((k_poolblock_fwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
     switch (b->KS) { case 1: PBF(1); break; case 2: PBF(2); break; default: PBF(3); break; }
 #undef PBF
     T4K_LAUNCH_CHECK(); return T4K_OK;
@@ -242,9 +242,9 @@ int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *b, int N, 
     const long nthr = total / VW;
     const int bs = (nthr < (long)BLK * 2 * st().cu_count) ? 64 : BLK;
     const dim3 grid((unsigned)std::min<long>((nthr + bs - 1) / bs, 8192)), blk(bs);
-#define PBB_(KS_) do { if (VW == 4) hipLaunchKernelGGL((k_poolblock_bwd<KS_, 4>), grid, blk, 0, S(s), p); \
-                       else if (VW == 2) hipLaunchKernelGGL((k_poolblock_bwd<KS_, 2>), grid, blk, 0, S(s), p); \
-                       else hipLaunchKernelGGL((k_poolblock_bwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
+#define PBB_(KS_) do { if (VW == 4) T4K_LAUNCH((k_poolblock_bwd<KS_, 4>), grid, blk, 0, S(s), p); \
+                       else if (VW == 2) T4K_LAUNCH((k_poolblock_bwd<KS_, 2>), grid, blk, 0, S(s), p); \
+                       else T4K_LAUNCH((k_poolblock_bwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
     switch (b->KS) { case 1: PBB_(1); break; case 2: PBB_(2); break; default: PBB_(3); break; }
 #undef PBB_
     T4K_LAUNCH_CHECK(); return T4K_OK;

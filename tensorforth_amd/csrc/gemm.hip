@@ -1412,8 +1412,8 @@ void launch_plain_(const PlainP &q, int tmq, int tnq, unsigned gx, hipStream_t s
     static int fastpro = -1; if (fastpro < 0) { const char *e = getenv("T4K_GEMM_FASTPRO"); fastpro = e ? atoi(e) : 1; }
     const bool pow2 = fastpro && (tmq & (tmq - 1)) == 0 && (tnq & (tnq - 1)) == 0 && tmq >= 4 && (tmq * tnq) % 32 == 0;
     const dim3 grid(gx, PAIR ? 2 : 1);
-    if (pow2) hipLaunchKernelGGL((k_gemm_nn_plain<true, AKC, BKC, EPI, PAIR, RAGK>),  grid, dim3(512), lds_bytes, s, q);
-    else      hipLaunchKernelGGL((k_gemm_nn_plain<false, AKC, BKC, EPI, PAIR, RAGK>), grid, dim3(512), lds_bytes, s, q);
+    if (pow2) T4K_LAUNCH((k_gemm_nn_plain<true, AKC, BKC, EPI, PAIR, RAGK>),  grid, dim3(512), lds_bytes, s, q);
+    else      T4K_LAUNCH((k_gemm_nn_plain<false, AKC, BKC, EPI, PAIR, RAGK>), grid, dim3(512), lds_bytes, s, q);
 }
 void launch_nn_plain(const GemmP &p, dim3 grid, hipStream_t s) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, 1.0f, 0.0f, nullptr, nullptr, nullptr };
@@ -1586,7 +1586,7 @@ void launch_plain128_(const PlainP &q, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)2 * 256 * 64 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain128<AKC, BKC, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
-    hipLaunchKernelGGL((k_gemm_plain128<AKC, BKC, EPI>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
+    T4K_LAUNCH((k_gemm_plain128<AKC, BKC, EPI>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
 }
 void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, nullptr, nullptr };
@@ -1607,10 +1607,10 @@ void launch_glds(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds<BK, false, true>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_done = true;
     }
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm_glds<BK, true,  false>), grid, dim3(256), lds_bytes, s, p);
-    else if (!tA)   hipLaunchKernelGGL((k_gemm_glds<BK, true,  true>),  grid, dim3(256), lds_bytes, s, p);
-    else if (!tB)   hipLaunchKernelGGL((k_gemm_glds<BK, false, false>), grid, dim3(256), lds_bytes, s, p);
-    else            hipLaunchKernelGGL((k_gemm_glds<BK, false, true>),  grid, dim3(256), lds_bytes, s, p);
+    if (!tA && !tB) T4K_LAUNCH((k_gemm_glds<BK, true,  false>), grid, dim3(256), lds_bytes, s, p);
+    else if (!tA)   T4K_LAUNCH((k_gemm_glds<BK, true,  true>),  grid, dim3(256), lds_bytes, s, p);
+    else if (!tB)   T4K_LAUNCH((k_gemm_glds<BK, false, false>), grid, dim3(256), lds_bytes, s, p);
+    else            T4K_LAUNCH((k_gemm_glds<BK, false, true>),  grid, dim3(256), lds_bytes, s, p);
 }
 
 template <int BK, bool RAGK>
@@ -1624,10 +1624,10 @@ void launch_glds8_(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds8<BK, false, true, false, RAGK>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_done = true;
     }
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm_glds8<BK, true,  false, false, RAGK>), grid, dim3(512), lds_bytes, s, p);
-    else if (!tA)   hipLaunchKernelGGL((k_gemm_glds8<BK, true,  true,  false, RAGK>), grid, dim3(512), lds_bytes, s, p);
-    else if (!tB)   hipLaunchKernelGGL((k_gemm_glds8<BK, false, false, false, RAGK>), grid, dim3(512), lds_bytes, s, p);
-    else            hipLaunchKernelGGL((k_gemm_glds8<BK, false, true,  false, RAGK>), grid, dim3(512), lds_bytes, s, p);
+    if (!tA && !tB) T4K_LAUNCH((k_gemm_glds8<BK, true,  false, false, RAGK>), grid, dim3(512), lds_bytes, s, p);
+    else if (!tA)   T4K_LAUNCH((k_gemm_glds8<BK, true,  true,  false, RAGK>), grid, dim3(512), lds_bytes, s, p);
+    else if (!tB)   T4K_LAUNCH((k_gemm_glds8<BK, false, false, false, RAGK>), grid, dim3(512), lds_bytes, s, p);
+    else            T4K_LAUNCH((k_gemm_glds8<BK, false, true,  false, RAGK>), grid, dim3(512), lds_bytes, s, p);
 }
 template <int BK>
 void launch_glds8(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) { launch_glds8_<BK, false>(p, grid, tA, tB, s); }
@@ -1696,7 +1696,7 @@ void launch_one(const GemmP &p, dim3 grid, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p);
+    T4K_LAUNCH(kern, grid, dim3(256), lds_bytes, s, p);
 }
 template <int BM, int BN, int BK, bool VEC, bool SKEW, bool FULL>
 void launch_variant(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
@@ -1760,12 +1760,9 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             const MaskChain mc32 = mcp ? *mcp : MaskChain{nullptr, nullptr, nullptr, nullptr};
             // arrival slots: ints [512, 1024) of the stream's gate block; the epoch is this stream's launch count (never 0, slots cleared when it wraps)
             unsigned *slots = reinterpret_cast<unsigned *>(gate_for(hs, 0)) + 512;
-            static unsigned epochs[64];
-            const int li = lane_of(hs);
-            unsigned epoch = ++epochs[li < 63 ? li : 63];
-            if (alias32 && epoch == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); epoch = ++epochs[li < 63 ? li : 63]; }
-            if (a1 + ar + a2 <= cap - 32) hipLaunchKernelGGL(k_gemm_dual32<8>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
-            else                     hipLaunchKernelGGL(k_gemm_dual32<4>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
+            const unsigned epoch = next_slot_epoch(hs, slots);     // the lane's ONE counter, shared with k_head_bwd_dual32 (t4k_common.h)
+            if (a1 + ar + a2 <= cap - 32) T4K_LAUNCH(k_gemm_dual32<8>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
+            else                     T4K_LAUNCH(k_gemm_dual32<4>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
             return true;
         }
     }
@@ -1786,7 +1783,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     const MaskChain mc = mcp ? *mcp : MaskChain{nullptr, nullptr, nullptr, nullptr};
 #define T4K_DUAL(F1_, F2_) do { auto kern = k_gemm_dual<false, false, true, false, F1_, F2_>; static bool attr_done = false; \
         if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; } \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, alias ? gate : nullptr, mc); } while (0)
+        T4K_LAUNCH(kern, grid, dim3(256), lds_bytes, hs, p1, p2, (int)(t1 + riders), (int)t1, (int)t2, alias ? gate : nullptr, mc); } while (0)
     if (f1 && f2) T4K_DUAL(true, true); else if (f1) T4K_DUAL(true, false); else if (f2) T4K_DUAL(false, true); else T4K_DUAL(false, false);
 #undef T4K_DUAL
     return true;
@@ -1856,9 +1853,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             } else { defer->part = p.part; defer->nsplit = ns; defer->mn = mn; }
             const dim3 g32(gx, (unsigned)ns);
             static int nw8 = -1; if (nw8 < 0) { const char *e = getenv("T4K_GEMM_S32_NW8"); nw8 = e ? atoi(e) : 1; }
-#define T4K_S32(A_, B_) do { if (t32 * ns > 2L * st().cu_count) hipLaunchKernelGGL((k_gemm_s32<A_, B_, 4>), g32, dim3(256), 0, hs2, p, ep, fr); \
-                             else if (nw8 && kc >= 384)          hipLaunchKernelGGL((k_gemm_s32<A_, B_, 8, 8>), g32, dim3(512), 0, hs2, p, ep, fr);   /* deep k per slab: 8 k-groups */ \
-                             else                                hipLaunchKernelGGL((k_gemm_s32<A_, B_, 8>), g32, dim3(256), 0, hs2, p, ep, fr); } while (0)
+#define T4K_S32(A_, B_) do { if (t32 * ns > 2L * st().cu_count) T4K_LAUNCH((k_gemm_s32<A_, B_, 4>), g32, dim3(256), 0, hs2, p, ep, fr); \
+                             else if (nw8 && kc >= 384)          T4K_LAUNCH((k_gemm_s32<A_, B_, 8, 8>), g32, dim3(512), 0, hs2, p, ep, fr);   /* deep k per slab: 8 k-groups */ \
+                             else                                T4K_LAUNCH((k_gemm_s32<A_, B_, 8>), g32, dim3(256), 0, hs2, p, ep, fr); } while (0)
             if (akc && !bkc) T4K_S32(true, false); else if (akc) T4K_S32(true, true); else if (!bkc) T4K_S32(false, false); else T4K_S32(false, true);
 #undef T4K_S32
             T4K_LAUNCH_CHECK();
@@ -2019,7 +2016,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             fr.cp_blocks = grid_for(rider->cp_n, 4); if (fr.cp_blocks > 1024) fr.cp_blocks = 1024;
             rider->cp_blocks = fr.cp_blocks;
         }
-        hipLaunchKernelGGL(k_splitk_fold, dim3(gfold + fr.cp_blocks), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N, ep, fr);
+        T4K_LAUNCH(k_splitk_fold, dim3(gfold + fr.cp_blocks), dim3(BLK), 0, hs, p.part, O, mn, nsplit, alpha, beta, bias, N, ep, fr);
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;
@@ -2263,10 +2260,7 @@ static int head_bwd_launch(float *X2, const float *W2, float *P, const float *TG
     unsigned *slots = nullptr; unsigned epoch = 0;
     if (train) {                                                  // arrival slots of the in-place dX (as linear_bwd_dual); a frozen layer has no dW readers to wait for
         slots = reinterpret_cast<unsigned *>(gate) + 512;
-        static unsigned epochs[64];
-        const int li = lane_of(hs);
-        epoch = ++epochs[li < 63 ? li : 63];
-        if (epoch == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); epoch = ++epochs[li < 63 ? li : 63]; }
+        epoch = next_slot_epoch(hs, slots);                       // the lane's ONE counter, shared with k_gemm_dual32
     }
     HeadBwd hb = { P, TGT, W2, mc2.m1, X2, DW2, DB2, mc2.d1, Y2, DB1, N, EA, EB, train ? 1 : 0, (int)(a1 + a2 + nc), gate, mc2.m2, mc2.d2, mc1 };
     const int EAp = (EA + 3) & ~3;
@@ -2276,7 +2270,7 @@ static int head_bwd_launch(float *X2, const float *W2, float *P, const float *TG
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_dual32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); attr = true; }
     if (lds > 48 * 1024) return fail(T4K_ERR_UNSUPPORTED, "%s: %zu bytes of LDS", who, lds);
-    hipLaunchKernelGGL(k_head_bwd_dual32<8>, dim3((unsigned)(a1 + a2 + nc)), dim3(256), lds, hs, q1, q2, (int)a1, (int)a1, (int)a2, slots, epoch, hb);
+    T4K_LAUNCH(k_head_bwd_dual32<8>, dim3((unsigned)(a1 + a2 + nc)), dim3(256), lds, hs, q1, q2, (int)a1, (int)a1, (int)a2, slots, epoch, hb);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }
@@ -2314,7 +2308,7 @@ int t4k_gemm_f64acc(const float *A, const float *B, float *O, float alpha, float
     T4K_REQUIRE_INIT();
     if (!A || !B || !O || M < 0 || N < 0 || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_gemm_f64acc: bad argument");
     const long total = (long)M * N * C; if (total == 0) return T4K_OK;
-    hipLaunchKernelGGL(k_gemm_f64, dim3(grid_for(total)), dim3(BLK), 0, S(s), A, B, O, alpha, beta, M, N, K, C);
+    T4K_LAUNCH(k_gemm_f64, dim3(grid_for(total)), dim3(BLK), 0, S(s), A, B, O, alpha, beta, M, N, K, C);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }

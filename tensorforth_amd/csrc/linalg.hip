@@ -140,31 +140,31 @@ extern "C" {
 int t4k_inverse(float *A, float *I, int K, int *status_dev, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!A || !I || !status_dev || K <= 0) return fail(T4K_ERR_ARG, "t4k_inverse: bad argument");
-    hipLaunchKernelGGL(k_inverse, dim3(1), dim3(BLK), 0, S(s), A, I, K, status_dev);
+    T4K_LAUNCH(k_inverse, dim3(1), dim3(BLK), 0, S(s), A, I, K, status_dev);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_plu(float *A, float *I, int *piv_dev, int K, int *status_dev, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!A || !piv_dev || !status_dev || K <= 0) return fail(T4K_ERR_ARG, "t4k_plu: bad argument");
-    hipLaunchKernelGGL(k_plu, dim3(1), dim3(BLK), 0, S(s), A, I, piv_dev, K, status_dev);
+    T4K_LAUNCH(k_plu, dim3(1), dim3(BLK), 0, S(s), A, I, piv_dev, K, status_dev);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_lu_inverse(float *A, float *I, int *piv_dev, int K, int *status_dev, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!A || !I || !piv_dev || !status_dev || K <= 0) return fail(T4K_ERR_ARG, "t4k_lu_inverse: bad argument");
-    hipLaunchKernelGGL(k_lu_inverse, dim3(1), dim3(BLK), 0, S(s), A, I, piv_dev, K, status_dev);
+    T4K_LAUNCH(k_lu_inverse, dim3(1), dim3(BLK), 0, S(s), A, I, piv_dev, K, status_dev);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_lu_extract(float *LU, int get_u, int K, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!LU || K <= 0) return fail(T4K_ERR_ARG, "t4k_lu_extract: bad argument");
-    hipLaunchKernelGGL(k_lu_extract, dim3(grid_for((long)K * K)), dim3(BLK), 0, S(s), LU, get_u, K);
+    T4K_LAUNCH(k_lu_extract, dim3(grid_for((long)K * K)), dim3(BLK), 0, S(s), LU, get_u, K);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_logdet(const float *LU, int K, float *logdet_dev, int *sign_dev, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!LU || !logdet_dev || !sign_dev || K <= 0) return fail(T4K_ERR_ARG, "t4k_logdet: bad argument");
-    hipLaunchKernelGGL(k_logdet, dim3(1), dim3(BLK), 0, S(s), LU, K, logdet_dev, sign_dev);
+    T4K_LAUNCH(k_logdet, dim3(1), dim3(BLK), 0, S(s), LU, K, logdet_dev, sign_dev);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

@@ -354,14 +354,14 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
         attr = true;
     }
     if (xfp) {
-        if (LG == 16)      hipLaunchKernelGGL((k_linsmall_fwd<16, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
-        else if (LG == 32) hipLaunchKernelGGL((k_linsmall_fwd<32, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
-        else               hipLaunchKernelGGL((k_linsmall_fwd<64, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+        if (LG == 16)      T4K_LAUNCH((k_linsmall_fwd<16, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+        else if (LG == 32) T4K_LAUNCH((k_linsmall_fwd<32, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+        else               T4K_LAUNCH((k_linsmall_fwd<64, true>), g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
         return T4K_OK;
     }
-    if (LG == 16)      hipLaunchKernelGGL(k_linsmall_fwd<16>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
-    else if (LG == 32) hipLaunchKernelGGL(k_linsmall_fwd<32>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
-    else               hipLaunchKernelGGL(k_linsmall_fwd<64>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+    if (LG == 16)      T4K_LAUNCH(k_linsmall_fwd<16>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+    else if (LG == 32) T4K_LAUNCH(k_linsmall_fwd<32>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
+    else               T4K_LAUNCH(k_linsmall_fwd<64>, g, b, lds, hs, X, W, B, Y, P, N, E0, E1, xf, oep);
     return T4K_OK;
 }
 
@@ -378,7 +378,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
             (!TGT || (gatec && st().d_sync && nwg <= st().cu_count)) && (cols_on >= 2 || N * E1 <= 32768)) {
             static bool attrc = false;
             if (!attrc) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd_cols), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attrc = true; }
-            hipLaunchKernelGGL(k_linsmall_bwd_cols, dim3(nwg), dim3(256), ldsc, hs, X, W, DY, DX, DW, DB, N, E0, E1, (train && DW) ? 1 : 0, gatec,
+            T4K_LAUNCH(k_linsmall_bwd_cols, dim3(nwg), dim3(256), ldsc, hs, X, W, DY, DX, DW, DB, N, E0, E1, (train && DW) ? 1 : 0, gatec,
                                MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
             return true;
         }
@@ -403,7 +403,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attr = true; }
-    hipLaunchKernelGGL(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB, CBK);
+    T4K_LAUNCH(k_linsmall_bwd, dim3(nA + nB), dim3(256), lds, hs, X, W, DY, DX, DW, DB, N, E0, E1, nB, nA, RA, gate, alias ? 1 : 0, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB, CBK);
     return true;
 }
 

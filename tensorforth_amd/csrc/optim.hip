@@ -2,6 +2,7 @@
 // Reference: k_sgd / k_adam / k_adamw src/nn/nmath.cu:419-472 (Model::sgd/adam/adamw
 // src/nn/gradient.cu:132-169); k_rand src/util.cu:56-70.
 #include "t4k_common.h"
+#include <string.h>
 
 using namespace t4k;
 
@@ -97,6 +98,43 @@ __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_r
     }
 }
 
+// ---- the optimizer step with a conv stack's pending partial fold inside (t4k_opt_step).  Workgroups [0, nfold) fold 16 gradient
+// elements each out of the backward's per-workgroup partial rows (cs_fold16: the arithmetic and order of k_cs_fold) and update those
+// parameters at once; workgroups behind them own the 1024-element chunks of k_opt_chunked, one element per thread, and leave the
+// tensors the fold workgroups handle alone (`skip`: bit i = table record i).  One launch instead of k_cs_fold + k_opt_chunked; the
+// result is bit-identical to the two launches (dg = DG + fold either way).
+struct FoldRecs { t4k_param_rec r[6]; };                   // the table record behind each fold segment
+__device__ __forceinline__ void opt1(int kind, const t4k_param_rec &r, long j, float dg, float lr, float b1, float b2, float wd, bool mom) {
+    float g = r.G[j];
+    if (kind == 0) {
+        float m = mom ? r.M[j] : 0.f;
+        sgd1(g, dg, m, r.Nw, lr, b1, mom);
+        if (mom) r.M[j] = m;
+    } else {
+        float m = r.M[j], v = r.V[j];
+        if (kind == 1) adam1(g, dg, m, v, lr, b1, b2); else adamw1(g, dg, m, v, lr, b1, b2, wd);
+        r.M[j] = m; r.V[j] = v;
+    }
+    r.G[j] = g; r.DG[j] = 0.f;
+}
+__global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec *__restrict__ tab, int nt, float lr, float b1, float b2, float wd,
+                                                   const CsFoldArgs fa, const FoldRecs fr, int nfold, unsigned long long skip) {
+    __shared__ CsFoldSm sm;
+    const bool mom = !(fabsf(b1) < DU_EPS);
+    if ((int)blockIdx.x < nfold) {
+        float v; int q, k;
+        if (cs_fold16(fa, blockIdx.x, sm, v, q, k)) opt1(kind, fr.r[q], k, fa.seg[q].dst[k] + v, lr, b1, b2, wd, mom);
+        return;
+    }
+    const int b = (int)blockIdx.x - nfold;
+    int i = 0;
+    while (i + 1 < nt && b >= tab[i + 1].pad) i++;
+    if ((skip >> i) & 1ull) return;
+    const t4k_param_rec r = tab[i];
+    const long j = ((long)b - r.pad) * 1024 + threadIdx.x;
+    if (j < r.n) opt1(kind, r, j, r.DG[j], lr, b1, b2, wd, mom);
+}
+
 // d[i] = scale * (bias + u_i): element i <- Philox(counter = (off+i)/4)[i%4].
 // The stream state (counter, seed) is read from device memory and advanced by the last workgroup to
 // finish, so the same launch captured in a hipGraph draws a fresh slice of the stream on every replay.
@@ -145,7 +183,7 @@ RngArg rng_draw(hipStream_t hs, uint64_t nq, bool sample_keyed) {
 void rng_sync_device(hipStream_t hs) {
     State &g = st();
     if (!g.d_rng || g.d_rng_ctr == g.rng_ctr) return;
-    hipLaunchKernelGGL(k_rng_seed_dev, dim3(1), dim3(1), 0, hs, g.d_rng, g.rng_ctr, g.seed);
+    T4K_LAUNCH(k_rng_seed_dev, dim3(1), dim3(1), 0, hs, g.d_rng, g.rng_ctr, g.seed);
     g.d_rng_ctr = g.rng_ctr;
 }
 }
@@ -156,19 +194,19 @@ int t4k_sgd(float *G, float *DG, float *M, int Nw, float lr, float beta, long n,
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!G || !DG || Nw == 0) return fail(T4K_ERR_ARG, "t4k_sgd: bad argument");
     if (!(fabsf(beta) < DU_EPS) && !M) return fail(T4K_ERR_ARG, "t4k_sgd: momentum tensor missing");
-    hipLaunchKernelGGL(k_sgd, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, Nw, lr, beta, n);
+    T4K_LAUNCH(k_sgd, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, Nw, lr, beta, n);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_adam(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!G || !DG || !M || !V) return fail(T4K_ERR_ARG, "t4k_adam: null");
-    hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, V, lr, b1, b2, n);
+    T4K_LAUNCH(k_adam, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, V, lr, b1, b2, n);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_adamw(float *G, float *DG, float *M, float *V, float lr, float b1, float b2, float wd, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!G || !DG || !M || !V) return fail(T4K_ERR_ARG, "t4k_adamw: null");
-    hipLaunchKernelGGL(k_adamw, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, V, lr, b1, b2, wd, n);
+    T4K_LAUNCH(k_adamw, dim3(grid_for(n)), dim3(BLK), 0, S(s), G, DG, M, V, lr, b1, b2, wd, n);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long max_n,
@@ -176,7 +214,7 @@ int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long ma
     T4K_REQUIRE_INIT(); if (n_tensors <= 0) return T4K_OK;
     if (!tab_dev || kind < 0 || kind > 2) return fail(T4K_ERR_ARG, "t4k_opt_multi: bad argument");
     int gx = grid_for(max_n); if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(k_opt_multi, dim3(gx, n_tensors), dim3(BLK), 0, S(s), kind, tab_dev, lr, b1, b2, wd);
+    T4K_LAUNCH(k_opt_multi, dim3(gx, n_tensors), dim3(BLK), 0, S(s), kind, tab_dev, lr, b1, b2, wd);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
@@ -184,7 +222,31 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n
                     float lr, float b1, float b2, float wd, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n_tensors <= 0 || n_chunks <= 0) return T4K_OK;
     if (!tab_dev || kind < 0 || kind > 2) return fail(T4K_ERR_ARG, "t4k_opt_chunked: bad argument");
-    hipLaunchKernelGGL(k_opt_chunked, dim3((unsigned)n_chunks), dim3(BLK), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd);
+    T4K_LAUNCH(k_opt_chunked, dim3((unsigned)n_chunks), dim3(BLK), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+
+// the optimizer step of a model: t4k_opt_chunked, plus whatever the backward deferred to it (t4k_conv_stack_bwd with train | 4: the
+// dF | dB partial fold) inside the same launch.  tab_host = the host's copy of the table tab_dev holds.
+int t4k_opt_step(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
+                 float lr, float b1, float b2, float wd, t4k_stream_t s) {
+    T4K_REQUIRE_INIT_NOFLUSH();
+    State &g = st();
+    if (!(g.pending & 1)) return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s);
+    const PendingFold &pf = pending_fold();
+    FoldRecs fr; memset((void *)&fr, 0, sizeof(fr));
+    unsigned long long skip = 0;
+    static int on = -1; if (on < 0) { const char *e = getenv("T4K_OPT_FOLD"); on = e ? atoi(e) : 1; }
+    bool ok = on && tab_dev && tab_host && kind >= 0 && kind <= 2 && n_tensors > 0 && n_tensors <= 64 && n_chunks > 0 && pf.hs == S(s) && !g.capturing;
+    for (int q = 0; ok && q < pf.fa.nseg; q++) {              // every pending segment must be a whole gradient tensor of this table
+        int hit = -1;
+        for (int i = 0; i < n_tensors; i++) if (tab_host[i].DG == pf.fa.seg[q].dst && tab_host[i].n == (long)pf.fa.seg[q].n) { hit = i; break; }
+        if (hit < 0) ok = false; else { fr.r[q] = tab_host[hit]; skip |= 1ull << hit; }
+    }
+    if (!ok) { flush_pending(); return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s); }
+    g.pending &= ~1;
+    const int nfold = pf.fa.total / 16;
+    T4K_LAUNCH(k_opt_step, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, pf.fa, fr, nfold, skip);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
@@ -203,14 +265,14 @@ int t4k_dropout_mask(float *mask, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!mask) return fail(T4K_ERR_ARG, "t4k_dropout_mask: null");
     const RngArg ra = rng_draw(S(s), (uint64_t)((n + 3) / 4), true);
-    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), mask, n, (int)T4K_UNIFORM, 0.0f, 1.0f, ra);
+    T4K_LAUNCH(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), mask, n, (int)T4K_UNIFORM, 0.0f, 1.0f, ra);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_rand(float *d, long n, int opt, float bias, float scale, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n <= 0) return T4K_OK;
     if (!d) return fail(T4K_ERR_ARG, "t4k_rand: null");
     const RngArg ra = rng_draw(S(s), (uint64_t)((n + 3) / 4));
-    hipLaunchKernelGGL(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), d, n, opt, bias, scale, ra);
+    T4K_LAUNCH(k_rand, dim3(grid_for((n + 3) / 4)), dim3(BLK), 0, S(s), d, n, opt, bias, scale, ra);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

@@ -77,11 +77,11 @@ int launch_reduce(const float *X, const float *Y, long n, float avg, float *out,
     long g = (n + (long)BLK * 16 - 1) / ((long)BLK * 16);
     if (g > RED_MAX_PARTS) g = RED_MAX_PARTS;
     if (g <= 1) {
-        hipLaunchKernelGGL(k_reduce1<OP>, dim3(1), dim3(BLK), 0, s, X, Y, n, avg, out, vec);
+        T4K_LAUNCH(k_reduce1<OP>, dim3(1), dim3(BLK), 0, s, X, Y, n, avg, out, vec);
     } else {
         float *part = ws_for(s);
-        hipLaunchKernelGGL(k_reduce1<OP>, dim3((int)g), dim3(BLK), 0, s, X, Y, n, avg, part, vec);
-        hipLaunchKernelGGL(k_reduce2<(OP == R_MAX || OP == R_MIN) ? OP : R_SUM>, dim3(1), dim3(BLK), 0, s, part, (int)g, out);
+        T4K_LAUNCH(k_reduce1<OP>, dim3((int)g), dim3(BLK), 0, s, X, Y, n, avg, part, vec);
+        T4K_LAUNCH(k_reduce2<(OP == R_MAX || OP == R_MIN) ? OP : R_SUM>, dim3(1), dim3(BLK), 0, s, part, (int)g, out);
     }
     T4K_LAUNCH_CHECK();
     return T4K_OK;
@@ -312,10 +312,10 @@ static int bn_stats_sync(const float *X, const float *Y, float *stat, float *DW,
     const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
     float *part = ws_for(s), *sums = part + (size_t)nch * 2 * C;
     if (((size_t)nch * 2 + 4) * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
-    hipLaunchKernelGGL(k_bn_part<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), X, Y, part, NHW, C, rpc);
-    hipLaunchKernelGGL(k_bn_sums, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, sums, C, (int)nch);
+    T4K_LAUNCH(k_bn_part<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), X, Y, part, NHW, C, rpc);
+    T4K_LAUNCH(k_bn_sums, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, sums, C, (int)nch);
     int rc = t4k_allreduce_sum(sums, 2L * C, s); if (rc != T4K_OK) return rc;
-    hipLaunchKernelGGL(k_bn_fin_sync<MODE>, dim3((C + BLK - 1) / BLK), dim3(BLK), 0, S(s), sums, stat, DW, DB,
+    T4K_LAUNCH(k_bn_fin_sync<MODE>, dim3((C + BLK - 1) / BLK), dim3(BLK), 0, S(s), sums, stat, DW, DB,
                        (float)NHW * (float)t4k_comm_world(), C, train);
     return T4K_OK;
 }
@@ -344,45 +344,45 @@ int t4k_nan_inf(const float *src, long n, int *cnt, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!src || !cnt) return fail(T4K_ERR_ARG, "t4k_nan_inf: null");
     T4K_HIP(hipMemsetAsync(cnt, 0, sizeof(int), S(s)));
-    if (n > 0) hipLaunchKernelGGL(k_nan_inf, dim3(grid_for(n, 8)), dim3(BLK), 0, S(s), src, n, cnt);
+    if (n > 0) T4K_LAUNCH(k_nan_inf, dim3(grid_for(n, 8)), dim3(BLK), 0, S(s), src, n, cnt);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_dot(const float *A, const float *B, float *O, float alpha, float beta, int K, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!A || !B || !O || K < 0 || C < 1) return fail(T4K_ERR_ARG, "t4k_dot: bad argument");
-    hipLaunchKernelGGL(k_dot, dim3(C), dim3(BLK), 0, S(s), A, B, O, alpha, beta, K, C);
+    T4K_LAUNCH(k_dot, dim3(C), dim3(BLK), 0, S(s), A, B, O, alpha, beta, K, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_softmax(const float *I, float *O, int N, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || C <= 0) return T4K_OK;
-    hipLaunchKernelGGL(k_softmax, dim3((N + 3) / 4), dim3(BLK), 0, S(s), I, O, N, C);
+    T4K_LAUNCH(k_softmax, dim3((N + 3) / 4), dim3(BLK), 0, S(s), I, O, N, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_logsoftmax(const float *I, float *O, int N, int C, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || C <= 0) return T4K_OK;
     if (!I || !O) return fail(T4K_ERR_ARG, "t4k_logsoftmax: null tensor");
-    hipLaunchKernelGGL(k_logsoftmax, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, S(s), I, O, N, C);
+    T4K_LAUNCH(k_logsoftmax, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, S(s), I, O, N, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_hit(const float *out, const float *hot, int N, int E, int *cnt, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!out || !hot || !cnt || N < 0 || E < 1) return fail(T4K_ERR_ARG, "t4k_hit: bad argument");
-    if (E <= 32)       hipLaunchKernelGGL(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
-    else if (E <= 256) hipLaunchKernelGGL(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
-    else               hipLaunchKernelGGL(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
+    if (E <= 32)       T4K_LAUNCH(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
+    else if (E <= 256) T4K_LAUNCH(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
+    else               T4K_LAUNCH(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, nullptr, nullptr);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_onehot_hit(const uint32_t *label, float *hot, const float *out, int N, int E, int *cnt, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!label || !out || !hot || !cnt || N < 0 || E < 1) return fail(T4K_ERR_ARG, "t4k_onehot_hit: bad argument");
-    if (E <= 32)       hipLaunchKernelGGL(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
-    else if (E <= 256) hipLaunchKernelGGL(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
-    else               hipLaunchKernelGGL(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
+    if (E <= 32)       T4K_LAUNCH(k_hit<1>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
+    else if (E <= 256) T4K_LAUNCH(k_hit<8>,  dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
+    else               T4K_LAUNCH(k_hit<64>, dim3(1), dim3(BLK), 0, S(s), out, hot, N, E, cnt, label, hot);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (N <= 0 || E0 <= 0) return T4K_OK;
-    hipLaunchKernelGGL(k_dlinear_db, dim3((E0 + 63) / 64), dim3(BLK), 0, S(s), DY, DB, N, E0);
+    T4K_LAUNCH(k_dlinear_db, dim3((E0 + 63) / 64), dim3(BLK), 0, S(s), DY, DB, N, E0);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B,
@@ -396,10 +396,10 @@ int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const
         const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
         float *part = ws_for(s);
         if ((size_t)nch * 2 * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
-        hipLaunchKernelGGL(k_bn_part<0>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), I, (const float *)nullptr, part, NHW, C, rpc);
-        hipLaunchKernelGGL(k_bn_fin<0>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, (float *)nullptr, (float *)nullptr, NHW, C, (int)nch, 0);
-    } else hipLaunchKernelGGL(k_bn_stats, dim3(C), dim3(BLK), 0, S(s), I, stat, NHW, C);
-    hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), I, O, XH, W, B, stat, total, C);
+        T4K_LAUNCH(k_bn_part<0>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), I, (const float *)nullptr, part, NHW, C, rpc);
+        T4K_LAUNCH(k_bn_fin<0>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, (float *)nullptr, (float *)nullptr, NHW, C, (int)nch, 0);
+    } else T4K_LAUNCH(k_bn_stats, dim3(C), dim3(BLK), 0, S(s), I, stat, NHW, C);
+    T4K_LAUNCH(k_bn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), I, O, XH, W, B, stat, total, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *DX,
@@ -413,10 +413,10 @@ int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *D
         const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
         float *part = ws_for(s);
         if ((size_t)nch * 2 * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
-        hipLaunchKernelGGL(k_bn_part<1>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), DY, XH, part, NHW, C, rpc);
-        hipLaunchKernelGGL(k_bn_fin<1>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, DW, DB, NHW, C, (int)nch, train);
-    } else hipLaunchKernelGGL(k_dbn_stats, dim3(C), dim3(BLK), 0, S(s), DY, XH, stat, DW, DB, NHW, C, train);
-    hipLaunchKernelGGL(k_dbn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), W, DY, XH, DX, stat, total, C);
+        T4K_LAUNCH(k_bn_part<1>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), DY, XH, part, NHW, C, rpc);
+        T4K_LAUNCH(k_bn_fin<1>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, DW, DB, NHW, C, (int)nch, train);
+    } else T4K_LAUNCH(k_dbn_stats, dim3(C), dim3(BLK), 0, S(s), DY, XH, stat, DW, DB, NHW, C, train);
+    T4K_LAUNCH(k_dbn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), W, DY, XH, DX, stat, total, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 

@@ -33,9 +33,14 @@ int spin_check() {
     const int code = *(volatile int *)g.spin_err;
     if (!code) return T4K_OK;
     *(volatile int *)g.spin_err = 0;
-    static const char *what[] = { "", "dual GEMM writer gate", "dual-GEMM epoch slots", "pair-mode GEMM flag", "head backward dW gate", "head backward staging gate" };
-    return fail(T4K_ERR_HIP, "an inter-workgroup wait timed out (%s): the launch's workgroups were not co-resident - results of that launch are invalid; "
-                             "set T4K_GEMM_DUAL=0 T4K_GEMM_DUAL32=0 T4K_LINSMALL_GATE=0 on a shared or partitioned device", what[code > 0 && code < 6 ? code : 0]);
+    // what waited, and the switch that takes that path out (t4k.h / DESIGN.md section 9)
+    static const char *what[] = { "unknown wait", "dual GEMM writer gate", "dual-GEMM epoch slots", "pair-mode GEMM flag", "head backward dW gate",
+                                  "head backward staging gate", "column-sliced head backward target store", "conv-stack head band exchange", "fused head backward target store" };
+    static const char *off[]  = { "T4K_GEMM_DUAL=0 T4K_GEMM_DUAL32=0 T4K_LINSMALL_GATE=0 T4_STACK_HEAD=0 T4_HEAD_BWD=0", "T4K_GEMM_DUAL=0", "T4K_GEMM_DUAL32=0", "T4K_GEMM_PLAIN_PAIR=0",
+                                  "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_COLS=0", "T4_STACK_HEAD=0 (or T4K_STACK_HEAD=0)", "T4_HEAD_BWD=0 (or T4K_HEAD_BWD=0)" };
+    const int k = (code > 0 && code < 9) ? code : 0;
+    return fail(T4K_ERR_HIP, "an inter-workgroup wait timed out (code %d: %s): the launch's workgroups were not co-resident - results of that launch are invalid; "
+                             "on a shared or partitioned device set %s", code, what[k], off[k]);
 }
 }
 namespace { struct GraphRec { hipGraphExec_t exec; uint64_t rng_adv; }; }
@@ -88,6 +93,7 @@ void t4k_shutdown(void) {
 }
 
 const char *t4k_last_error(void)  { return st().err; }
+unsigned long long t4k_launch_count(void) { return st().launches; }
 const char *t4k_backend_name(void) { return "hip-gfx950"; }
 
 int t4k_device_info(int *cu_count, int *clock_khz, size_t *hbm_bytes) {

@@ -38,9 +38,14 @@ struct State {
     int        *d_sync  = nullptr;     // 32768 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags, [8192,32768) per-stream arrival gates (gate_for / flags_for; ints [512,1024) of a stream's block are the epoch slots of k_gemm_dual32)
     int        *spin_err = nullptr;   // pinned, device-visible error word of the inter-workgroup waits (spin_check)
     int         cu_count = 256;
-    char        err[256] = {0};
+    unsigned    slot_epoch[16] = {};  // per stream lane: launch count of the kernels that tag the arrival slots (next_slot_epoch)
+    unsigned long long launches = 0;  // kernels launched by the library since t4k_init (t4k_launch_count)
+    int         pending = 0;          // work a launch left for the NEXT entry point (pending.h): bit 0 = a conv stack's dF | dB partial fold
+    char        err[512] = {0};
 };
 State &st();
+// every kernel launch of the library goes through this macro and is counted: bench.py prints the MEASURED launches per step
+#define T4K_LAUNCH(kernel, ...) do { ++t4k::st().launches; hipLaunchKernelGGLInternal((kernel), __VA_ARGS__); } while (0)
 // what a drawing kernel receives: eager = (base, seed) by value and state == nullptr; inside a graph = the device copy
 struct RngArg { uint64_t base, seed; uint64_t *state; };
 RngArg rng_draw(hipStream_t hs, uint64_t nq, bool sample_keyed = false);    // host: reserve nq counters (4 elements each) of the stream for one launch (optim.hip)
@@ -70,6 +75,16 @@ inline int *gate_for(const void *s, int slot) {
 }
 // 16 broadcast flags of the same stream, one per 64-byte line (hundreds of waiting workgroups poll these instead of the counter)
 inline int *flags_for(const void *s) { int *g0 = gate_for(s, 0); return g0 ? g0 + 1024 : nullptr; }
+// The arrival slots (ints [512, 1024) of a lane's gate block) are tagged with a per-lane launch EPOCH by every kernel that uses them
+// (k_gemm_dual32, k_head_bwd_dual32): ONE counter per lane, shared by all of them - with a counter per kernel a stale tag left by one
+// could equal the other's current epoch and let an in-place dX writer pass before the dW readers have read X.
+// Never 0; the slots are cleared when the counter wraps.  Call only with a stream lane_of() knows.
+inline unsigned next_slot_epoch(hipStream_t hs, unsigned *slots) {
+    const int li = lane_of(hs);
+    unsigned &e = st().slot_epoch[(li >= 0 && li < 15) ? li : 15];
+    if (++e == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); e = 1; }
+    return e;
+}
 inline float *ws_for(const void *s) {            // accepts a t4k_stream_t or an already resolved hipStream_t
     State &g = st();
     if (s) for (int i = 0; i < g.n_lane; i++) if ((const void *)g.lane[i].s == s) return (float *)g.lane[i].ws;
@@ -90,7 +105,13 @@ void gemm_set_spin_err(int *p);          // gemm.hip
 void linsmall_set_spin_err(int *p);      // linear_small.hip
 int  spin_check();                       // runtime.hip: T4K_OK, or T4K_ERR_HIP when a wait timed out since the last check (clears the word)
 
-#define T4K_REQUIRE_INIT() do { if (!t4k::st().ready) return t4k::fail(T4K_ERR_NODEVICE, "t4k_init not called or no gfx950 device"); } while (0)
+// Deferred work.  t4k_conv_stack_bwd(train | 4) leaves its per-workgroup dF | dB partial rows UNFOLDED: t4k_opt_step, when it is the next
+// entry point, folds them inside the optimizer launch (fold + update = one launch); EVERY other entry point (they all start with
+// T4K_REQUIRE_INIT) first runs the stand-alone fold on the stream of the backward, so whatever the caller does next - read a gradient
+// tensor, accumulate a second backward, all-reduce the slab - sees exactly what the undeferred path would have left.
+void flush_pending();                    // conv_stack.hip
+#define T4K_REQUIRE_INIT_NOFLUSH() do { if (!t4k::st().ready) return t4k::fail(T4K_ERR_NODEVICE, "t4k_init not called or no gfx950 device"); } while (0)
+#define T4K_REQUIRE_INIT() do { T4K_REQUIRE_INIT_NOFLUSH(); if (t4k::st().pending) t4k::flush_pending(); } while (0)
 #define T4K_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) return t4k::hip_fail(_e, #call); } while (0)
 #define T4K_LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return t4k::hip_fail(_e, "kernel launch"); } while (0)
 
@@ -240,5 +261,38 @@ __device__ __forceinline__ void rng_state_read(const uint64_t *state, uint64_t &
     base = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     seed = __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// ---- fold of a conv stack's per-workgroup dF | dB partial rows (conv_stack.hip): dst[e] += sum over rows, in row order (deterministic).
+// A 1024-thread block handles 16 elements x 64 row groups: group g adds rows g, g+64, ... (independent loads, one round trip for up to
+// 256 rows), the 64 group sums are then added in order through LDS.  Used by k_cs_fold and, with the update behind it, by k_opt_step.
+struct CsFoldSeg { float *dst; int off, n, start; };                  // elements [off, off+n) of a partial row -> dst[0..n); start = first global element id
+struct CsFoldArgs { const float *part; long row; int nparts, nseg, total, pad_; CsFoldSeg seg[6]; };
+struct CsFoldSm { float a[64][17], b[4][17]; };
+// returns true for the ONE thread per element that holds the sum (`v`), with `q` the segment and `k` the element inside it
+__device__ __forceinline__ bool cs_fold16(const CsFoldArgs &a, int blk, CsFoldSm &sm, float &v, int &q, int &k) {
+    const int el = threadIdx.x & 15, g = threadIdx.x >> 4, e = blk * 16 + el;
+    int off = -1; q = 0; k = 0;
+#pragma unroll
+    for (int t = 0; t < 6; t++) if (t < a.nseg && e >= a.seg[t].start && e < a.seg[t].start + a.seg[t].n) { k = e - a.seg[t].start; off = a.seg[t].off + k; q = t; }
+    float s = 0.f;
+    if (off >= 0) {
+        const float *src = a.part + off;
+#pragma unroll 4
+        for (int i = g; i < a.nparts; i += 64) s += src[(long)i * a.row];
+    }
+    sm.a[g][el] = s;
+    __syncthreads();
+    if (g < 4 && off >= 0) {                                        // 4 lanes per element add 16 group sums each, in order ...
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) t += sm.a[g * 16 + i][el];
+        sm.b[g][el] = t;
+    }
+    __syncthreads();
+    v = ((sm.b[0][el] + sm.b[1][el]) + sm.b[2][el]) + sm.b[3][el];   // ... and the four are added in order
+    return g == 0 && off >= 0;
+}
+struct PendingFold { CsFoldArgs fa; hipStream_t hs; };
+PendingFold &pending_fold();             // conv_stack.hip
 
 } // namespace t4k

@@ -38,6 +38,8 @@ const char *ten4_output(ten4_vm *h) { h->out = h->vm.take_output(); return h->ou
 int ten4_grad_slab(ten4_vm *, float **p, long *n) {
     t4::Model *m = t4::Model::current;
     if (!m || !m->gslab) return -1;
+    t4::Model::slab_exported();                         // the caller reads the slab behind the library's back (torch.distributed on a zero-copy view):
+    t4k_sync(t4::stream());                             // nothing may stay deferred - now (any pending fold runs) or later
     *p = m->gslab->data; *n = (long)m->gslab->numel;
     return 0;
 }

@@ -103,10 +103,29 @@ bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true
 bool Model::use_stack  = getenv("T4_STACK") ? atoi(getenv("T4_STACK")) != 0 : true;
 bool Model::use_head_bwd = getenv("T4_HEAD_BWD") ? atoi(getenv("T4_HEAD_BWD")) != 0 : true;     // T4_HEAD_BWD=0: classifier-head backward and the linear layer in front of it as separate launches
 bool Model::use_stack_head = getenv("T4_STACK_HEAD") ? atoi(getenv("T4_STACK_HEAD")) != 0 : true;   // T4_STACK_HEAD=0: the classifier head behind a conv stack keeps its own launches
+bool Model::use_lazy_dx0 = getenv("T4_LAZY_DX0") ? atoi(getenv("T4_LAZY_DX0")) != 0 : true;
+bool Model::use_opt_fold = getenv("T4_OPT_FOLD") ? atoi(getenv("T4_OPT_FOLD")) != 0 : true;   // T4_OPT_FOLD=0: the conv stack's partial fold keeps its own launch behind the backward
 bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
 
+// Lazy dX of the first layer.  `in = dx` (backprop.cu:185) leaves the gradient w.r.t. the input batch in layer 0 and in the first conv
+// layer's scratch tensor; a training loop never reads either.  The conv-stack backward skips it (t4k_conv_stack_bwd, train | 8) and the
+// two tensors carry a mark; the first word that resolves one of them (Store::du2obj: `0 n@`, `0 nn.ex`, ten4_fetch, a chained backprop ...)
+// has it produced from the dO and the filter copy that backward left.  The next forward overwrites layer 0 and ends the offer (after it
+// `0 nn.ex` would show an EARLIER backward's dX - the one observable difference; T4_LAZY_DX0=0 restores the eager store).
+void Model::clear_dx0_marks() {
+    if (!dx0_stale_) return;
+    dx0_stale_ = false;
+    if (!layer.empty()) { at(0).stale_owner = nullptr; if (at(0).grad[4]) at(0).grad[4]->stale_owner = nullptr; }
+}
+void Model::materialize_dx0() {
+    if (!dx0_stale_) return;
+    clear_dx0_marks();
+    t4k_conv_stage stg[3]; int ops = 0;
+    if (stack_at(0, stg, ops) > 0) chk(t4k_conv_stack_dx0(stg, at(0).N(), stream()), "nn#bstack dX0");
+}
 void Model::invalidate() {
+    clear_dx0_marks();
     for (GraphSlot *g : { &g_fwd_, &g_bwd_, &g_opt_ }) { if (g->g) t4k_graph_destroy(g->g); *g = GraphSlot(); }
     finalized_ = false;
 }
@@ -264,6 +283,7 @@ static void dp_bn_mode(bool train) {
     if (t4k_comm_world() > 0) t4k_comm_sync_batchnorm(train && want);
 }
 void Model::run_forward(Tensor &input) {
+    clear_dx0_marks();                                   // this pass overwrites layer 0: a skipped dX of the previous backward is gone for good
     dp_bn_mode(train);
     const int L = (int)layer.size();
     Tensor &n0 = at(0);
@@ -617,7 +637,10 @@ void Model::run_backward(Tensor &tgt) {
                 const int k0 = stack_end_[i];
                 t4k_conv_stage stg[3]; int ops = 0;
                 const int ns = stack_at(k0, stg, ops);
-                if (ns > 0 && k0 + ops - 1 == i && chk(t4k_conv_stack_bwd(dy, stg, ns, at(k0).N(), (train ? 1 : 0) | ((k0 < (int)stack_fresh_.size() && stack_fresh_[k0]) ? 0 : 2), s), "nn#bstack") == T4K_OK) {
+                if (ns > 0 && k0 + ops - 1 == i && chk(t4k_conv_stack_bwd(dy, stg, ns, at(k0).N(), (train ? 1 : 0) | ((k0 < (int)stack_fresh_.size() && stack_fresh_[k0]) ? 0 : 2) | ((use_opt_fold && !grad_hook && !capturing_) ? 4 : 0) | ((use_lazy_dx0 && k0 == 0 && !capturing_ && !use_graphs) ? 8 : 0), s), "nn#bstack") == T4K_OK) {
+                    if (k0 == 0 && use_lazy_dx0 && t4k_conv_stack_dx0_pending(stg[0].O)) {
+                        dx0_stale_ = true; at(0).stale_owner = this; if (at(0).grad[4]) at(0).grad[4]->stale_owner = this;
+                    }
                     for (int k = i; k >= k0; k--) if (at(k).grad_fn == T4K_L_CONV) grads_ready(k, at(k));      // slab segments complete, last layer first
                     dy = at(k0).data; j += i - k0; i = k0;
                     continue;
@@ -796,7 +819,7 @@ void Model::build_table(Optim op) {                      // one multi-tensor lau
         }
     }
     if (tab_dev) t4k_free(tab_dev);
-    tab_n = (int)recs.size(); tab_kind = op; tab_dev = nullptr;
+    tab_n = (int)recs.size(); tab_kind = op; tab_dev = nullptr; tab_host_ = recs;
     if (tab_n) {
         t4k_malloc(&tab_dev, recs.size() * sizeof(t4k_param_rec));
         t4k_memcpy_h2d(tab_dev, recs.data(), recs.size() * sizeof(t4k_param_rec), stream()); t4k_sync(stream());
@@ -828,7 +851,7 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     dp_finish();
     if (!replay(g_opt_, tab_dev, (int)op, p)) {
         const bool cap = capturing_;
-        chk(t4k_opt_chunked(kind, (const t4k_param_rec *)tab_dev, tab_n, tab_chunks, lr, b1, b2, wd, stream()), nm);   // one workgroup per 1024 parameters
+        chk(t4k_opt_step(kind, (const t4k_param_rec *)tab_dev, tab_host_.data(), tab_n, tab_chunks, lr, b1, b2, wd, stream()), nm);   // one workgroup per 1024 parameters (+ a conv stack's deferred partial fold)
         end_capture(g_opt_, cap);
     }
     NLOG("} Model::%s\n", nm);
@@ -907,6 +930,7 @@ void Model::free_all() {
     for (Tensor *t : gx_) if (t) Store::get().free(*t);
     gx_.clear();
     if (gslab) { Store::get().free(*gslab); gslab = nullptr; }
+    for (int i = 0; i + 1 < (int)layer.size(); i++) if (at(i).grad_fn == T4K_L_CONV) t4k_conv_stack_release(at(i + 1).data);   // what a stack forward saved for its banded backward
     for (int i = (int)layer.size() - 1; i >= 0; i--) Store::get().free(*layer[i]);
     layer.clear();
     if (hot) { Store::get().free(*hot); hot = nullptr; }

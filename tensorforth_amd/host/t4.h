@@ -106,6 +106,7 @@ struct Tensor : Obj {
     DU    xparm = 0;
     float *data = nullptr;                   // device pointer (HBM)
     bool  owns = true;
+    struct Model *stale_owner = nullptr;     // the data is a dX the owner's backward skipped: Store::du2obj has the owner produce it before any word reads it
 
     uint32_t &H() { return shape[0]; }
     uint32_t &W() { return shape[1]; }
@@ -222,6 +223,9 @@ struct Model : Obj {
 
     Tensor &at(int i) { return *layer[i < 0 ? (int)layer.size() + i : i]; }
     int  batch_size() { return layer.empty() ? 1 : (int)layer[0]->N(); }
+    static void slab_exported() { use_opt_fold = false; }   // a zero-copy view of the gradient slab left the VM (ten4_grad_slab): its readers are invisible to the
+                                               // library, so a conv stack's partial fold is never deferred to the optimizer again in this process
+    void materialize_dx0();                    // produce the skipped dX of layer 0 now (Store::du2obj calls it through Tensor::stale_owner)
     void tick() { epoch++; iter = 0; }
 
     Model &add(int fn, uint32_t n = 0, DU bias = 0, uint16_t *opt = nullptr);
@@ -264,6 +268,7 @@ private:
     void run_backward(Tensor &tgt);
     Model &gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd);
     // one-launch optimizer over a device parameter table
+    std::vector<t4k_param_rec> tab_host_;      // host copy of tab_dev (t4k_opt_step matches a deferred fold's tensors against it)
     void *tab_dev = nullptr; int tab_n = 0; long tab_max = 0; int tab_chunks = 0; Optim tab_kind = OPTI_SGD;
     void build_table(Optim op);
     // ---- execution engine: the critical path (activations fwd, dX chain bwd) runs on the main stream;
@@ -288,6 +293,10 @@ private:
     int also_ready_ = -1;                      // a second layer whose gradients the last bstep launch produced (run_backward reports it)
     static bool use_stack_head;                // T4_STACK_HEAD=0: conv stack and classifier head as separate launches
     static bool use_stack;                     // T4_STACK=0: no sample-resident conv stacks (csrc/conv_stack.hip)
+    static bool use_lazy_dx0;                  // T4_LAZY_DX0=0: a conv stack's backward always computes the first layer's dX (default: on demand, materialize_dx0)
+    bool dx0_stale_ = false;
+    void clear_dx0_marks();
+    static bool use_opt_fold;                  // T4_OPT_FOLD=0: the conv stack's dF | dB partial fold as a launch of its own (default: inside the optimizer launch, t4k_opt_step)
     // sample-resident conv stack starting at layer i: [conv + run] x ns (stages filled for the C-ABI); ops = layers it covers
     int  stack_at(int i, t4k_conv_stage *st, int &ops);
     bool finalized_ = false, side_dirty_ = false, capturable_ = true;

@@ -104,7 +104,11 @@ int Store::put(Obj *o) {
     return id;
 }
 void Store::release(Obj *o) { objs_[o->id] = nullptr; free_ids_.push_back(o->id); nlive_--; delete o; }
-Obj &Store::du2obj(DU v) { return *objs_[du_bits(v) >> 2]; }
+Obj &Store::du2obj(DU v) {
+    Obj *o = objs_[du_bits(v) >> 2];
+    if (o && o->type == T_TENSOR && ((Tensor *)o)->stale_owner) ((Tensor *)o)->stale_owner->materialize_dx0();   // a lazily skipped dX: produce it before anybody looks
+    return *o;
+}
 DU   Store::obj2du(Obj &o) { return bits_du(((uint32_t)o.id << 2) | 1u); }
 
 Tensor &Store::tensor(uint64_t sz) {

@@ -52,3 +52,33 @@ def test_conv_stack_device_source_compiles_for_gfx950_without_a_device():
     from tensorforth_amd.lib import T4K
     h = T4K()
     assert h.lib.t4k_conv_stack_selftest() == 0, h.lib.t4k_last_error().decode(errors="replace")[-3000:]
+
+
+def test_release_library_has_no_lab_switches():
+    """The conv-stack ablation hooks (T4K_STACK_LAB_*: kernels that skip work, wrong results) and the stamp pointer hook exist only in a
+    LAB build (make -C tensorforth_amd/csrc LAB=1 -> libt4hip_lab.so); the shipped library does not even contain their names, so no
+    environment variable can switch them on."""
+    blob = open(os.path.join(ROOT, "tensorforth_amd", "libt4hip.so"), "rb").read()
+    for name in (b"T4K_STACK_LAB_NOSTORE", b"T4K_STACK_LAB_NOW1", b"T4K_STACK_LAB_NOXCHG", b"T4K_STACK_PROF_PTR"):
+        assert name + b"\0" not in blob, name               # as a C string of its own (what getenv would be handed); comments of the embedded source may mention it
+    assert b"#define CS_LAB_" not in blob
+    assert b"#ifdef CS_LAB_NOW1" in blob                     # (the embedded device source keeps the guarded text; nothing can define the macro)
+
+
+def test_conv_stack_code_objects_are_cached_on_disk(tmp_path):
+    """hipRTC output is kept on disk keyed by the hash of the specialised source: a second process (another rank, the next run, a tree
+    shipped after build()) loads the code object instead of compiling.  T4K_CACHE_DIR redirects it."""
+    code = ("import os, time; from tensorforth_amd.lib import T4K; h = T4K(); t0 = time.time(); "
+            "assert h.lib.t4k_conv_stack_selftest() == 0; print(time.time() - t0)")
+    env = dict(os.environ, T4K_CACHE_DIR=str(tmp_path), PYTHONPATH=ROOT)
+    t_cold = float(subprocess.check_output(["python3", "-c", code], env=env, cwd=ROOT).decode().split()[-1])
+    objs = [f for f in os.listdir(tmp_path) if f.startswith("cs_") and f.endswith(".hsaco")]
+    assert len(objs) >= 5, objs
+    assert all(open(os.path.join(tmp_path, f), "rb").read(4) == b"\x7fELF" for f in objs)
+    t_warm = float(subprocess.check_output(["python3", "-c", code], env=env, cwd=ROOT).decode().split()[-1])
+    assert t_warm < 0.5 * t_cold + 0.05, (t_cold, t_warm)
+    # a truncated file is not trusted: it is recompiled and replaced
+    victim = os.path.join(tmp_path, objs[0]); full = os.path.getsize(victim)
+    open(victim, "wb").write(b"\x7fELFgarbage")
+    subprocess.check_output(["python3", "-c", code], env=env, cwd=ROOT)
+    assert os.path.getsize(victim) >= 64

@@ -19,5 +19,6 @@ for p in mfma hbm lds; do
   C=$(find "$O/pmc_$p" -name '*counter_collection.csv' | head -1)
   python "$R/tools/pmc_summary.py" "$C" > "$O/pmc_$p.txt"
 done
+python "$R/tools/traffic_json.py" "$(find "$O/pmc_hbm" -name '*counter_collection.csv' | head -1)" "$O/bench_traffic.json" "TCC_EA0 request counters, separate --pmc pass of bench.py, tools/profile_bench.sh $TAG"
 tail -1 "$O/bench.json"
 head -25 "$O/kernel_trace.txt"
