@@ -144,6 +144,16 @@ def extras(vm_cls, local, ms_step, args, torch):
                   "rounds_timed": rounds, "algorithmic_bytes_per_round": gb, "hbm_frac": round(gb / gdt / 1e9 / PEAK_HBM_GBS, 5),
                   "flop_per_round": gf, "mfma_frac": round(gf / gdt / 1e12 / PEAK_F32_MFMA_TFLOPS, 5)}
     g.close()
+    # ---- config #5's strong-scaling denominator: the same net at batch 1024 on ONE GPU (8 x 128 sharded is the weak-scaling line above)
+    b = vm_cls(device=local, seed=1234)
+    txt = b.eval("0 trace\n1024 28 28 1 nn.model 0.5 10 conv2d 2 maxpool relu 0.5 20 conv2d 0.5 dropout 2 maxpool relu flatten 100 linear 0.5 dropout 10 linear softmax constant net\n"
+                 "1024 28 28 1 tensor rand constant img\n: hot ( T -- T ) 1024 0 do 1 i 10 * i 7 * 10 mod + t! loop ;\n10240 vector zeros hot 1024 1 10 1 reshape4 constant lbl\n"
+                 ": steps ( N n -- N ) 1- for img forward lbl backprop 0.01 0.0 nn.sgd next ;\nnet 5 steps\n")
+    assert "?" not in txt.replace("-> ok", ""), txt
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); b.eval("100 steps\n"); torch.cuda.synchronize()
+    out["batch1024_1gpu_ms_per_step"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
+    b.close()
     # ---- dataset-fed step: IDX file -> pinned double buffer (reader thread) -> one staging launch -> forward backprop nn.sgd
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as d:
@@ -254,6 +264,38 @@ def main():
                 k.lib.t4k_comm_destroy()
             elif k.lib.t4k_comm_world() != world or k.lib.t4k_comm_rank() != rank:
                 sys.stderr.write("bench: RCCL communicator has %d ranks, %d asked for\n" % (k.lib.t4k_comm_world(), world)); sys.exit(3)
+    # ---- the one-shot peer exchange (csrc/xchg.hip): every rank's receive window is shared through an IPC handle (all_gather'ed below), the
+    # optimizer launch then sums the gradient slab over the ranks itself - fold + all-reduce + SGD in one kernel, no collective between
+    # `backprop` and `nn.sgd`.  Checked against a known sum before it is trusted; RCCL (above) stays the fallback and carries the scalars.
+    xchg = False
+    if dp and native and world > 1 and os.environ.get("T4_DP_XCHG", "1") == "1":
+        h = (ctypes.c_ubyte * 64)()
+        good = torch.tensor([1.0 if k.lib.t4k_xchg_create(1 << 17, rank, world, h) == 0 else 0.0], device="cuda")
+        mine = torch.tensor(list(h), dtype=torch.uint8, device="cuda")
+        allh = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        dist.all_gather(allh, mine); dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        if float(good.item()) > 0:
+            blob = b"".join(bytes(t.cpu().tolist()) for t in allh)
+            good = torch.tensor([1.0 if k.lib.t4k_xchg_connect(blob) == 0 else 0.0], device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            dist.barrier()
+            if float(good.item()) > 0:                        # self-check: sum over ranks of (rank + 1) * i must be i * world (world + 1) / 2, twice (both window parities)
+                probe = torch.arange(70000, dtype=torch.float32, device="cuda") % 1000
+                for _ in range(2):
+                    v = (probe * (rank + 1)).contiguous()
+                    torch.cuda.synchronize()
+                    rc = k.lib.t4k_xchg_allreduce(v.data_ptr(), v.numel(), None) or k.lib.t4k_sync(None)
+                    okv = rc == 0 and bool(torch.equal(v, probe * (world * (world + 1) // 2)))
+                    good = torch.tensor([1.0 if okv else 0.0], device="cuda"); dist.all_reduce(good, op=dist.ReduceOp.MIN)
+                    if float(good.item()) <= 0:
+                        break
+            xchg = float(good.item()) > 0
+        if not xchg:
+            if rank == 0:
+                sys.stderr.write("bench: one-shot peer exchange unavailable or failed its self-check (%s) - the slab goes through RCCL\n" % k.lib.t4k_last_error().decode(errors="replace")[-300:])
+            k.lib.t4k_xchg_destroy()
+            if native:
+                k.call("t4k_rand_set_shard", rank, world)     # (destroy resets the shard the exchange had set)
     if dp and not native:
         k.call("t4k_rand_set_shard", rank, world)         # torch.distributed reduces the slab; the masks are still keyed by sample
     joined = k.lib.t4k_comm_world() if native else (dist.get_world_size() if dp else 1)
@@ -303,7 +345,7 @@ def main():
     k.lib.t4k_conv_stack_stats.restype = None
     k.lib.t4k_conv_stack_stats(ctypes.byref(cj), ctypes.byref(cd), ctypes.byref(cf))
     stack_mode = "off" if (cj.value + cd.value == 0) else ("jit" if cj.value else "prebuilt")
-    want = {"nn_f": 4, "nn_c": 4}[args.net] + (1 if (dp and native) else 0)     # cs_fwd(+head), head backward + linear, cs_bwd_b, optimizer (+ fold); RCCL between them: the fold keeps its launch
+    want = {"nn_f": 4, "nn_c": 4}[args.net] + (1 if (dp and native and not xchg) else 0)     # cs_fwd(+head), head backward + linear, cs_bwd_b, optimizer (+ fold [+ exchange]); with RCCL between them the fold keeps its launch
     if not args.allow_fallback and os.environ.get("T4_STACK", "1") != "0" and (stack_mode == "off" or cf.value or launches > want + 0.01):
         sys.stderr.write("bench: the timed step is NOT the described path: conv_stack=%s (jit %d, cache %d, failed %d), %.2f launches per step (expected <= %d); "
                          "%s\n(--allow-fallback prints the line anyway)\n" % (stack_mode, cj.value, cd.value, cf.value, launches, want, k.lib.t4k_last_error().decode(errors="replace")[-600:]))
@@ -338,7 +380,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
-                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": round(launches, 2), "launches_source": "t4k_launch_count() around the timed loop", "conv_stack": stack_mode, "allreduce": ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None)),
+                       "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": round(launches, 2), "launches_source": "t4k_launch_count() around the timed loop", "conv_stack": stack_mode, "allreduce": ("one-shot peer exchange inside the optimizer launch (csrc/xchg.hip)" if xchg else ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None))),
                        "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None,
                        "final_loss_note": "random images and labels, batch-SUM gradients (reference semantics): a throughput run, not a convergence test; training parity vs the oracle is in tests/"},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
@@ -349,7 +391,20 @@ def main():
         if sustained:
             out["sustained_ms_per_step"] = round(sustained[0], 4)
             out["sustained_steps"] = sustained[1]
-        if world == 1 and not args.no_extras:
+        if world == 1 and not dp and not args.no_extras:
+            # ---- what the data-parallel machinery itself costs on ONE GPU: the same loop with a one-rank exchange in self mode - the optimizer
+            # launch takes its exchanging form (k_opt_step<true>: pushes to nobody, adds its own element out of the same code path)
+            h = (ctypes.c_ubyte * 64)()
+            if k.lib.t4k_xchg_create(1 << 17, 0, 1, h) == 0 and k.lib.t4k_xchg_connect(bytes(h)) == 0:
+                k.lib.t4k_xchg_self(1)
+                run(args.warmup or 5); torch.cuda.synchronize()
+                l1 = k.lib.t4k_launch_count()
+                t0 = time.perf_counter(); run(args.steps); torch.cuda.synchronize()
+                dms = (time.perf_counter() - t0) / args.steps * 1e3
+                out["dp_overhead_us"] = round((dms - ms_step) * 1e3, 2)
+                out["dp_overhead_note"] = "same %d steps with the one-shot exchange connected (world 1, self mode): %.4f ms/step, %.2f launches/step" % (args.steps, dms, (k.lib.t4k_launch_count() - l1) / args.steps)
+                k.lib.t4k_xchg_self(0)
+            k.lib.t4k_xchg_destroy()
             out.update(extras(VM, local, ms_step, args, torch))
         # ---- GEMM 1024^3 fp32 (word `matmul`), HIP events on the launch stream
         g = torch.Generator(device="cuda"); g.manual_seed(1234)
@@ -425,6 +480,8 @@ def main():
                                    "gemm_note": "reference's blocked host GEMM (tensor.cu:97-123 restated): one thread on the full 1024^3 product, then %d workers on %d-row slabs for ~2 s" % (len(gr), rows)}
         print(json.dumps(out), flush=True)
     if dp:
+        if xchg:
+            torch.cuda.synchronize(); dist.barrier(); k.lib.t4k_xchg_destroy()
         if native:
             k.lib.t4k_comm_destroy()
         dist.barrier(); dist.destroy_process_group()

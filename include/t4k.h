@@ -112,6 +112,23 @@ int t4k_comm_destroy(void);
  * switches it on for training passes only (an evaluation pass that only some ranks run would hang in the collective). */
 int t4k_comm_sync_batchnorm(int on);
 
+/* ONE-SHOT gradient exchange over peer-mapped windows (csrc/xchg.hip; the reference has no multi-GPU path - the seam is Model::sgd / adam,
+ * src/nn/gradient.cu:63-142).  Every rank allocates a receive window (t4k_xchg_create -> a 64-byte IPC handle), the launcher hands all
+ * handles to all ranks, every rank maps its peers (t4k_xchg_connect).  From then on t4k_opt_step_dp() sums the gradient slab over all ranks
+ * INSIDE the optimizer launch: each rank writes {epoch, value} words straight into every peer's window (xGMI is point to point: all links
+ * at once) and adds the `world` copies of each element in rank order - fold + all-reduce + update in one launch, no collective kernel.
+ * t4k_comm_world / t4k_comm_rank report the exchange's job when no RCCL communicator exists, and t4k_allreduce_sum then sums over the same
+ * windows, so the host's scalar reductions need no second transport.  Dropout masks are keyed by the sample's place in the whole batch
+ * from t4k_xchg_connect on (as after t4k_comm_init).  Waits for a peer are bounded: a missing rank gives T4K_ERR_HIP at the next t4k_sync. */
+int t4k_xchg_create(long slab_floats, int rank, int world, void *handle64);
+int t4k_xchg_connect(const void *handles /* world x 64 bytes, rank order */);
+int t4k_xchg_allreduce(float *buf, long n, t4k_stream_t s);   /* in-place SUM over the ranks through the windows (any n; rank order: deterministic) */
+int t4k_xchg_self(int on);                         /* measurement: a one-rank job takes the exchanging optimizer launch too (bench.py dp_overhead_us) */
+int t4k_xchg_active(void);                         /* 1 when t4k_opt_step_dp will exchange (connected and world > 1, or self mode) */
+int t4k_xchg_world(void);                          /* 0 = not connected */
+int t4k_xchg_rank(void);
+int t4k_xchg_destroy(void);
+
 /* hipGraph capture of a launch sequence (replaces ~40 launch+sync pairs per training
  * step of the reference).  begin..end captures every t4k_* kernel call
  * issued on `s`; launch replays it. */
@@ -436,6 +453,10 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n
  * all-reduces the slab before the optimizer sees what the undeferred path leaves.  tab_host: the caller's host copy of tab_dev. */
 int t4k_opt_step(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
                  float lr, float b1, float b2, float wd, t4k_stream_t s);
+/* the data-parallel form: with the one-shot exchange connected (t4k_xchg_connect, world > 1) every gradient element is summed over all
+ * ranks inside the same launch (slab / slab_n: the model's gradient slab, holding every DG of the table); otherwise t4k_opt_step. */
+int t4k_opt_step_dp(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
+                    float lr, float b1, float b2, float wd, float *slab, long slab_n, t4k_stream_t s);
 
 #ifdef __cplusplus
 }

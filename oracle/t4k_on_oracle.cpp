@@ -269,6 +269,12 @@ int t4k_opt_step(int kind, const t4k_param_rec *tab, const t4k_param_rec *, int 
     return t4k_opt_multi(kind, tab, nt, 0, lr, b1, b2, wd, st);
 }
 
+int t4k_opt_step_dp(int kind, const t4k_param_rec *tab, const t4k_param_rec *, int nt, int, float lr, float b1, float b2, float wd, float *, long, t4k_stream_t st) {
+    return t4k_opt_multi(kind, tab, nt, 0, lr, b1, b2, wd, st);
+}
+int t4k_xchg_world(void) { return 0; }
+int t4k_xchg_active(void) { return 0; }
+
 // the sample-resident conv stack is a launch-count optimisation of the product: the oracle VM always runs the separate layers
 int t4k_conv_stack_ok(const t4k_conv_stage *, int, int) { return 0; }
 int t4k_conv_stack_release(const float *) { return T4K_OK; }

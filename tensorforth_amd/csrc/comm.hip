@@ -66,10 +66,16 @@ int t4k_comm_init(const void *id128, int rank, int world) {
     st().shard_rank = rank; st().shard_world = world;     // dropout masks are keyed by the sample's place in the whole batch from now on
     return T4K_OK;
 }
-int t4k_comm_world(void) { return R.comm ? R.world : 0; }
-int t4k_comm_rank(void)  { return R.comm ? R.rank : 0; }
+// world / rank of the data-parallel job: the RCCL communicator's, or the one-shot peer exchange's (xchg.hip) when only that is connected
+int t4k_comm_world(void) { return R.comm ? R.world : t4k_xchg_world(); }
+int t4k_comm_rank(void)  { return R.comm ? R.rank : t4k_xchg_rank(); }
 int t4k_allreduce_sum(float *buf, long n, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
+    if (!R.comm && xchg().connected) {                          // no RCCL: the same sum over the peer windows (rank order, deterministic)
+        if (n <= 0) return T4K_OK;
+        if (!buf) return fail(T4K_ERR_ARG, "t4k_allreduce_sum: null");
+        return xchg().world > 1 ? xchg_allreduce(buf, n, S(s)) : T4K_OK;
+    }
     if (!R.comm) return fail(T4K_ERR_UNSUPPORTED, "t4k_allreduce_sum: no communicator (t4k_comm_init)");
     if (n <= 0) return T4K_OK;
     if (!buf) return fail(T4K_ERR_ARG, "t4k_allreduce_sum: null");

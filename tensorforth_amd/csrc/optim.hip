@@ -117,13 +117,23 @@ __device__ __forceinline__ void opt1(int kind, const t4k_param_rec &r, long j, f
     }
     r.G[j] = g; r.DG[j] = 0.f;
 }
+// XCHG: the gradient element is first summed over all ranks through the one-shot peer exchange (xchg.hip) - pushed into every peer's
+// window, then added up in rank order out of this rank's window - so fold + all-reduce + update are ONE launch.  `slab` = the model's
+// gradient slab: an element's place in the windows is its offset in the slab.
+T4K_SPIN_DECL
+__global__ void k_opt_set_err(int *p) { g_spin_err_dev = p; }
+template <bool XCHG>
 __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec *__restrict__ tab, int nt, float lr, float b1, float b2, float wd,
-                                                   const CsFoldArgs fa, const FoldRecs fr, int nfold, unsigned long long skip) {
+                                                   const CsFoldArgs fa, const FoldRecs fr, int nfold, unsigned long long skip, const float *slab, const XchgDev xd) {
     __shared__ CsFoldSm sm;
     const bool mom = !(fabsf(b1) < DU_EPS);
     if ((int)blockIdx.x < nfold) {
         float v; int q, k;
-        if (cs_fold16(fa, blockIdx.x, sm, v, q, k)) opt1(kind, fr.r[q], k, fa.seg[q].dst[k] + v, lr, b1, b2, wd, mom);
+        if (cs_fold16(fa, blockIdx.x, sm, v, q, k)) {
+            float dg = fa.seg[q].dst[k] + v;
+            if (XCHG) { const long z = (long)(fa.seg[q].dst - slab) + k; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev); }
+            opt1(kind, fr.r[q], k, dg, lr, b1, b2, wd, mom);
+        }
         return;
     }
     const int b = (int)blockIdx.x - nfold;
@@ -132,7 +142,11 @@ __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec
     if ((skip >> i) & 1ull) return;
     const t4k_param_rec r = tab[i];
     const long j = ((long)b - r.pad) * 1024 + threadIdx.x;
-    if (j < r.n) opt1(kind, r, j, r.DG[j], lr, b1, b2, wd, mom);
+    if (j < r.n) {
+        float dg = r.DG[j];
+        if (XCHG) { const long z = (long)(r.DG - slab) + j; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev); }
+        opt1(kind, r, j, dg, lr, b1, b2, wd, mom);
+    }
 }
 
 // d[i] = scale * (bias + u_i): element i <- Philox(counter = (off+i)/4)[i%4].
@@ -228,26 +242,56 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n
 
 // the optimizer step of a model: t4k_opt_chunked, plus whatever the backward deferred to it (t4k_conv_stack_bwd with train | 4: the
 // dF | dB partial fold) inside the same launch.  tab_host = the host's copy of the table tab_dev holds.
+// _dp: with the one-shot peer exchange connected (t4k_xchg_connect) the gradients are SUMMED OVER ALL RANKS on the way - `slab` / `slab_n` =
+// the model's gradient slab, which must hold every DG of the table.  Without an exchange it is t4k_opt_step.
+static int opt_step_impl(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
+                         float lr, float b1, float b2, float wd, const float *slab, long slab_n, t4k_stream_t s) {
+    State &g = st();
+    const bool dp = slab && xchg().connected && (xchg().world > 1 || xchg().self);
+    bool slab_ok = dp && tab_dev && tab_host && n_tensors > 0 && n_tensors <= 64 && n_chunks > 0 && slab_n <= xchg().n && !g.capturing && kind >= 0 && kind <= 2;
+    for (int i = 0; slab_ok && i < n_tensors; i++) if (tab_host[i].DG < slab || tab_host[i].DG + tab_host[i].n > slab + slab_n) slab_ok = false;
+    if (dp && !slab_ok) {                                     // cannot ride in the update: sum the slab first (same transport, its own launches), then the plain step
+        if (g.pending) flush_pending();
+        const int rc = xchg_allreduce(const_cast<float *>(slab), slab_n, S(s)); if (rc) return rc;
+        return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s);
+    }
+    if (!(g.pending & 1) && !dp) return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s);
+    const PendingFold &pf = pending_fold();
+    FoldRecs fr; memset((void *)&fr, 0, sizeof(fr));
+    CsFoldArgs fa; memset((void *)&fa, 0, sizeof(fa));
+    unsigned long long skip = 0;
+    int nfold = 0;
+    if (g.pending & 1) {
+        static int on = -1; if (on < 0) { const char *e = getenv("T4K_OPT_FOLD"); on = e ? atoi(e) : 1; }
+        bool ok = on && tab_dev && tab_host && kind >= 0 && kind <= 2 && n_tensors > 0 && n_tensors <= 64 && n_chunks > 0 && pf.hs == S(s) && !g.capturing;
+        for (int q = 0; ok && q < pf.fa.nseg; q++) {              // every pending segment must be a whole gradient tensor of this table
+            int hit = -1;
+            for (int i = 0; i < n_tensors; i++) if (tab_host[i].DG == pf.fa.seg[q].dst && tab_host[i].n == (long)pf.fa.seg[q].n) { hit = i; break; }
+            if (hit < 0) ok = false; else { fr.r[q] = tab_host[hit]; skip |= 1ull << hit; }
+        }
+        if (!ok) { flush_pending(); if (!dp) return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s); skip = 0; }
+        else { g.pending &= ~1; fa = pf.fa; nfold = pf.fa.total / 16; }
+    }
+    static bool err_set = false;
+    if (!err_set && g.spin_err) { T4K_LAUNCH(k_opt_set_err, dim3(1), dim3(1), 0, S(s), g.spin_err); err_set = true; }
+    if (dp) {
+        const XchgDev xd = xchg_begin(false);
+        T4K_LAUNCH(k_opt_step<true>, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, fa, fr, nfold, skip, slab, xd);
+    } else {
+        XchgDev xd; memset((void *)&xd, 0, sizeof(xd));
+        T4K_LAUNCH(k_opt_step<false>, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, fa, fr, nfold, skip, slab, xd);
+    }
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
 int t4k_opt_step(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
                  float lr, float b1, float b2, float wd, t4k_stream_t s) {
     T4K_REQUIRE_INIT_NOFLUSH();
-    State &g = st();
-    if (!(g.pending & 1)) return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s);
-    const PendingFold &pf = pending_fold();
-    FoldRecs fr; memset((void *)&fr, 0, sizeof(fr));
-    unsigned long long skip = 0;
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_OPT_FOLD"); on = e ? atoi(e) : 1; }
-    bool ok = on && tab_dev && tab_host && kind >= 0 && kind <= 2 && n_tensors > 0 && n_tensors <= 64 && n_chunks > 0 && pf.hs == S(s) && !g.capturing;
-    for (int q = 0; ok && q < pf.fa.nseg; q++) {              // every pending segment must be a whole gradient tensor of this table
-        int hit = -1;
-        for (int i = 0; i < n_tensors; i++) if (tab_host[i].DG == pf.fa.seg[q].dst && tab_host[i].n == (long)pf.fa.seg[q].n) { hit = i; break; }
-        if (hit < 0) ok = false; else { fr.r[q] = tab_host[hit]; skip |= 1ull << hit; }
-    }
-    if (!ok) { flush_pending(); return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s); }
-    g.pending &= ~1;
-    const int nfold = pf.fa.total / 16;
-    T4K_LAUNCH(k_opt_step, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, pf.fa, fr, nfold, skip);
-    T4K_LAUNCH_CHECK(); return T4K_OK;
+    return opt_step_impl(kind, tab_dev, tab_host, n_tensors, n_chunks, lr, b1, b2, wd, nullptr, 0, s);
+}
+int t4k_opt_step_dp(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
+                    float lr, float b1, float b2, float wd, float *slab, long slab_n, t4k_stream_t s) {
+    T4K_REQUIRE_INIT_NOFLUSH();
+    return opt_step_impl(kind, tab_dev, tab_host, n_tensors, n_chunks, lr, b1, b2, wd, slab, slab_n, s);
 }
 
 int t4k_rand_init(uint64_t seed) { T4K_REQUIRE_INIT(); State &g = st(); g.seed = seed; g.rng_ctr = 0; g.d_rng_ctr = ~0ull; return T4K_OK; }

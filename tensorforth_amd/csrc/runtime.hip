@@ -35,10 +35,12 @@ int spin_check() {
     *(volatile int *)g.spin_err = 0;
     // what waited, and the switch that takes that path out (t4k.h / DESIGN.md section 9)
     static const char *what[] = { "unknown wait", "dual GEMM writer gate", "dual-GEMM epoch slots", "pair-mode GEMM flag", "head backward dW gate",
-                                  "head backward staging gate", "column-sliced head backward target store", "conv-stack head band exchange", "fused head backward target store" };
+                                  "head backward staging gate", "column-sliced head backward target store", "conv-stack head band exchange", "fused head backward target store",
+                                  "one-shot gradient exchange: a peer's element never arrived" };
     static const char *off[]  = { "T4K_GEMM_DUAL=0 T4K_GEMM_DUAL32=0 T4K_LINSMALL_GATE=0 T4_STACK_HEAD=0 T4_HEAD_BWD=0", "T4K_GEMM_DUAL=0", "T4K_GEMM_DUAL32=0", "T4K_GEMM_PLAIN_PAIR=0",
-                                  "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_COLS=0", "T4_STACK_HEAD=0 (or T4K_STACK_HEAD=0)", "T4_HEAD_BWD=0 (or T4K_HEAD_BWD=0)" };
-    const int k = (code > 0 && code < 9) ? code : 0;
+                                  "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_COLS=0", "T4_STACK_HEAD=0 (or T4K_STACK_HEAD=0)", "T4_HEAD_BWD=0 (or T4K_HEAD_BWD=0)",
+                                  "T4_DP_XCHG=0 (the slab then goes through RCCL); check that every rank reached the optimizer" };
+    const int k = (code > 0 && code < 10) ? code : 0;
     return fail(T4K_ERR_HIP, "an inter-workgroup wait timed out (code %d: %s): the launch's workgroups were not co-resident - results of that launch are invalid; "
                              "on a shared or partitioned device set %s", code, what[k], off[k]);
 }
@@ -71,8 +73,10 @@ int t4k_init(int device) {
         T4K_HIP(hipMalloc(&g.ws, g.ws_bytes));
         T4K_HIP(hipMemsetAsync(g.ws, 0, g.ws_bytes, g.stream));
     }
-    if (!g.d_zero) { T4K_HIP(hipMalloc((void **)&g.d_zero, 4096)); T4K_HIP(hipMemset(g.d_zero, 0, 4096)); }
-    if (!g.d_sync) { T4K_HIP(hipMalloc((void **)&g.d_sync, 32768 * sizeof(int))); T4K_HIP(hipMemset(g.d_sync, 0, 32768 * sizeof(int))); }
+    // (zeroed on the library stream: a null-stream hipMemset is not ordered with a non-blocking stream's kernels)
+    if (!g.d_zero) { T4K_HIP(hipMalloc((void **)&g.d_zero, 4096)); T4K_HIP(hipMemsetAsync(g.d_zero, 0, 4096, g.stream)); }
+    if (!g.d_sync) { T4K_HIP(hipMalloc((void **)&g.d_sync, 32768 * sizeof(int))); T4K_HIP(hipMemsetAsync(g.d_sync, 0, 32768 * sizeof(int), g.stream)); }
+    T4K_HIP(hipStreamSynchronize(g.stream));            // ... and complete before any stream (a caller's own, t4k_set_default_stream) can launch
     if (!g.spin_err) {                                  // error word of the bounded inter-workgroup waits: pinned host memory the kernels can write
         T4K_HIP(hipHostMalloc((void **)&g.spin_err, 64, hipHostMallocMapped)); *g.spin_err = 0;
         gemm_set_spin_err(g.spin_err); linsmall_set_spin_err(g.spin_err);
@@ -177,7 +181,7 @@ int t4k_event_destroy(t4k_event_t e) { T4K_REQUIRE_INIT(); if (e) T4K_HIP(hipEve
 int t4k_graph_begin(t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     State &g = st();
-    if (!g.d_rng) { T4K_HIP(hipMalloc((void **)&g.d_rng, 4 * sizeof(uint64_t))); T4K_HIP(hipMemset(g.d_rng, 0, 4 * sizeof(uint64_t))); g.d_rng_ctr = ~0ull; }
+    if (!g.d_rng) { T4K_HIP(hipMalloc((void **)&g.d_rng, 4 * sizeof(uint64_t))); T4K_HIP(hipMemsetAsync(g.d_rng, 0, 4 * sizeof(uint64_t), S(s))); g.d_rng_ctr = ~0ull; }
     T4K_HIP(hipStreamBeginCapture(S(s), hipStreamCaptureModeThreadLocal));
     g.capturing = true; g.cap_adv = 0;                  // draws recorded from here on read / advance the device copy of the stream
     return T4K_OK;

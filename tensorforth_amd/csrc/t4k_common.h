@@ -292,6 +292,46 @@ __device__ __forceinline__ bool cs_fold16(const CsFoldArgs &a, int blk, CsFoldSm
     v = ((sm.b[0][el] + sm.b[1][el]) + sm.b[2][el]) + sm.b[3][el];   // ... and the four are added in order
     return g == 0 && off >= 0;
 }
+// ---- one-shot peer exchange (xchg.hip): every rank owns a window of 64-bit words {epoch, value}; a rank PUSHES its element into slot
+// `rank` of every peer's window and SUMS the slots of its own window in rank order once their tags carry the call's epoch
+constexpr int T4K_XCHG_MAX = 8;
+struct Xchg { bool connected = false, self = false; int rank = 0, world = 0; long n = 0; unsigned long long *win[T4K_XCHG_MAX] = {}; unsigned epoch_slab = 0, epoch_gen = 0; };
+Xchg &xchg();
+struct XchgDev { unsigned long long *win[T4K_XCHG_MAX]; long per; unsigned long long patience; unsigned epoch; int rank, world; };   // windows already offset to the call's region and parity; patience in 100 MHz ticks
+XchgDev xchg_begin(bool generic);                    // host: the device view of the next call (advances the region's epoch)
+int xchg_allreduce(float *buf, long n, hipStream_t hs);
+__device__ __forceinline__ void xchg_push(const XchgDev &x, long j, float v) {
+    const unsigned long long w = ((unsigned long long)x.epoch << 32) | (unsigned long long)__float_as_uint(v);
+#pragma unroll
+    for (int r = 0; r < T4K_XCHG_MAX; r++)
+        if (r < x.world && r != x.rank) __hip_atomic_store(x.win[r] + (long)x.rank * x.per + j, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float xchg_sum(const XchgDev &x, long j, float mine, int *err) {
+    unsigned long long w[T4K_XCHG_MAX];
+    const unsigned long long *my = x.win[x.rank] + j;
+#pragma unroll
+    for (int r = 0; r < T4K_XCHG_MAX; r++)            // every slot's load in flight before the first tag is looked at
+        w[r] = (r < x.world && r != x.rank) ? __hip_atomic_load(my + (long)r * x.per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < T4K_XCHG_MAX; r++) {          // rank order on every rank: the same numbers added in the same order
+        if (r >= x.world) break;
+        if (r == x.rank) { s += mine; continue; }
+        // a peer may be late by whole seconds (its first step loads / compiles kernels): the bound is wall time (s_memrealtime, 100 MHz), not polls
+        unsigned long long t0 = 0;
+        for (int it = 0; (unsigned)(w[r] >> 32) != x.epoch; it++) {
+            if ((it & 63) == 63) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (!t0) t0 = now;
+                else if (now - t0 > x.patience) { if (err) __hip_atomic_store(err, 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+            __builtin_amdgcn_s_sleep(2);
+            w[r] = __hip_atomic_load(my + (long)r * x.per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        s += __uint_as_float((unsigned)w[r]);
+    }
+    return s;
+}
 struct PendingFold { CsFoldArgs fa; hipStream_t hs; };
 PendingFold &pending_fold();             // conv_stack.hip
 

@@ -582,10 +582,18 @@ void Model::dp_begin_backward() {
     }
     dp_done_lo_ = dp_pend_lo_ = numel;
 }
+// T4_DP_XCHG=0: the slab is all-reduced by a collective of its own (RCCL, or the exchange's generic kernel) in front of the optimizer
+static const bool use_xchg = getenv("T4_DP_XCHG") ? atoi(getenv("T4_DP_XCHG")) != 0 : true;
 void Model::dp_finish() {                                // before the update: reduce what is left, join the communication stream
-    if (!gslab || t4k_comm_world() <= 0) return;
+    dp_in_opt_ = false;
+    if (!gslab || (t4k_comm_world() <= 0 && !t4k_xchg_active())) return;
     const long numel = (long)gslab->numel;
     const long rest = (dp_done_lo_ >= 0 && dp_done_lo_ <= numel) ? dp_done_lo_ : numel;
+    // one-shot peer exchange connected and nothing reduced early: the optimizer launch sums the slab over the ranks itself (t4k_opt_step_dp)
+    if (use_xchg && t4k_xchg_active() && rest == numel && !dp_busy_ && !dp_mixed_ && !use_graphs) {
+        dp_in_opt_ = true; dp_done_lo_ = dp_pend_lo_ = -1;
+        return;
+    }
     if (rest > 0) chk(t4k_allreduce_sum(gslab->data, rest, stream()), "allreduce");
     static const bool tr = getenv("T4_DP_TRACE") != nullptr;
     if (tr) fprintf(stderr, "dp: final all-reduce of slab [0, %ld) of %ld\n", rest, numel);
@@ -851,7 +859,9 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     dp_finish();
     if (!replay(g_opt_, tab_dev, (int)op, p)) {
         const bool cap = capturing_;
-        chk(t4k_opt_step(kind, (const t4k_param_rec *)tab_dev, tab_host_.data(), tab_n, tab_chunks, lr, b1, b2, wd, stream()), nm);   // one workgroup per 1024 parameters (+ a conv stack's deferred partial fold)
+        if (dp_in_opt_) chk(t4k_opt_step_dp(kind, (const t4k_param_rec *)tab_dev, tab_host_.data(), tab_n, tab_chunks, lr, b1, b2, wd, gslab->data, (long)gslab->numel, stream()), nm);
+        else chk(t4k_opt_step(kind, (const t4k_param_rec *)tab_dev, tab_host_.data(), tab_n, tab_chunks, lr, b1, b2, wd, stream()), nm);   // one workgroup per 1024 parameters (+ a conv stack's deferred partial fold)
+        dp_in_opt_ = false;
         end_capture(g_opt_, cap);
     }
     NLOG("} Model::%s\n", nm);

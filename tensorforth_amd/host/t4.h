@@ -295,6 +295,7 @@ private:
     static bool use_stack;                     // T4_STACK=0: no sample-resident conv stacks (csrc/conv_stack.hip)
     static bool use_lazy_dx0;                  // T4_LAZY_DX0=0: a conv stack's backward always computes the first layer's dX (default: on demand, materialize_dx0)
     bool dx0_stale_ = false;
+    bool dp_in_opt_ = false;                   // this optimizer call sums the gradient slab over the ranks itself (one-shot peer exchange, t4k_opt_step_dp)
     void clear_dx0_marks();
     static bool use_opt_fold;                  // T4_OPT_FOLD=0: the conv stack's dF | dB partial fold as a launch of its own (default: inside the optimizer launch, t4k_opt_step)
     // sample-resident conv stack starting at layer i: [conv + run] x ns (stages filled for the C-ABI); ops = layers it covers
