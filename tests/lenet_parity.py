@@ -2,7 +2,7 @@
 sums, verification of max-pool arg-max ties, and one training step of a product VM against the oracle VM."""
 import numpy as np
 
-from vm_util import rel_err
+from vm_util import check_tensor, rel_err
 
 NET = "0.5 10 conv2d 2 maxpool relu 0.5 20 conv2d 0.5 dropout 2 maxpool relu flatten 100 linear 0.5 dropout 10 linear softmax"
 PARAMS = [("w0", "0 nn.w"), ("b0", "0 nn.b"), ("w3", "3 nn.w"), ("b3", "3 nn.b"), ("w8", "8 nn.w"), ("b8", "8 nn.b"), ("w10", "10 nn.w"), ("b10", "10 nn.b")]
@@ -66,9 +66,11 @@ def _check_rows(name, got, want, skip, tol=TOL):
     _check(name, got[keep], want[keep], tol)
 
 
-def _check(name, got, want, tol=TOL):
-    e = rel_err(got, want)
-    assert e <= tol, "%s: max|d|/max|ref| = %.3g > %.1g" % (name, e, tol)
+FLOOR = 1e-3                                                  # element-aware bar: |d| <= tol (|ref| + FLOOR max|ref|) on >= 99.99 % of the elements (vm_util.check_tensor)
+
+
+def _check(name, got, want, tol=TOL, floor=None):
+    check_tensor(name, got, want, tol, floor=max(floor or 0.0, FLOOR))   # max|d| / max|ref| <= tol AND the element-aware bar
 
 
 
@@ -99,10 +101,10 @@ def step_vs_oracle(g, o, img, step, lr=0.01):
     exact_g["dw0"], exact_g["db0"] = conv_df64(img, gdo0); exact_g["dw3"], exact_g["db3"] = conv_df64(x3g, gdo3)
     for n_, e in GRADS:
         if n_ in exact:
-            _check("step %d %s: oracle vs float64 on the oracle's operands" % (step, n_), go[n_], exact[n_].reshape(go[n_].shape))
+            _check("step %d %s: oracle vs float64 on the oracle's operands" % (step, n_), go[n_], exact[n_].reshape(go[n_].shape), floor=1e-2)   # (the oracle sums ~1e5 terms sequentially in fp32)
             _check("step %d %s: product vs float64 on the product's operands" % (step, n_), gw[n_], exact_g[n_].reshape(gw[n_].shape))
             if not flipped:
-                _check("step %d %s: product vs oracle (no arg-max tie in this step)" % (step, n_), gw[n_], go[n_])
+                _check("step %d %s: product vs oracle (no arg-max tie in this step)" % (step, n_), gw[n_], go[n_], floor=1e-2)
         else:
             _check("step %d %s" % (step, n_), gw[n_], go[n_])
     _check_rows("step %d dx" % step, _get(g, "0 n@"), _get(o, "0 n@"), flipped)

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from vm_util import SCRIPTS, TEN4, TEN4_ORACLE, OracleVM, compare, numbers_after, rel_err, run_vm, tokens
+from vm_util import SCRIPTS, TEN4, TEN4_ORACLE, OracleVM, check_tensor, compare, numbers_after, rel_err, run_vm, tokens
 
 pytestmark = pytest.mark.gpu
 
@@ -123,8 +123,20 @@ def _adam_check(name, got, want, lr, g_first=None, steps=1):
     assert d.max() <= 2.0 * steps * step_max, "%s: |d| = %.3g exceeds what %d Adam steps can move" % (name, d.max(), steps)
 
 
+# Element-aware bar for the GAN's gradient tensors (vm_util.check_tensor; the tensor-norm bar of 1e-4 holds for EVERY element regardless):
+# D's gradients accumulate a REAL and a FAKE backprop whose contributions largely cancel, G's have passed backwards through six GEMMs - an
+# element below a hundredth of its tensor's largest has no 1e-4 accuracy of its own on either side.  Measured over three seeds, floor 1e-3:
+# 15 of 131 072 (D 3 dW), 3 of 256 (D 6 dW), 45 of 401 408 (G 4 dW) elements beyond the bar; floor 1e-2: 420 of 200 704 (0.2 %) of the frozen
+# discriminator's dX on the worst seed, a handful elsewhere.  The LeNet configs (#3, #5) hold 99.99 % (tests/lenet_parity.py); here the bar is 99 %.
+GAN_ELEM = dict(floor=1e-2, elem_min=0.99, min_outliers=2)
+
+
 def _gan_two_rounds(seed):
-    """Returns None when the run is parity-green, or a description of the activation-kink flips that make it ill-conditioned."""
+    """Two `train_d train_g` rounds of the product VM against the oracle VM, phase by phase, on full tensors.  Returns the list of
+    activation-kink flips met on the way (empty: none).  A pre-activation within rounding of the leakyrelu kink makes the fp32 summation
+    order decide the branch - in the reference as much as here; such a flip is VERIFIED to be at the kink (|x| <= 1e-5 of the tensor's
+    scale), the gradients of that phase then describe two equally valid trajectories, so the product VM takes over the oracle's gradient
+    tensors (ten4_store) and the run CONTINUES: every seed goes through both rounds."""
     g, o = _pair(seed)
     try:
         src = _body("cfg4_gan256", "D 2 rounds")
@@ -137,9 +149,8 @@ def _gan_two_rounds(seed):
         og = {}                                                  # the oracle's gradients in front of each optimizer call
 
         def kinks(tag):
-            """leakyrelu derivative masks (1 / 0.2) must agree; where they do not, the pre-activation must sit AT the kink (|x| below
-            1e-5 of the tensor's scale) - then fp32 summation order decides the branch, in the reference as much as here, and everything
-            downstream of that sample is a different (equally valid) trajectory"""
+            """leakyrelu derivative masks (1 / 0.2) must agree; where they do not, the pre-activation must sit AT the kink"""
+            n = 0
             for m, acts in (("D", (1, 4)), ("G", (1, 3))):
                 for L in acts:
                     a, b = _fetch(g, m, "%d nn.ex" % L), _fetch(o, m, "%d nn.ex" % L)
@@ -148,30 +159,42 @@ def _gan_two_rounds(seed):
                         bad = np.argwhere(a != b)
                         for i_ in bad:
                             assert abs(x[tuple(i_)]) <= 1e-5 * np.abs(x).max(), "%s %s layer %d: masks differ AWAY from the kink at %s" % (tag, m, L, i_)
-                        flips.append("%s %s layer %d: %d element(s) at the leakyrelu kink" % (tag, m, L, len(bad)))
+                        assert len(bad) <= 4, "%s %s layer %d: %d mask elements differ" % (tag, m, L, len(bad))
+                        flips.append("%s %s layer %d: %d element(s) at the leakyrelu kink" % (tag, m, L, len(bad))); n += len(bad)
+            return n
+
+        def adopt(model, exprs):
+            """the product VM continues from the oracle's tensors"""
+            for e in exprs:
+                g.store(_fetch(o, model, e), "%s %s" % (model, e)); g.eval("drop drop")
+        DG = ("0 nn.dw", "0 nn.db", "3 nn.dw", "3 nn.db", "6 nn.dw", "6 nn.db")
+        GG = ("4 nn.dw", "4 nn.db", "2 nn.dw", "2 nn.db", "0 nn.dw", "0 nn.db")
         for rnd in (1, 2):
-            # one round by hand: forward values and raw gradients are well conditioned -> 1e-4; dropout masks bit-exact
+            # one round by hand: forward values and raw gradients are well conditioned -> 1e-4 (tensor norm AND element-aware); dropout masks bit-exact
             for vm in (g, o):
                 vm.eval("D 1 trainable real forward REAL backprop F forward FAKE backprop\n")
-            kinks("round %d train_d" % rnd)
-            if flips:
-                return "; ".join(flips)
-            for e in ("0 nn.dw", "0 nn.db", "3 nn.dw", "3 nn.db", "6 nn.dw", "6 nn.db", "2 nn.ex", "5 nn.ex"):
-                a, b = _fetch(g, "D", e), _fetch(o, "D", e)
-                if e.endswith("nn.ex"):
-                    assert np.array_equal(a, b), "D " + e
-                else:
-                    err = rel_err(a, b); assert err <= TOL, "round %d D %s (two accumulated backprops): %.3g" % (rnd, e, err)
-                    og[("D", e.replace("nn.d", "nn."))] = b
+            flipped = kinks("round %d train_d" % rnd)
+            for e in ("2 nn.ex", "5 nn.ex"):
+                assert np.array_equal(_fetch(g, "D", e), _fetch(o, "D", e)), "D " + e
+            for e in DG:
+                b = _fetch(o, "D", e); og[("D", e.replace("nn.d", "nn."))] = b
+                if not flipped:
+                    check_tensor("round %d D %s (two accumulated backprops)" % (rnd, e), _fetch(g, "D", e), b, TOL, **GAN_ELEM)
+            if flipped:
+                adopt("D", DG)
             for vm in (g, o):
                 vm.eval("0.0001 0.5 nn.adam 0 trainable F forward REAL backprop 0 n@ G swap backprop\n")
-            kinks("round %d train_g" % rnd)
-            if flips:
-                return "; ".join(flips)
-            err = rel_err(_fetch(g, "D", "0 n@"), _fetch(o, "D", "0 n@")); assert err <= TOL, "round %d dX of the frozen D: %.3g" % (rnd, err)
-            for e in ("4 nn.dw", "4 nn.db", "2 nn.dw", "2 nn.db", "0 nn.dw", "0 nn.db"):
+            flipped2 = kinks("round %d train_g" % rnd)
+            if not flipped2:
+                # (floor 1e-2 from here on: these gradients have passed through the discriminator's three layers backwards and - for G's - the
+                # generator's as well; an element below a hundredth of the tensor's largest carries the rounding of a six-GEMM chain on both sides)
+                check_tensor("round %d dX of the frozen D" % rnd, _fetch(g, "D", "0 n@"), _fetch(o, "D", "0 n@"), TOL, **GAN_ELEM)
+            for e in GG:
                 b = _fetch(o, "G", e); og[("G", e.replace("nn.d", "nn."))] = b
-                err = rel_err(_fetch(g, "G", e), b); assert err <= TOL, "round %d G %s: %.3g" % (rnd, e, err)
+                if not flipped2:
+                    check_tensor("round %d G %s" % (rnd, e), _fetch(g, "G", e), b, TOL, **GAN_ELEM)
+            if flipped2:
+                adopt("G", GG)
             for vm in (g, o):
                 vm.eval("0.0004 0.5 nn.adam drop\n")
             assert g.rand_tell() == o.rand_tell()
@@ -182,25 +205,24 @@ def _gan_two_rounds(seed):
                 # Round 2 starts from ONE set of parameters (the oracle's, written into the product VM at full precision): the +-15.8 lr
                 # steps Adam takes on rounding-level gradient elements would otherwise make round 2 a comparison of two trajectories
                 for m, layers in (("D", (0, 3, 6)), ("G", (0, 2, 4))):
-                    for L in layers:
-                        for kind in ("nn.w", "nn.b"):
-                            g.store(_fetch(o, m, "%d %s" % (L, kind)), "%s %d %s" % (m, L, kind)); g.eval("drop drop")
+                    adopt(m, ["%d %s" % (L, kind) for L in layers for kind in ("nn.w", "nn.b")])
         for vm in (g, o):
             vm.eval("G Z forward\n")
         err = rel_err(_fetch(g, "G", "-1 n@"), _fetch(o, "G", "-1 n@"))
         assert err <= 2 * TOL, "generator output after two rounds (tanh of a 3-layer product of post-Adam weights): %.3g" % err
-        return None
+        return flips
     finally:
         g.close(); o.close()
 
 
 def test_config4_gan256_full_tensors_vs_oracle_vm():
     """config #4: the t4_40b GAN nets at N = 256, two `train_d train_g` rounds (BCE, Adam beta1 = 0.5, dropout in D), every gradient
-    tensor at 1e-4 relative, post-Adam weights by _adam_check.  A run in which a pre-activation lands within rounding of the leakyrelu
-    kink (seed 31 does, in round 2: |x| = 6e-7, one element of 131 072) is ill-conditioned from that sample on; such a run is
-    checked up to the flip (the flip itself must be AT the kink) and the next seed is taken - two of three seeds must go all the way."""
-    notes = [_gan_two_rounds(seed) for seed in (31, 47, 2024)]
-    assert sum(n is None for n in notes) >= 2, notes
+    tensor at 1e-4 relative (tensor norm and element-aware), post-Adam weights by _adam_check - ALL THREE seeds go through both rounds.
+    Seed 31 meets a pre-activation within rounding of the leakyrelu kink in round 2 (|x| = 6e-7, one element of 131 072): the flip is
+    verified to be AT the kink, the product VM takes over the oracle's gradients for that phase, and the run continues."""
+    notes = {seed: _gan_two_rounds(seed) for seed in (31, 47, 2024)}
+    assert sum(len(v) for v in notes.values()) <= 3, notes           # kinks are rare events: a handful over three seeds at most
+    assert sum(1 for v in notes.values() if not v) >= 2, notes       # ... and most seeds never meet one
 
 
 def test_config4_gan256_printed_text_vs_live_oracle_vm():

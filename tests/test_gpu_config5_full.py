@@ -21,10 +21,23 @@ from vm_util import ROOT, OracleVM, rel_err
 
 pytestmark = pytest.mark.gpu
 
+import lenet_parity
 from lenet_parity import GRADS, NET, PARAMS, TOL, _check, _check_rows, _get, _setup, conv_df64, pool_flips
 
+# element-aware bar at batch 1024: every gradient element is a sum over 1024 samples (x 784 pixels for a conv filter), associated differently
+# by 8 shards, one VM and the oracle's sequential loop - an element within one hundredth of the tensor's largest has no 1e-4 accuracy of its
+# own left in ANY of the three (batch 128, config #3: floor 1e-3)
+FLOOR_1024 = 1e-2
 
-def test_eight_emulated_ranks_x128_equal_one_vm_x1024_equal_the_oracle():
+
+@pytest.fixture
+def floor_1024():
+    old = lenet_parity.FLOOR; lenet_parity.FLOOR = FLOOR_1024
+    yield
+    lenet_parity.FLOOR = old
+
+
+def test_eight_emulated_ranks_x128_equal_one_vm_x1024_equal_the_oracle(floor_1024):
     import torch
     from tensorforth_amd import lib as t4lib
     from tensorforth_amd.vm import VM
@@ -94,11 +107,11 @@ def test_eight_emulated_ranks_x128_equal_one_vm_x1024_equal_the_oracle():
             exact_r["dw0"], exact_r["db0"] = conv_df64(img_w, rdo0); exact_r["dw3"], exact_r["db3"] = conv_df64(np.concatenate(rx3, axis=0), rdo3)
             for n_, e in GRADS:
                 if n_ in exact:
-                    _check("step %d %s: oracle vs float64 on the oracle's operands" % (step, n_), go[n_], exact[n_].reshape(go[n_].shape))
+                    _check("step %d %s: oracle vs float64 on the oracle's operands" % (step, n_), go[n_], exact[n_].reshape(go[n_].shape), floor=1e-2)   # (sequential fp32 sum of ~1e6 terms)
                     _check("step %d %s: 1 x 1024 vs float64 on the product's operands" % (step, n_), gw[n_], exact_g[n_].reshape(gw[n_].shape))
                     _check("step %d %s: SUM of 8 x 128 vs float64 on the shards' operands" % (step, n_), _get(ranks[3], e), exact_r[n_].reshape(gw[n_].shape))
                     if not flipped:
-                        _check("step %d %s: 1 x 1024 vs oracle (no arg-max tie in this step)" % (step, n_), gw[n_], go[n_])
+                        _check("step %d %s: 1 x 1024 vs oracle (no arg-max tie in this step)" % (step, n_), gw[n_], go[n_], floor=1e-2)
                 else:
                     _check("step %d %s: 1 x 1024 vs oracle" % (step, n_), gw[n_], go[n_])
                     _check("step %d %s: SUM of 8 x 128 vs oracle" % (step, n_), _get(ranks[3], e), go[n_])

@@ -101,6 +101,38 @@ def rel_err(got, want):
     return float(np.max(np.abs(got - want)) / max(1e-30, np.max(np.abs(want))))
 
 
+def elem_frac(got, want, rtol=1e-4, floor=1e-3):
+    """ELEMENT-aware companion of rel_err (which is a tensor-norm figure: small elements get no bar of their own there): the share of
+    elements with |got - want| <= rtol * (|want| + floor * max|want|) - every element is held to 1e-4 of ITS OWN magnitude, down to a
+    floor of one thousandth of the tensor's largest element (below that an fp32 sum of ~1000 terms has no relative accuracy left, in the
+    reference as much as here)."""
+    import numpy as np
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if want.size == 0:
+        return 1.0
+    bound = rtol * (np.abs(want) + floor * max(1e-30, np.max(np.abs(want))))
+    return float(np.mean(np.abs(got - want) <= bound))
+
+
+ELEM_MIN = 0.9999                                        # share of elements that must meet the element-aware bar (VERDICT r3 #5a)
+ELEM_LOG = {}                                            # name -> worst share seen (printed by the tests that use it)
+
+
+def check_tensor(name, got, want, tol=1e-4, elem_min=ELEM_MIN, floor=1e-3, min_outliers=0):
+    """tensor-norm bar AND element-aware bar on one tensor.  floor = 1e-2 is used where the REFERENCE side is an fp32 sum of ~1e5 terms in
+    sequential order (the oracle's conv filter gradients, nmath.tcu:211-338): measured against float64 the product meets the 1e-3 floor on
+    every element of every LeNet gradient, the sequential sum does not (1 element of 90 / of 1800, tools/experiments/elemlog.py)."""
+    e = rel_err(got, want)
+    assert e <= tol, "%s: max|d|/max|ref| = %.3g > %.1g" % (name, e, tol)
+    f = elem_frac(got, want, rtol=tol, floor=floor)
+    ELEM_LOG[name] = min(f, ELEM_LOG.get(name, 1.0))
+    import numpy as np
+    n = int(np.asarray(want).size)
+    allowed = max(min_outliers, int((1.0 - elem_min) * n + 1e-9))            # elements that may miss the element-aware bar (all of them still meet the tensor-norm bar above)
+    assert round((1.0 - f) * n) <= allowed, "%s: %d of %d elements beyond %.0e of their own magnitude (floor %.0e max|ref|), %d allowed" % (name, round((1.0 - f) * n), n, tol, floor, allowed)
+
+
 def tokens(text):
     out = []
     for line in text.splitlines():
