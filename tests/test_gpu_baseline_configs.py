@@ -259,3 +259,115 @@ def test_config2_matmul_word_1024_is_exact_on_integer_operands():
     # the printer elides to the first / last three rows and columns (aio_tensor.cpp:141-226 restated in host/printer.cpp)
     corner = C[np.ix_([0, 1, 2, 1021, 1022, 1023], [0, 1, 2, 1021, 1022, 1023])].astype(np.float64).ravel()
     assert numbers_after(out, "C", 36) == list(corner)
+
+
+# ---------------------------------------------------------------------------------------------------------------- t4_40a (the net config #4 names)
+NET_40A = "0.5 10 conv2d 2 maxpool relu flatten 100 linear relu 10 linear softmax"       # examples/t4_40a.4th:10-13 (`nn_c`), N = 256, lr nn.adam (0.001, b1 = 0.9)
+P40 = [("w0", "0 nn.w"), ("b0", "0 nn.b"), ("w4", "4 nn.w"), ("b4", "4 nn.b"), ("w6", "6 nn.w"), ("b6", "6 nn.b")]
+G40 = [("dw0", "0 nn.dw"), ("db0", "0 nn.db"), ("dw4", "4 nn.dw"), ("db4", "4 nn.db"), ("dw6", "6 nn.dw"), ("db6", "6 nn.db")]
+
+
+def _setup_40a(vm, n=256):
+    out = vm.eval("0 trace\n%d 28 28 1 nn.model %s constant net\n%d 28 28 1 tensor rand constant img\n" % (n, NET_40A, n) +
+                  ": hot ( T -- T ) %d 0 do 1 i 10 * i 7 * 10 mod + t! loop ;\n%d vector zeros hot %d 1 10 1 reshape4 constant lbl\n" % (n, n * 10, n) +
+                  ": fw ( N -- N ) img forward ;\n: bw ( N -- N ) lbl backprop ;\n: opt ( N -- N ) 0.001 nn.adam ;\n")
+    assert "?" not in out.replace("-> ok", ""), out
+
+
+def test_t4_40a_net_at_its_own_size_three_adam_steps_vs_oracle_vm():
+    """The net BASELINE config #4 literally names (examples/t4_40a.4th:10-13 + 27-31: `nn_c`, N = 256, `forward backprop lr nn.adam` with the
+    word's defaults b1 = 0.9, b2 = 0.999) through the C++ VM - sample-resident conv stack with the classifier head in its launch (mid layer =
+    relu), fused head backward, fold inside the Adam launch - against the oracle VM on FULL tensors: forward output, every gradient (1e-4,
+    tensor norm and element-aware; a max-pool arg-max tie is verified and the filter gradient then held to float64 on each side's own operands),
+    post-Adam parameters by the propagated-gradient rule of _adam_check (first step) / its bulk rule (later steps)."""
+    import lenet_parity as lp
+    global ADAM_B1
+    g, o = _pair(77)
+    b1_old = ADAM_B1
+    try:
+        ADAM_B1 = 0.9
+        for vm in (g, o):
+            _setup_40a(vm)
+        img = g.fetch("img"); g.eval("drop")
+        assert np.array_equal(o.fetch("img"), img); o.eval("drop")
+        ties = 0
+        for step in range(3):
+            g.eval("net fw\n"); o.eval("net fw\n")
+            c1o = lp._get(o, "1 n@")                                 # conv output the max-pool selects from
+            check_tensor("step %d softmax output" % step, lp._get(g, "-1 n@"), lp._get(o, "-1 n@"), TOL)
+            g.eval("bw\n"); o.eval("bw\n")
+            gw = {n_: lp._get(g, e) for n_, e in G40}; go = {n_: lp._get(o, e) for n_, e in G40}
+            do0, gdo0 = lp._get(o, "1 n@"), lp._get(g, "1 n@")       # dO of the conv layer = dX of the pool (in-place convention)
+            flipped = lp.pool_flips("step %d dO conv1" % step, gdo0, do0, c1o)
+            ties += len(flipped)
+            ex_o = lp.conv_df64(img, do0); ex_g = lp.conv_df64(img, gdo0)
+            for n_, _e in G40:
+                if n_ in ("dw0", "db0"):
+                    k_ = 0 if n_ == "dw0" else 1
+                    check_tensor("step %d %s: oracle vs float64" % (step, n_), go[n_], ex_o[k_].reshape(go[n_].shape), TOL, floor=1e-2)
+                    check_tensor("step %d %s: product vs float64 on its own operands" % (step, n_), gw[n_], ex_g[k_].reshape(gw[n_].shape), TOL)
+                    if not flipped:
+                        check_tensor("step %d %s" % (step, n_), gw[n_], go[n_], TOL, floor=1e-2)
+                else:
+                    check_tensor("step %d %s" % (step, n_), gw[n_], go[n_], TOL)
+            keep = np.array([i not in flipped for i in range(img.shape[0])])
+            check_tensor("step %d dX of layer 0 (produced on demand)" % step, lp._get(g, "0 n@")[keep], lp._get(o, "0 n@")[keep], TOL)
+            g.eval("opt drop\n"); o.eval("opt drop\n")
+            for n_, e in P40:
+                po, pw = lp._get(o, e), lp._get(g, e)
+                if flipped and n_ in ("w0", "b0"):
+                    continue                                         # a verified tie: this step's filter update follows another (equally valid) winner
+                _adam_check("step %d %s" % (step, n_), pw, po, 1e-3, g_first=go["d" + n_] if step == 0 else None, steps=step + 1)
+                g.store(po, "net " + e); g.eval("drop drop")          # next step from ONE set of parameters (the oracle's)
+        assert ties <= 4
+    finally:
+        ADAM_B1 = b1_old
+        g.close(); o.close()
+
+
+TB_40A = '''0 trace
+256 28 28 1 nn.model 0.5 10 conv2d 2 maxpool relu flatten 100 linear relu 10 linear softmax constant md0
+256 28 28 1 tensor rand constant img
+: hot ( T -- T ) 256 0 do 1 i 10 * i 7 * 10 mod + t! loop ;
+2560 vector zeros hot 256 1 10 1 reshape4 constant lbl
+: histo ( M -- M ) 0 nn.w 30 s" nn/conv0" .histo 4 nn.w 30 s" nn/lin4" .histo 6 nn.w 30 s" nn/lin6" .histo ;
+md0 img forward lbl backprop 0.001 nn.adam
+1 .tbstep
+img forward lbl loss.ce s" train/loss" .scalar
+histo
+img 16 s" mnist/train" .tile
+drop
+bye
+'''
+
+
+def test_t4_40a_tensorboard_words_read_live_hbm_tensors(tmp_path):
+    """`ten4 -t <logdir>` on the GPU: the t4_40a script's `.scalar` / `.histo` / `.tile` words (examples/t4_40a.4th:16-31) after one Adam step of
+    the N = 256 net - the histograms are built from weight tensors that live in HBM and were just updated by the fused launch plan.  Compared
+    record by record with the file the oracle VM writes for the same script: same tags and steps, the image tile byte for byte (same Philox
+    draw), the loss at 1e-4, histogram edges at 1e-4 of the range and bucket counts equal up to elements that sit on a bucket edge."""
+    if not os.path.exists(TEN4_ORACLE):
+        pytest.skip("oracle VM binary not shipped")
+    import glob
+    import subprocess
+    from test_tensorboard_sink import records
+    blobs = {}
+    for name, binary in (("gpu", TEN4), ("cpu", TEN4_ORACLE)):
+        d = tmp_path / name
+        env = dict(os.environ, T4_SEED="40", T4_TB_FIXED_TIME="1700000000")
+        r = subprocess.run([binary, "-t", str(d), "-r", "r"], input=TB_40A, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "check TensorBoard param" not in r.stdout, r.stdout[-2000:]
+        blobs[name] = records(open(glob.glob(os.path.join(str(d), "r", "events.out.tfevents.*"))[0], "rb").read())
+    gr, cr = blobs["gpu"], blobs["cpu"]
+    assert len(gr) == len(cr) == 6                               # version, scalar, three histograms, tile
+    assert gr[0] == cr[0] and gr[5] == cr[5]                     # header; the image tile of the batch (identical draw -> identical PNG bytes)
+
+    import struct
+    # scalar: last 4 bytes = the f32 value
+    assert gr[1][:-4] == cr[1][:-4]
+    lg, lc = struct.unpack("<f", gr[1][-4:])[0], struct.unpack("<f", cr[1][-4:])[0]
+    assert abs(lg - lc) <= 1e-4 * abs(lc), (lg, lc)
+    for i in (2, 3, 4):                                          # histograms: same length, every f64 field close, counts equal up to edge elements
+        assert len(gr[i]) == len(cr[i])
+        a = np.frombuffer(gr[i][-(31 * 8):], "<f8"); b = np.frombuffer(cr[i][-(31 * 8):], "<f8")      # the 31 bucket counts (packed doubles, last field)
+        assert a.sum() == b.sum() and np.abs(a - b).sum() <= max(4.0, 2e-4 * a.sum()), (i, np.abs(a - b).sum())

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from vm_util import SCRIPTS, TEN4_ORACLE, ROOT, numbers_after, run_vm
+from vm_util import SCRIPTS, TEN4, TEN4_ORACLE, ROOT, numbers_after, run_vm
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +41,11 @@ def _close(got, want, tol=2.5e-4, rtol=2e-4):
 
 
 def test_cnn_step_script_equals_numpy_model(oracle_vm, oracle):
-    out = run_vm(oracle_vm, os.path.join(SCRIPTS, "cnn_step.4th"), seed=1)
+    _cnn_step_vs_numpy(oracle_vm, oracle)
+
+
+def _cnn_step_vs_numpy(binary, oracle, env=None):
+    out = run_vm(binary, os.path.join(SCRIPTS, "cnn_step.4th"), seed=1, env_extra=env)
     m = oracle.OracleModel(4, 28, 28, 1, seed=1)
     m.conv2d(10, 0.5).maxpool(2).relu().conv2d(20, 0.5).maxpool(2).relu().flatten().linear(100).linear(10).softmax()
     img = _urand(oracle, (4, 28, 28, 1))
@@ -67,7 +71,11 @@ def test_cnn_step_script_equals_numpy_model(oracle_vm, oracle):
 
 
 def test_train_loop_script_with_dropout_momentum_and_adam_equals_numpy_model(oracle_vm, oracle):
-    out = run_vm(oracle_vm, os.path.join(SCRIPTS, "cnn_train_loop.4th"), seed=1)
+    _train_loop_vs_numpy(oracle_vm, oracle)
+
+
+def _train_loop_vs_numpy(binary, oracle, env=None):
+    out = run_vm(binary, os.path.join(SCRIPTS, "cnn_train_loop.4th"), seed=1, env_extra=env)
     m = oracle.OracleModel(8, 28, 28, 1, seed=1)
     m.conv2d(10, 0.5).maxpool(2).relu().conv2d(20, 0.5).dropout(0.5).maxpool(2).relu().flatten().linear(100).dropout(0.5).linear(10).softmax()
     img = _urand(oracle, (8, 28, 28, 1))
@@ -99,3 +107,17 @@ def test_train_loop_script_with_dropout_momentum_and_adam_equals_numpy_model(ora
     _close(numbers_after(out, "aw0", 1), [mlp.layers[0].w.sum(dtype=np.float64)], tol=5e-3, rtol=1e-3)
     w3 = mlp.layers[3].w.reshape(4, 12)                            # printed with the width elision of the reference's printer (first 3 ... last 3)
     _close(numbers_after(out, "aw3", 24), w3[:, [0, 1, 2, 9, 10, 11]], tol=1e-3)
+
+
+# every launch plan of the PRODUCT host against the numpy model - not against goldens the same host/model.cpp wrote: the pattern matcher
+# (stack_at, head / run fusion, fold inside the optimizer, lazy first-layer dX) decides which kernels run, the numpy model knows none of it
+PLANS = [{}, {"T4_OPT_FOLD": "0"}, {"T4_LAZY_DX0": "0"}, {"T4_HEAD_BWD": "0"}, {"T4_STACK_HEAD": "0"}, {"T4_STACK_HEAD": "0", "T4_HEAD_BWD": "0"}, {"T4_STACK": "0"}, {"T4_FUSE": "0"},
+         {"T4_OPT_FOLD": "0", "T4_LAZY_DX0": "0", "T4_HEAD_BWD": "0", "T4_STACK_HEAD": "0"}]
+PLAN_IDS = ["default", "fold-apart", "eager-dx0", "head-bwd-apart", "head-fwd-apart", "head-apart", "no-stack", "one-launch-per-layer", "round2-plan"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", PLANS, ids=PLAN_IDS)
+def test_every_lenet_launch_plan_of_the_product_vm_equals_the_numpy_model(oracle, env):
+    _cnn_step_vs_numpy(TEN4, oracle, env)                     # forward, CE, every gradient, dX of the input (`0 n@` after backprop: produced on demand under the default plan), SGD, Adam
+    _train_loop_vs_numpy(TEN4, oracle, env)                   # both dropouts, momentum SGD over six steps, a second model (tanh / dropout / sigmoid MLP, MSE, Adam) on the same stream
