@@ -86,6 +86,9 @@ unsigned long long t4k_launch_count(void);
 /* Library streams own a private workspace, so independent work (e.g. dW beside dX) may be forked
  * onto them and still be captured into one graph through event edges. */
 int t4k_stream_create(t4k_stream_t *s);
+/* A stream WITHOUT a library workspace: copies and element-wise launches only (the batch prefetch of the dataset feed,
+ * src/mu/dataset.cu:112 "TODO: async prefetch"); not a lane - kernels that need split-K / partial slabs refuse or serialise on it. */
+int t4k_stream_create_plain(t4k_stream_t *s);
 int t4k_stream_destroy(t4k_stream_t s);
 int t4k_stream_wait_event(t4k_stream_t s, t4k_event_t e);   /* fork / join edge (also inside a capture) */
 int t4k_set_default_stream(t4k_stream_t s);        /* adopt an external stream (e.g. torch's current) */

@@ -36,6 +36,7 @@ int t4k_memcpy_d2d(void *d, const void *s, size_t n, t4k_stream_t) { memmove(d, 
 int t4k_memset(void *d, int b, size_t n, t4k_stream_t) { memset(d, b, n); return T4K_OK; }
 int t4k_sync(t4k_stream_t) { return T4K_OK; }
 int t4k_stream_create(t4k_stream_t *s) { *s = nullptr; return T4K_OK; }
+int t4k_stream_create_plain(t4k_stream_t *s) { *s = nullptr; return T4K_OK; }
 int t4k_stream_destroy(t4k_stream_t) { return T4K_OK; }
 int t4k_stream_wait_event(t4k_stream_t, t4k_event_t) { return T4K_OK; }
 int t4k_set_default_stream(t4k_stream_t) { return T4K_OK; }

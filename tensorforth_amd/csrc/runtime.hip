@@ -154,6 +154,11 @@ int t4k_stream_create(t4k_stream_t *s) {
     g.lane[g.n_lane].s = h; g.lane[g.n_lane].ws = ws; g.n_lane++;
     return T4K_OK;
 }
+int t4k_stream_create_plain(t4k_stream_t *s) {
+    T4K_REQUIRE_INIT();
+    hipStream_t h; T4K_HIP(hipStreamCreateWithFlags(&h, hipStreamNonBlocking)); *s = (t4k_stream_t)h;
+    return T4K_OK;
+}
 int t4k_stream_destroy(t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (!s) return T4K_OK;
     State &g = st();

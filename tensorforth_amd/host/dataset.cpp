@@ -26,9 +26,9 @@ static std::map<std::string, Corpus *> &corpora() {      // Loader::init src/ld/
 static uint32_t be32(FILE *f) { uint8_t b[4] = {0, 0, 0, 0}; if (fread(b, 1, 4, f) != 4) return 0; return (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3]; }
 
 bool Corpus::init(int batch) {
-    cancel_ahead();
+    idle();
     if (N != batch) for (int sl = 0; sl < 2; sl++) { if (pix[sl]) { t4k_host_free(pix[sl]); pix[sl] = nullptr; } if (lab[sl]) { t4k_host_free(lab[sl]); lab[sl] = nullptr; } }
-    N = batch; eof = false; batch_sz = 0;
+    N = batch;
     if (fd) { fclose(fd); fd = nullptr; } if (fl) { fclose(fl); fl = nullptr; }
     fd = fopen(f_data.c_str(), "rb");
     if (!fd) { hprintf("failed to open file %s\n", f_data.c_str()); return false; }
@@ -45,31 +45,63 @@ bool Corpus::init(int batch) {
     corpus_sz = n;
     return true;
 }
-// One persistent reader thread per corpus (spawning a thread per batch costs more than the read): the main thread
-// posts (batch, slot), the reader fills the pinned slot and signals.
+// One persistent reader thread per corpus (spawning a thread per batch costs more than the read): the main thread queues
+// batch numbers, the reader waits for the launch that last read the pinned slot, fills it and signals.
 struct Reader {
     std::thread th; std::mutex mu; std::condition_variable cv;
-    int req_bid = -1, req_slot = 0, result = 0; bool busy = false, quit = false;
+    int queue[2] = {-1, -1};                             // at most one request per slot
+    bool busy = false;
 };
 static void reader_main(Corpus *c, Reader *r) {
     std::unique_lock<std::mutex> lk(r->mu);
     for (;;) {
-        r->cv.wait(lk, [r] { return r->quit || (r->busy && r->req_bid >= 0); });
-        if (r->quit) return;
-        const int bid = r->req_bid, slot = r->req_slot;
-        r->req_bid = -1;
+        r->cv.wait(lk, [r] { return r->queue[0] >= 0 || r->queue[1] >= 0; });
+        const int q = (r->queue[0] >= 0 && (r->queue[1] < 0 || r->queue[0] < r->queue[1])) ? 0 : 1;   // lower batch first
+        const int bid = r->queue[q], slot = bid & 1;
+        r->busy = true;
+        const bool wait_ev = c->pin_wait[slot]; c->pin_wait[slot] = false;
         lk.unlock();
+        if (wait_ev) t4k_event_sync(c->pin_done[slot]);  // the staging launch of the batch this slot held
         const int n = c->read_into(bid, slot);
         lk.lock();
-        r->result = n; r->busy = false;
+        c->slot_n[slot] = n; r->queue[q] = -1; r->busy = false;
         r->cv.notify_all();
     }
 }
-void Corpus::cancel_ahead() {                            // wait for an outstanding read-ahead and forget it
-    if (worker) { Reader *r = (Reader *)worker; std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r] { return !r->busy; }); }
-    ahead_bid = -1; ahead_n = 0;
+void Corpus::ensure_slots() {
+    const size_t cell = (size_t)H * W * C;
+    for (int s = 0; s < 2; s++)
+        if (!pix[s]) { void *p; t4k_host_alloc(&p, (size_t)N * cell); pix[s] = (uint8_t *)p; t4k_host_alloc(&p, sizeof(uint32_t) * N); lab[s] = (uint32_t *)p;
+                       if (!pin_done[s]) t4k_event_create(&pin_done[s]); }
 }
-void Corpus::rewind() { eof = false; cancel_ahead(); }
+void Corpus::idle() {                                    // wait for outstanding reads and forget what the slots hold
+    if (worker) { Reader *r = (Reader *)worker; std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r] { return !r->busy && r->queue[0] < 0 && r->queue[1] < 0; }); }
+    for (int s = 0; s < 2; s++) { if (pin_wait[s] && pin_done[s]) t4k_event_sync(pin_done[s]); pin_wait[s] = false; slot_bid[s] = -1; slot_n[s] = 0; }
+}
+void Corpus::request(int bid) {                          // the staging launch of the batch the slot holds now must have been ISSUED
+    if (bid < 0 || bid >= n_batches() || slot_bid[bid & 1] == bid) return;
+    ensure_slots();
+    if (!worker) { Reader *r = new Reader(); worker = r; r->th = std::thread(reader_main, this, r); r->th.detach(); }
+    Reader *r = (Reader *)worker;
+    { std::unique_lock<std::mutex> lk(r->mu);
+      r->cv.wait(lk, [&] { return r->queue[bid & 1] < 0; });            // an earlier request for this slot (unusual word order) finishes first
+      slot_bid[bid & 1] = bid; r->queue[bid & 1] = bid; }
+    r->cv.notify_all();
+}
+int Corpus::wait_batch(int bid) {
+    if (bid < 0 || bid >= n_batches()) return 0;
+    const int slot = bid & 1;
+    ensure_slots();
+    Reader *r = (Reader *)worker;
+    if (slot_bid[slot] != bid) {                         // nobody was asked to: cold start / after a rewind - read here
+        if (r) { std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r, slot] { return r->queue[slot] < 0; }); }
+        if (pin_wait[slot]) { t4k_event_sync(pin_done[slot]); pin_wait[slot] = false; }
+        slot_bid[slot] = bid; slot_n[slot] = read_into(bid, slot);
+        return slot_n[slot];
+    }
+    if (r) { std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r, slot] { return r->queue[slot] < 0; }); }   // a request leaves the queue when its read is done
+    return slot_n[slot];
+}
 int Corpus::read_into(int bid, int slot) {               // returns the number of samples read (0 at end of corpus)
     const long off = (long)N * bid;
     if (off >= corpus_sz) return 0;
@@ -97,34 +129,29 @@ int Corpus::read_into(int bid, int slot) {               // returns the number o
     }
     return (int)n;
 }
-bool Corpus::fetch(int bid) {
-    const long off = (long)N * bid;
-    if (eof || off >= corpus_sz) { hprintf("%s::fetch EOF reached (needs rewind)\n", cifar ? "Cifar10" : "Mnist"); eof = true; return false; }
-    const size_t cell = (size_t)H * W * C;
-    for (int s = 0; s < 2; s++) {
-        if (!pix[s]) { void *p; t4k_host_alloc(&p, (size_t)N * cell); pix[s] = (uint8_t *)p; t4k_host_alloc(&p, sizeof(uint32_t) * N); lab[s] = (uint32_t *)p; t4k_event_create(&copied[s]); }
-    }
-    const int slot = bid & 1;
-    int n;
-    if (ahead_bid == bid && worker) {                    // read ahead by the reader thread
-        Reader *r = (Reader *)worker; std::unique_lock<std::mutex> lk(r->mu);
-        r->cv.wait(lk, [r] { return !r->busy; }); n = r->result;
-    } else { cancel_ahead(); if (copied[slot]) t4k_event_sync(copied[slot]); n = read_into(bid, slot); }
-    ahead_bid = -1;
-    cur_slot = slot; batch_sz = n;
-    if (off + (long)n >= corpus_sz) eof = true;
-    else {                                               // read batch bid+1 into the other slot while the GPU works on this one
-        const int nslot = slot ^ 1, nbid = bid + 1;
-        if (copied[nslot]) t4k_event_sync(copied[nslot]);    // that slot's previous H2D copies (batch bid-1) have long finished
-        ahead_bid = nbid;
-        if (!worker) { Reader *r = new Reader(); worker = r; r->th = std::thread(reader_main, this, r); r->th.detach(); }
-        Reader *r = (Reader *)worker;
-        { std::lock_guard<std::mutex> lk(r->mu); r->req_bid = nbid; r->req_slot = nslot; r->busy = true; }
-        r->cv.notify_all();
-    }
-    return n > 0;
-}
 
+// The feed.  Batch b of an epoch lives in dbuf[b % 3] / lbuf[b % 3].  fetch(b) makes batch b current (swaps `data` / `label`: a pointer
+// swap once the pipeline runs), then issues the staging launch of batch b + 1 - (x - mean) * scale and the labels, read straight out of
+// the pinned slot over the fabric - on a side stream, and asks the reader thread for batch b + 2.  Ordering:
+//   * the side stream writes dbuf[(b+1) % 3] = the buffer of batch b - 2: it waits for the main-stream mark recorded at fetch(b - 1),
+//     which stands behind every launch that read batches <= b - 2 (a wait on the SIDE stream: nothing is added to the step's stream);
+//   * the model must not read dbuf[b % 3] before its staging launch is done: the HOST waits for that launch's event - issued one whole
+//     step earlier, so the wait is a query; no cross-stream edge on the step's stream (measured in round 3: +8 us per edge);
+//   * the reader refills pinned slot b & 1 after the event of the launch that read it (waited for on the reader thread).
+static t4k_stream_t feed_stream() {
+    static t4k_stream_t s = nullptr; static bool tried = false;
+    if (!tried) { tried = true; if (t4k_stream_create_plain(&s) != T4K_OK) s = nullptr; }
+    return s;
+}
+static const bool g_prefetch = getenv("T4_FEED_PREFETCH") ? atoi(getenv("T4_FEED_PREFETCH")) != 0 : true;
+void Dataset::release_ring() {
+    for (int i = 0; i < 3; i++) {
+        if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]);
+        if (dbuf[i]) t4k_free(dbuf[i]); if (lbuf[i]) t4k_free(lbuf[i]);
+        dbuf[i] = nullptr; lbuf[i] = nullptr; dev_bid[i] = -1; mark_set[i] = false;
+    }
+    data = nullptr; label = nullptr; ring_numel = 0;
+}
 int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     if (ds_name) {
         auto it = corpora().find(ds_name);
@@ -134,22 +161,61 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
         dataset_size = cp->corpus_sz;
         numel = (uint64_t)cp->N * cp->H * cp->W * cp->C;
         rank = 4; shape[0] = cp->H; shape[1] = cp->W; shape[2] = cp->C; shape[3] = cp->N;
+        rewind = true;
     }
     if (!cp) { hprintf("  } dataset#fetch => not found in Loader\n"); return -1; }
-    if (rewind) { cp->rewind(); batch_id = done = 0; }
     die_if_no_backend();
-    if (!cp->fetch(batch_id)) { hprintf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
-    const int n = batch_sz = cp->batch_sz;
-    done = cp->eof;
-    die_if_no_backend();
-    if (!data)    { void *p; t4k_malloc(&p, sizeof(float) * numel); data = (float *)p; t4k_memset(data, 0, sizeof(float) * numel, stream()); }
-    if (!label)   { void *p; t4k_malloc(&p, sizeof(uint32_t) * N()); label = (uint32_t *)p; }
-    if (!raw_dev) { void *p; t4k_malloc(&p, numel); raw_dev = (uint8_t *)p; }
-    const long NX = (long)n * HWC();
-    // The kernels read the pinned staging slot directly over the fabric (hipHostMalloc memory is device visible): no
-    // DMA-engine copy, so no cross-engine synchronisation bubble in front of `forward` (measured: 2 H2D copies ~ 40 us/step)
-    chk(t4k_stage_batch(cp->cur_pix(), data, NX, mean, scale, cp->cur_lab(), label, n, stream()), "dataset#load");   // (x - mean) * scale and the labels, one launch
-    t4k_event_record(cp->copied[cp->cur_slot], stream());    // the staging slot may be refilled once these kernels are done
+    if (rewind) {                                        // also after `normalize`: whatever was staged ahead is void
+        cp->idle();
+        for (int i = 0; i < 3; i++) { if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]); dev_bid[i] = -1; }
+        batch_id = done = 0;
+    }
+    const int b = batch_id, nb = cp->n_batches();
+    if (done || b >= nb) { hprintf("%s::fetch EOF reached (needs rewind)\n", cp->cifar ? "Cifar10" : "Mnist"); done = 1; hprintf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
+    if (ring_numel != numel) {
+        if (ring_numel) { t4k_sync(stream()); release_ring(); }
+        for (int i = 0; i < 3; i++) {
+            void *p; t4k_malloc(&p, sizeof(float) * numel); dbuf[i] = (float *)p; t4k_memset(p, 0, sizeof(float) * numel, stream());
+            t4k_malloc(&p, sizeof(uint32_t) * N()); lbuf[i] = (uint32_t *)p;
+            if (!staged[i]) { t4k_event_create(&staged[i]); t4k_event_create(&mark[i]); }
+        }
+        ring_numel = numel;
+    }
+    const long cell = HWC();
+    t4k_stream_t side = g_prefetch ? feed_stream() : nullptr;     // none on a backend without streams (the oracle's): every batch then takes the in-stream path
+    // ---- batch b becomes current
+    const int r = b % 3;
+    if (dev_bid[r] == b) t4k_event_sync(staged[r]);      // staged ahead (issued a step ago)
+    else {
+        const int n = cp->wait_batch(b);
+        if (n <= 0) { hprintf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
+        chk(t4k_stage_batch(cp->pix[b & 1], dbuf[r], (long)n * cell, mean, scale, cp->lab[b & 1], lbuf[r], n, stream()), "dataset#load");   // (x - mean) * scale and the labels, one launch
+        t4k_event_record(cp->pin_done[b & 1], stream()); cp->pin_wait[b & 1] = true;
+        // a short last batch leaves the previous batch's samples behind it (Dataset::_load copies batch_sz samples into ONE buffer, dataset.cu:142-158)
+        if (n < cp->N && b > 0) t4k_memcpy_d2d(dbuf[r] + (long)n * cell, dbuf[(b + 2) % 3] + (long)n * cell, sizeof(float) * (size_t)(cp->N - n) * cell, stream());
+        dev_bid[r] = b; dev_n[r] = n;
+    }
+    data = dbuf[r]; label = lbuf[r]; batch_sz = dev_n[r];
+    done = ((long)b * cp->N + batch_sz >= cp->corpus_sz) ? 1 : 0;
+    if (!done) {
+        // ---- batch b + 1 goes to its buffer on the side stream if the reader already holds it (full batches only); a cold start just asks for it
+        const int b1 = b + 1, r1 = b1 % 3;
+        if (side && dev_bid[r1] != b1 && cp->slot_bid[b1 & 1] == b1 && (long)(b1 + 1) * cp->N <= cp->corpus_sz) {
+            const int n1 = cp->wait_batch(b1);
+            if (n1 == cp->N) {
+                const int pm = (b + 2) % 3;              // the mark of fetch(b - 1)
+                if (!mark_set[pm]) { t4k_event_record(mark[pm], stream()); mark_set[pm] = true; }      // pipeline start: behind everything issued so far
+                t4k_stream_wait_event(side, mark[pm]);
+                chk(t4k_stage_batch(cp->pix[b1 & 1], dbuf[r1], (long)n1 * cell, mean, scale, cp->lab[b1 & 1], lbuf[r1], n1, side), "dataset#prefetch");
+                t4k_event_record(staged[r1], side);
+                t4k_event_record(cp->pin_done[b1 & 1], side); cp->pin_wait[b1 & 1] = true;
+                dev_bid[r1] = b1; dev_n[r1] = n1;
+            }
+        }
+        cp->request(b1);                                 // no-op when the slot holds (or is being filled with) that batch
+        cp->request(b + 2);                              // slot b & 1: batch b's staging launch has been issued, the reader waits for its event
+    }
+    if (side) { t4k_event_record(mark[r], stream()); mark_set[r] = true; }
     batch_id++;
     return 0;
 }

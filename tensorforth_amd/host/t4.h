@@ -179,35 +179,43 @@ private:
 // ---------------------------------------------------------------- Dataset / loaders
 struct Corpus {
     std::string name, f_data, f_label;
-    int N = 0, H = 0, W = 0, C = 0, corpus_sz = 0, batch_sz = 0;
-    bool eof = false;
+    int N = 0, H = 0, W = 0, C = 0, corpus_sz = 0;
     FILE *fd = nullptr, *fl = nullptr;
     bool init(int batch);                      // src/ld/mnist.cpp:21-62 (IDX header, big endian)
-    bool fetch(int batch_id);                  // batch -> staging slot (batch_id & 1); the next batch is read ahead by a worker thread
-    void rewind();
     bool cifar = false;
-    // double-buffered pinned staging: slot s = batch & 1 holds u8 pixels + u32 labels of one batch, so the
-    // H2D copies are truly asynchronous and the file read of batch b+1 overlaps the GPU work of batch b
+    int  n_batches() const { return N > 0 ? (corpus_sz + N - 1) / N : 0; }
+    // double-buffered pinned staging: slot s = batch & 1 holds u8 pixels + u32 labels of one batch; a persistent
+    // reader thread fills a slot (after the event of the launch that last read it) while the GPU works on earlier batches
     uint8_t  *pix[2] = {nullptr, nullptr};
     uint32_t *lab[2] = {nullptr, nullptr};
-    t4k_event_t copied[2] = {nullptr, nullptr};  // recorded after a slot's H2D copies: the reader waits on it before refilling the slot
-    int  ahead_bid = -1, ahead_n = 0;          // batch the worker is reading / has read, and its sample count
+    t4k_event_t pin_done[2] = {nullptr, nullptr};   // recorded behind the staging launch that reads the slot
+    bool pin_wait[2] = {false, false};              // the event has been recorded since the slot was last filled
+    int  slot_bid[2] = {-1, -1}, slot_n[2] = {0, 0};   // batch a slot holds (or is being filled with) and its sample count
     void *worker = nullptr;                    // persistent reader thread (dataset.cpp)
-    int  read_into(int bid, int slot);         // blocking file read (runs on the worker thread)
-    void cancel_ahead();
-    uint8_t  *cur_pix() { return pix[cur_slot]; }
-    uint32_t *cur_lab() { return lab[cur_slot]; }
-    int cur_slot = 0;
+    int  read_into(int bid, int slot);         // blocking file read (runs on the worker thread, or inline on a cold start)
+    void ensure_slots();
+    void request(int bid);                     // read batch bid into slot bid & 1, asynchronously
+    int  wait_batch(int bid);                  // samples of batch bid once its slot is filled (reads inline when nobody was asked to)
+    void idle();                               // wait for the reader and forget what the slots hold
 };
 struct Dataset : Tensor {
     uint64_t dataset_size = 0;
     int batch_id = 0, batch_sz = 0, done = 1;
-    uint32_t *label = nullptr;                 // device
-    uint8_t *raw_dev = nullptr;                // device staging of the u8 batch
+    uint32_t *label = nullptr;                 // device: labels of the current batch (one of lbuf)
     DU mean = 0.0f, scale = 1.0f / 256.0f;     // src/mu/dataset.h:36-37
     Corpus *cp = nullptr;
+    // prefetch ring (the reference's TODO, src/mu/dataset.cu:112): batch b lives in dbuf[b % 3]; while the model works on batch b the
+    // staging launch of batch b + 1 runs on a side stream, so `fetch` / `next` only swap `data` / `label`
+    float    *dbuf[3] = {nullptr, nullptr, nullptr};
+    uint32_t *lbuf[3] = {nullptr, nullptr, nullptr};
+    int       dev_bid[3] = {-1, -1, -1}, dev_n[3] = {0, 0, 0};
+    t4k_event_t staged[3] = {nullptr, nullptr, nullptr};   // side stream: batch is in its buffer
+    t4k_event_t mark[3] = {nullptr, nullptr, nullptr};     // main stream: recorded at fetch(b), i.e. behind everything that read batches < b
+    bool mark_set[3] = {false, false, false};
+    uint64_t ring_numel = 0;
     void set_norm(DU m, DU s) { mean = m; scale = 1.0f / s; }
     int  fetch(const char *ds_name, bool rewind);
+    void release_ring();
 };
 
 // ---------------------------------------------------------------- Model

@@ -163,9 +163,8 @@ void Store::drop(Obj &o) {
     if (o.type == T_MODEL) { ((Model &)o).free_all(); release(&o); return; }
     if (o.type == T_DATASET) {
         Dataset &d = (Dataset &)o;
-        if (d.data) t4k_free(d.data);
-        if (d.label) t4k_free(d.label);
-        if (d.raw_dev) t4k_free(d.raw_dev);
+        if (d.cp) d.cp->idle();
+        d.release_ring();
         d.data = nullptr; d.owns = false;
         release(&o); return;
     }
