@@ -56,6 +56,7 @@ struct GemmP {
     // optional rider (generic 64x64 kernel only): workgroups beyond the tile grid add the column sums of a [rows, E] matrix
     // into cs_out - the bias gradient of a linear layer shares the launch of its weight-gradient GEMM
     const float *cs_X; float *cs_out; int cs_rows, cs_E;
+    const float *Z;                    // 4 KiB of zeros (State::d_zero): source of LDS-DMA lanes past the K range / the matrix edge (DMA variants of the 32x32 kernels)
 };
 
 // FULL: every K slice is whole stages (K-slice%BK == 0, VEC): no predicates, no branches in the K loop, so the compiler can sink the
@@ -435,7 +436,9 @@ __device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const flo
     }
 }
 struct NoPro { __device__ void operator()() const {} };
-template <bool AKC, bool BKC, int CB, int NW = 4, bool ALDS = false, typename PRO = NoPro>   // NW waves = NW k-groups per 32x32 tile; ALDS: the A tile is prepared in LDS by `pro`, which runs while the first B fragments are in flight
+// DMA: the operand fragments come through wave-private LDS blocks filled by global_load_lds_dwordx4 (see the K loop) - `red` is then the
+// workgroup's dynamic LDS of NW x 16 KiB; k-group w's partial accumulators land at red + w RS
+template <bool AKC, bool BKC, int CB, int NW = 4, bool ALDS = false, typename PRO = NoPro, bool DMA = false, bool RST = false>   // NW waves = NW k-groups per 32x32 tile; ALDS: the A tile is prepared in LDS by `pro`, which runs while the first B fragments are in flight
 __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, float *red,
                                               int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
                                               const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0,
@@ -495,6 +498,115 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(slots + 4 * bx + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    constexpr int RS = DMA ? 4096 : 1024;                         // floats between two k-groups' partial accumulators in `red`
+    if constexpr (DMA) {
+        // Coalesced operand fetch for slivers.  The register path above makes every wave load a gather (32 rows x 16 bytes: 64 cache-line
+        // look-ups per instruction for 1 KiB, the address unit's queue stalls the wave's issue - SQ_WAIT_INST_ANY 42 % on the K-contiguous
+        // forward layers).  Here a wave moves its k range in blocks of 32 k through two private LDS slots (A 4 KiB + B 4 KiB each):
+        // a DMA instruction takes whole 128-byte runs (8 rows x 32 k of a K-contiguous operand, 8 k rows x 32 columns of the other kind),
+        // no VGPR round trip, no barrier in the K loop (the blocks are the wave's own: s_waitcnt vmcnt only).
+        //   K-contiguous block [32 rows][32 k]: the 16-byte quad q of row r sits at quad (q ^ ((r >> 1) & 7)) - the 16 lanes of a
+        //   ds_read_b128 group ({0-3,12-15,20-27} ...) then cover all 64 banks once;  [K][M] block: [32 k][32 columns], ds_read_b32 rows.
+        static_assert(!ALDS, "DMA operands come from global memory");
+        typedef __attribute__((address_space(3))) const float lds_f;
+        typedef __attribute__((address_space(3))) const v4f lds_v4;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)red;
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        const int nblk = (kend - kbeg + 31) >> 5;
+        const int b0 = wu * nblk / NW, b1 = (wu + 1) * nblk / NW;
+        const int i8 = lane >> 3, i7 = lane & 7;
+        const float *pa[4], *pb[4]; int ka[4], kb[4];            // lane's source of DMA instruction j at k = 0, and the k (within a block) its validity hangs on
+        const bool acol = AKC || m0 + 4 * i7 < M, bcol = BKC || n0 + 4 * i7 < N;
+        const float *zsrc = p.Z + 4 * i7;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = 8 * j + i8, q = i7 ^ ((r >> 1) & 7);
+            if (AKC) { pa[j] = p.A + (long)min(m0 + r, M - 1) * K + 4 * q; ka[j] = 4 * q; } else { pa[j] = p.A + (long)r * M + m0 + 4 * i7; ka[j] = r; }
+            if (BKC) { pb[j] = p.B + (long)min(n0 + r, N - 1) * K + 4 * q; kb[j] = 4 * q; } else { pb[j] = p.B + (long)r * N + n0 + 4 * i7; kb[j] = r; }
+        }
+        auto issue = [&](int b, int slot) __attribute__((always_inline)) {
+            const int k0 = kbeg + 32 * b;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float *sa = (k0 + ka[j] < kend && acol) ? (AKC ? pa[j] + k0 : pa[j] + (long)k0 * M) : zsrc;
+                const float *sb = (k0 + kb[j] < kend && bcol) ? (BKC ? pb[j] + k0 : pb[j] + (long)k0 * N) : zsrc;
+                const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((wu * 4096 + slot * 2048 + j * 256) * 4));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sa), "s"(la) : "memory");
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sb), "s"(la + 4096u) : "memory");
+            }
+        };
+        const int sw = (l31 >> 1) & 7;
+        auto frag = [&](int slot, float (&fa)[4][4], float (&fb)[4][4]) __attribute__((always_inline)) {
+            lds_f *a = (lds_f *)red + wu * 4096 + slot * 2048, *b = a + 1024;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (AKC) { const v4f t = *(lds_v4 *)(a + l31 * 32 + (((2 * c + h) ^ sw) << 2)); fa[c][0] = t[0]; fa[c][1] = t[1]; fa[c][2] = t[2]; fa[c][3] = t[3]; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fa[c][j] = a[(8 * c + 4 * h + j) * 32 + l31];
+                }
+                if (BKC) { const v4f t = *(lds_v4 *)(b + l31 * 32 + (((2 * c + h) ^ sw) << 2)); fb[c][0] = t[0]; fb[c][1] = t[1]; fb[c][2] = t[2]; fb[c][3] = t[3]; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fb[c][j] = b[(8 * c + 4 * h + j) * 32 + l31];
+                }
+            }
+        };
+        // Everything a wave needs is requested before its first wait: blocks 0 and 1 by DMA into the two slots, blocks 2 and 3 (RST) into
+        // registers with the DMA's own lane -> address map (coalesced) - they are written to a slot (ds_write_b128, the DMA's image) once
+        // its fragments have been read.  A second round trip would cost more than the copies: the fetch is what bounds these launches.
+        const int nb = b1 - b0;
+        v4f rs[RST ? 2 : 1][8];
+        auto regload = [&](int b, int x) __attribute__((always_inline)) {
+            const int k0 = kbeg + 32 * b;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float *sa = (k0 + ka[j] < kend && acol) ? (AKC ? pa[j] + k0 : pa[j] + (long)k0 * M) : zsrc;
+                const float *sb = (k0 + kb[j] < kend && bcol) ? (BKC ? pb[j] + k0 : pb[j] + (long)k0 * N) : zsrc;
+                rs[x][j] = *reinterpret_cast<const v4f *>(sa); rs[x][4 + j] = *reinterpret_cast<const v4f *>(sb);
+            }
+        };
+        auto regstore = [&](int x, int slot) __attribute__((always_inline)) {
+            typedef __attribute__((address_space(3))) v4f lds_w4;
+            lds_w4 *d = (lds_w4 *)((__attribute__((address_space(3))) float *)red + wu * 4096 + slot * 2048) + lane;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { d[j * 64] = rs[x][j]; d[256 + j * 64] = rs[x][4 + j]; }
+        };
+        auto wait_vm = [&](int blocks_after) __attribute__((always_inline)) {       // DMA and register loads return in issue order
+            if (blocks_after >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (blocks_after == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (blocks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto mm4 = [&](float (&fa)[4][4], float (&fb)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][2], fb[c][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][3], fb[c][3], acc1, 0, 0, 0);
+            }
+        };
+        if (nb > 0) {
+            issue(b0, 0);
+            if (nb > 1) issue(b0 + 1, 1);
+            if (RST) { if (nb > 2) regload(b0 + 2, 0); if (nb > 3) regload(b0 + 3, 1); }
+            constexpr int AHEAD = RST ? 4 : 2;                   // blocks requested up front
+            int slot = 0;
+            for (int i = 0; i < nb; i++) {
+                if (i < 2 || !RST) wait_vm(min(nb, i < AHEAD ? AHEAD : i + 2) - 1 - i);   // blocks 2, 3 of RST: the register copies' own waits (compiler-counted) cover them
+                else if (i >= 4) wait_vm(0);                      // deeper ranges (not dispatched today): DMA again, one block at a time
+                float fa[4][4], fb[4][4];
+                frag(slot, fa, fb);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (RST) { if (i == 0 && nb > 2) regstore(0, 0); if (i == 1 && nb > 3) regstore(1, 1); if (i + 2 < nb && i >= 2) issue(b0 + i + 2, slot); }
+                else if (i + 2 < nb) issue(b0 + i + 2, slot);    // the slot's fragments sit in registers
+                if (i + 1 >= nb) arrive();
+                mm4(fa, fb);
+                slot ^= 1;
+            }
+        } else arrive();
+    } else {
     if (ALDS) {                                                   // the first B fragments fly while the workgroup prepares its A tile (barriers inside: every thread calls pro)
         if (c0 < c1) s32_fetch<AKC, BKC, CB, ALDS, false, true>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
         pro();
@@ -513,9 +625,10 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
             }
         }
     } else arrive();
+    }
     // the four k-groups meet in LDS: red[w][r][lane]
 #pragma unroll
-    for (int r = 0; r < 16; r++) red[(w * 16 + r) * 64 + lane] = acc0[r] + acc1[r];
+    for (int r = 0; r < 16; r++) red[w * RS + r * 64 + lane] = acc0[r] + acc1[r];
     // In-place dX: a writer waits until the reader workgroups of ITS columns have consumed their loads of the shared buffer.  No
     // counters: a reader stores this launch's epoch into its slot (fire and forget), the writer's first wave polls those slots with
     // agent-scope loads until all of them carry the epoch - one store and one load round trip on the critical path, nothing to re-arm.
@@ -549,7 +662,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         const int r = QN * w + q, gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         float v = red[r * 64 + lane];
 #pragma unroll
-        for (int g = 1; g < NW; g++) v += red[(g * 16 + r) * 64 + lane];         // k-groups in order
+        for (int g = 1; g < NW; g++) v += red[g * RS + r * 64 + lane];           // k-groups in order
         if (gm < M && gn < N) {
             const long z = (long)gm * N + gn;
             if (p.nsplit > 1) { p.part[(long)by * M * N + z] = v; continue; }       // split-K slab: the consumer folds (XFold / k_splitk_fold)
@@ -587,6 +700,31 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CB
     if ((int)blockIdx.x >= p.tiles_m * p.tiles_n && blockIdx.y) return;   // column-sum riders run once
     gemm_s32_body<AKC, BKC, CB, NW>(p, blockIdx.x, red, nullptr, 0, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
 }
+// the same launch with the operands staged by LDS-DMA (gemm_s32_body<.., DMA>): dynamic LDS = NW x 16 KiB
+template <bool AKC, bool BKC, int NW, bool RST>
+__global__ void __launch_bounds__(64 * NW) k_gemm_l32(GemmP p, ActEpi ep, FoldRider fr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nwork = (int)gridDim.x - fr.cp_blocks;
+    if ((int)blockIdx.x >= nwork) {                              // the model's copy of the batch into its layer 0 rides along (forward.cu:39)
+        if (blockIdx.y) return;
+        const long t0 = (long)((int)blockIdx.x - nwork) * (64 * NW) + threadIdx.x, step = (long)fr.cp_blocks * (64 * NW);
+        if (fr.cp_vec) {
+            const long n4 = fr.cp_n >> 2;
+            for (long z = t0; z < n4; z += step) reinterpret_cast<float4 *>(fr.cp_dst)[z] = reinterpret_cast<const float4 *>(fr.cp_src)[z];
+            for (long z = (n4 << 2) + t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
+        } else
+            for (long z = t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
+        return;
+    }
+    if ((int)blockIdx.x >= p.tiles_m * p.tiles_n && blockIdx.y) return;   // column-sum riders run once
+    gemm_s32_body<AKC, BKC, 4, NW, false, NoPro, true, RST>(p, blockIdx.x, lds, nullptr, 0, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
+}
+template <bool AKC, bool BKC, int NW, bool RST>
+void launch_l32(const GemmP &p, const ActEpi &ep, const FoldRider &fr, dim3 grid, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_l32<AKC, BKC, NW, RST>), hipFuncAttributeMaxDynamicSharedMemorySize, NW * 16384); attr_done = true; }
+    T4K_LAUNCH((k_gemm_l32<AKC, BKC, NW, RST>), grid, dim3(64 * NW), (size_t)NW * 16384, s, p, ep, fr);
+}
 // dW += dY^T X (+ dB rider) and dX = dY W of one linear layer on 32x32 tiles (see k_gemm_dual for the gate)
 // CB = k chunks (of 8) per register batch: 8 = 64 k in flight twice over (216 VGPRs, 2 workgroups per CU), 4 = half of that (4 per CU)
 template <int CB>
@@ -594,6 +732,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 
     __shared__ float red[4 * 16 * 64];
     if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, CB>(p1, blockIdx.x, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
     else                       gemm_s32_body<true, false, CB>(p2, (int)blockIdx.x - nb1, red, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
+}
+
+// k_gemm_dual32 with LDS-DMA operand blocks (gemm_s32_body<.., DMA>): 4 waves, 64 KiB of dynamic LDS.  More workgroups than resident slots are
+// fine here although the dX writers spin on the dW readers' slots: a writer's readers all have LOWER workgroup ids, each XCD dispatches its
+// workgroups in id order and a reader never waits - so every reader is running or done before the first writer of its XCD takes a slot
+// (the same dispatch-order argument as the conv stack's band exchange; the wait is bounded and reported anyway).
+template <bool RST>
+__global__ void __launch_bounds__(256) k_gemm_dual_l32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, MaskChain mc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, 4, 4, false, NoPro, true, RST>(p1, blockIdx.x, lds, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
+    else                       gemm_s32_body<true, false, 4, 4, false, NoPro, true, RST>(p2, (int)blockIdx.x - nb1, lds, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
 }
 
 // ---- classifier-head backward + the backward of the linear layer in front of it, ONE launch (t4k_mlp_head_bwd).
@@ -1761,6 +1910,17 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             // arrival slots: ints [512, 1024) of the stream's gate block; the epoch is this stream's launch count (never 0, slots cleared when it wraps)
             unsigned *slots = reinterpret_cast<unsigned *>(gate_for(hs, 0)) + 512;
             const unsigned epoch = next_slot_epoch(hs, slots);     // the lane's ONE counter, shared with k_head_bwd_dual32 (t4k_common.h)
+            static int l32d = -1; if (l32d < 0) { const char *e = getenv("T4K_GEMM_DUAL_L32"); l32d = e ? atoi(e) : 1; }
+            if (l32d && g.d_zero && N <= 512 && E0 <= 512) {             // coalesced operand blocks through LDS-DMA; a wave walks at most four 32-deep blocks
+                q1.Z = q2.Z = g.d_zero;
+                const dim3 gd((unsigned)(a1 + ar + a2));
+#define T4K_DL32(R_) do { static bool attr_done = false; \
+                    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_dual_l32<R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_done = true; } \
+                    T4K_LAUNCH(k_gemm_dual_l32<R_>, gd, dim3(256), (size_t)65536, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32); } while (0)
+                if (N > 256 || E0 > 256) T4K_DL32(true); else T4K_DL32(false);
+#undef T4K_DL32
+                return true;
+            }
             if (a1 + ar + a2 <= cap - 32) T4K_LAUNCH(k_gemm_dual32<8>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
             else                     T4K_LAUNCH(k_gemm_dual32<4>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
             return true;
@@ -1853,6 +2013,21 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             } else { defer->part = p.part; defer->nsplit = ns; defer->mn = mn; }
             const dim3 g32(gx, (unsigned)ns);
             static int nw8 = -1; if (nw8 < 0) { const char *e = getenv("T4K_GEMM_S32_NW8"); nw8 = e ? atoi(e) : 1; }
+            // operands through LDS-DMA blocks (k_gemm_l32) when every 16-byte DMA lane is aligned and whole: coalesced fetch instead of row gathers
+            static int l32 = -1; if (l32 < 0) { const char *e = getenv("T4K_GEMM_L32"); l32 = e ? atoi(e) : 1; }
+            if (l32 && st().d_zero && aligned16(A) && aligned16(B) && (akc ? K % 4 == 0 : M % 4 == 0) && (bkc ? K % 4 == 0 : N % 4 == 0)) {
+                p.Z = st().d_zero;
+                const int nblk = (kc + 31) / 32;
+                // waves per workgroup (= k-groups) and whether a wave walks more than two blocks (RST: blocks 2, 3 wait in registers)
+                const bool w8 = nblk > 16 || (nblk >= 6 && t32 * ns <= (long)st().cu_count);
+                const bool rst = nblk > (w8 ? 16 : 8);
+#define T4K_L32(A_, B_) do { if (w8) { if (rst) launch_l32<A_, B_, 8, true>(p, ep, fr, g32, hs2); else launch_l32<A_, B_, 8, false>(p, ep, fr, g32, hs2); } \
+                             else    { if (rst) launch_l32<A_, B_, 4, true>(p, ep, fr, g32, hs2); else launch_l32<A_, B_, 4, false>(p, ep, fr, g32, hs2); } } while (0)
+                if (akc && !bkc) T4K_L32(true, false); else if (akc) T4K_L32(true, true); else if (!bkc) T4K_L32(false, false); else T4K_L32(false, true);
+#undef T4K_L32
+                T4K_LAUNCH_CHECK();
+                return T4K_OK;
+            }
 #define T4K_S32(A_, B_) do { if (t32 * ns > 2L * st().cu_count) T4K_LAUNCH((k_gemm_s32<A_, B_, 4>), g32, dim3(256), 0, hs2, p, ep, fr); \
                              else if (nw8 && kc >= 384)          T4K_LAUNCH((k_gemm_s32<A_, B_, 8, 8>), g32, dim3(512), 0, hs2, p, ep, fr);   /* deep k per slab: 8 k-groups */ \
                              else                                T4K_LAUNCH((k_gemm_s32<A_, B_, 8>), g32, dim3(256), 0, hs2, p, ep, fr); } while (0)
