@@ -328,6 +328,123 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd_cols(const float *X, const
     }
 }
 
+// ---- thin heads (E0 <= 4 outputs, e.g. a discriminator's 256 -> 1 layer).  The kernels above give an OUTPUT to a lane: with one output
+// per row, 4 lanes of a wave work and each walks a 256-step dependent LDS chain (k_linsmall_fwd<16>: 10 us for 0.13 MFLOP).
+// Forward: a wave per batch row, the lanes split k (16-byte loads when the rows allow), xor-tree over the wave, lane e finishes output e.
+__global__ void __launch_bounds__(256) k_linthin_fwd(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ B,
+                                                     float *__restrict__ Y, int N, int E0, int E1, int vec, ActEpi oep) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float *xr = X + (long)n * E1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    if (vec) {
+        for (int k = lane * 4; k < E1; k += 256) {
+            const v4 x = *reinterpret_cast<const v4 *>(xr + k);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (e < E0) { const v4 w = *reinterpret_cast<const v4 *>(W + (long)e * E1 + k);
+                              acc[e] = fmaf(x[3], w[3], fmaf(x[2], w[2], fmaf(x[1], w[1], fmaf(x[0], w[0], acc[e])))); }
+            }
+        }
+    } else {
+        for (int k = lane; k < E1; k += 64) {
+            const float x = xr[k];
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (e < E0) acc[e] = fmaf(x, W[(long)e * E1 + k], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] += __shfl_xor(acc[e], off, 64);
+    if (lane < E0) {
+        float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+        v += B ? B[lane] : 0.f;
+        const long z = (long)n * E0 + lane;
+        Y[z] = v;
+        if (oep.layer) {
+            float u = 0.f;
+            if (oep.layer == T4K_L_DROPOUT) { uint64_t ob, os; rng_begin(oep.rng, ob, os); u = philox_u01_at(ob, os, z); }
+            float a, f; act_rt(oep.layer, v, u, oep.alpha, a, f); oep.F[z] = f; oep.A[z] = a;
+        }
+    }
+}
+// Backward: a workgroup owns RA batch rows and every column (thread = column c, c + 256).  Nothing it reads is written by another
+// workgroup - its rows of X become its rows of dX in place, its rows of `out` take `out - target` in place - so there is no arrival gate
+// (k_linsmall_bwd: the dX writers wait two agent-scope round trips for the dW readers).  What crosses workgroups is the batch sum:
+// each one leaves dW | dB partials of its rows in the workspace (agent-scope stores), takes a ticket, and the LAST one adds the partials
+// in row order into dW | dB (deterministic; nobody waits for anybody).  All loads of a thread go out before its first store.
+template <int RA>
+__global__ void __launch_bounds__(256) k_linthin_bwd(const float *X, const float *__restrict__ W, const float *DY, float *DX, float *DW, float *DB,
+                                                     int N, int E0, int E1, int train, int *ticket, float *part,
+                                                     const float *__restrict__ MASK, float *__restrict__ DXM,
+                                                     const float *__restrict__ TGT, float *DYW, float *DY2,
+                                                     const float *__restrict__ MASKB, float *__restrict__ DXMB) {
+    __shared__ float dys[RA * 4];
+    __shared__ int last_s;
+    const int tid = threadIdx.x, row0 = blockIdx.x * RA, nr = min(RA, N - row0);
+    const int c0 = tid, c1 = tid + 256;
+    const bool h0 = c0 < E1, h1 = c1 < E1;
+    float w0[4], w1[4], x0[RA], x1[RA], m0[RA], m1[RA], mb0[RA], mb1[RA];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { w0[e] = (e < E0 && h0) ? W[(long)e * E1 + c0] : 0.f; w1[e] = (e < E0 && h1) ? W[(long)e * E1 + c1] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < RA; r++) {
+        const long o = (long)(row0 + (r < nr ? r : 0)) * E1;
+        x0[r] = (train && h0) ? X[o + c0] : 0.f; x1[r] = (train && h1) ? X[o + c1] : 0.f;
+        m0[r] = (DXM && h0) ? MASK[o + c0] : 0.f; m1[r] = (DXM && h1) ? MASK[o + c1] : 0.f;
+        mb0[r] = (DXMB && h0) ? MASKB[o + c0] : 0.f; mb1[r] = (DXMB && h1) ? MASKB[o + c1] : 0.f;
+    }
+    float dyv = 0.f;
+    if (tid < RA * E0) { const int r = tid / E0; if (r < nr) { const long o = (long)row0 * E0 + tid; dyv = DY[o] - (TGT ? TGT[o] : 0.f); } dys[(tid / E0) * 4 + tid % E0] = dyv; }
+    __syncthreads();
+    if (TGT && tid < nr * E0) { const long o = (long)row0 * E0 + tid; DYW[o] = dyv; if (DY2) DY2[o] = dyv; }     // `out -= target` (backprop.cu:152-160), these rows are nobody else's
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < RA; r++) {
+        if (r >= nr) break;
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) if (e < E0) { const float dy = dys[r * 4 + e]; d0 = fmaf(dy, w0[e], d0); d1 = fmaf(dy, w1[e], d1); a0[e] = fmaf(dy, x0[r], a0[e]); a1[e] = fmaf(dy, x1[r], a1[e]); }
+        if (DX) {
+            const long o = (long)(row0 + r) * E1;
+            if (h0) { DX[o + c0] = d0; if (DXM) { const float g1 = d0 * m0[r]; DXM[o + c0] = g1; if (DXMB) DXMB[o + c0] = g1 * mb0[r]; } }
+            if (h1) { DX[o + c1] = d1; if (DXM) { const float g1 = d1 * m1[r]; DXM[o + c1] = g1; if (DXMB) DXMB[o + c1] = g1 * mb1[r]; } }
+        }
+    }
+    if (!train) return;
+    // partials of this row group: [wg][E0][E1] then [wg][E0] bias sums behind all of them
+    const int G = (int)gridDim.x;
+    float *pw = part + (long)blockIdx.x * E0 * E1, *pb = part + (long)G * E0 * E1 + (long)blockIdx.x * E0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (e < E0) {
+        if (h0) __hip_atomic_store(pw + (long)e * E1 + c0, a0[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h1) __hip_atomic_store(pw + (long)e * E1 + c1, a1[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < E0) { float b = 0.f; for (int r = 0; r < nr; r++) b += dys[r * 4 + tid]; __hip_atomic_store(pb + tid, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) last_s = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+    __syncthreads();
+    if (!last_s) return;
+    if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // re-armed for the next launch on this stream
+    for (int i = tid; i < E0 * E1; i += 256) {                  // every partial's load is independent: one round trip, then the sum in row order
+        float s_ = 0.f;
+        int g = 0;
+        for (; g + 8 <= G; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = __hip_atomic_load(part + (long)(g + j) * E0 * E1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s_ += v[j];
+        }
+        for (; g < G; g++) s_ += __hip_atomic_load(part + (long)g * E0 * E1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DW[i] += s_;
+    }
+    if (tid < E0) { float b = 0.f; for (int g = 0; g < G; g++) b += __hip_atomic_load(part + (long)G * E0 * E1 + (long)g * E0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); DB[tid] += b; }
+}
+
 } // namespace
 
 namespace t4k {
@@ -341,6 +458,12 @@ bool linear_small_ok(int E0, int E1) {
 int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xfp, const ActEpi *oepp) {
     const ActEpi oep = oepp ? *oepp : ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
     XFold xf; if (xfp) xf = *xfp; else { xf.part = nullptr; xf.nsplit = 0; xf.mn = 0; xf.bias = nullptr; xf.Y = nullptr; xf.ep = ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}}; }
+    static int thin = -1; if (thin < 0) { const char *e = getenv("T4K_LINTHIN"); thin = e ? atoi(e) : 1; }
+    if (thin && !xfp && !P && E0 <= 4 && N > 0) {             // thin head: a wave per row
+        const int vec = (E1 % 4 == 0) && aligned16(X) && aligned16(W);
+        T4K_LAUNCH(k_linthin_fwd, dim3((N + 3) / 4), dim3(256), 0, hs, X, W, B, Y, N, E0, E1, vec, oep);
+        return T4K_OK;
+    }
     const int LG = E0 <= 16 ? 16 : (E0 <= 32 ? 32 : 64);
     const int RPB = (xfp ? 1 : 4) * (64 / LG);
     const size_t lds = sizeof(float) * (size_t)(E0 * (E1 + 1) + RPB * E1);
@@ -369,6 +492,19 @@ int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, f
 bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX, float *DW, float *DB,
                       int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM, const float *TGT, float *DY2,
                       const float *MASKB, float *DXMB) {
+    {   // thin head (E0 <= 4): row-group workgroups, no arrival gate, the last one folds the dW | dB partials
+        static int thin = -1; if (thin < 0) { const char *e = getenv("T4K_LINTHIN"); thin = e ? atoi(e) : 1; }
+        constexpr int RA = 4;
+        const int G = (N + RA - 1) / RA;
+        const bool tr = train && DW;
+        int *tk = gate_for(hs, 2);                               // ints 8.. of the stream's gate block: the ticket (zero between launches)
+        float *part = ws_for(hs) ? ws_for(hs) + st().ws_bytes / 8 : nullptr;      // second half of the stream's workspace (transient column-sum partials; the first half may hold a conv stack's deferred dF partials)
+        if (thin && E0 <= 4 && E1 <= 512 && N >= 1 && (DX || tr) && (!tr || (DB && tk && part && (size_t)(G + 1) * E0 * E1 * sizeof(float) <= st().ws_bytes / 2))) {
+            T4K_LAUNCH(k_linthin_bwd<RA>, dim3(G), dim3(256), 0, hs, X, W, DY, DX, DW, DB, N, E0, E1, tr ? 1 : 0, tk, part,
+                       MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
+            return true;
+        }
+    }
     {   // column-sliced kernel: batches that fit LDS whole (N x (E0 + 16) floats), every output of dW in one thread (E0 x 16 <= 256)
         static int cols_on = -1; if (cols_on < 0) { const char *e = getenv("T4K_LINSMALL_COLS"); cols_on = e ? atoi(e) : 1; }
         const size_t ldsc = sizeof(float) * ((size_t)N * E0 + (size_t)E0 * LSC_CW + (size_t)N * LSC_CW + 256);
