@@ -492,7 +492,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     };
     // gate_mode 1 with per-wave slots (gate_n <= 128 reader workgroups): a wave reports as soon as its LAST operand fragments sit in
     // registers, in front of its last MFMA batch - the writers' wait then overlaps that batch, the LDS reduction and the epilogue
-    const bool early = gate_mode == 1 && gate_n <= 128;
+    const bool early = gate_mode == 1 && gate_n <= 128 && NW == 4;       // per-wave slots: 4 per reader workgroup
     auto arrive = [&]() __attribute__((always_inline)) {
         if (!early) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -639,7 +639,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         if (w == 0) {
             // only the readers of the columns this tile overwrites matter: dW tiles (e0t, tn), e0t = 0 .. gate_n / tiles_n - 1 (both GEMMs
             // have the same column tiling), each with 4 per-wave slots when those fit the 512-int block (gate_n <= 128)
-            const int per = gate_n <= 128 ? 4 : 1, rows = gate_n / p.tiles_n, nslot = rows * per;
+            const int per = (gate_n <= 128 && NW == 4) ? 4 : 1, rows = gate_n / p.tiles_n, nslot = rows * per;
             for (int spin_it = 0;; spin_it++) {
                 if (spin_it > T4K_SPIN_MAX) { if (lane == 0 && g_spin_err_dev) __hip_atomic_store(g_spin_err_dev, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // bounded: see t4k_common.h
                 bool ok = true;
@@ -738,11 +738,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 
 // fine here although the dX writers spin on the dW readers' slots: a writer's readers all have LOWER workgroup ids, each XCD dispatches its
 // workgroups in id order and a reader never waits - so every reader is running or done before the first writer of its XCD takes a slot
 // (the same dispatch-order argument as the conv stack's band exchange; the wait is bounded and reported anyway).
-template <bool RST>
-__global__ void __launch_bounds__(256) k_gemm_dual_l32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, MaskChain mc) {
+template <bool RST, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) k_gemm_dual_l32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, MaskChain mc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, 4, 4, false, NoPro, true, RST>(p1, blockIdx.x, lds, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
-    else                       gemm_s32_body<true, false, 4, 4, false, NoPro, true, RST>(p2, (int)blockIdx.x - nb1, lds, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
+    if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, 4, NW, false, NoPro, true, RST>(p1, blockIdx.x, lds, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
+    else                       gemm_s32_body<true, false, 4, NW, false, NoPro, true, RST>(p2, (int)blockIdx.x - nb1, lds, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
 }
 
 // ---- classifier-head backward + the backward of the linear layer in front of it, ONE launch (t4k_mlp_head_bwd).
@@ -1911,13 +1911,14 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             unsigned *slots = reinterpret_cast<unsigned *>(gate_for(hs, 0)) + 512;
             const unsigned epoch = next_slot_epoch(hs, slots);     // the lane's ONE counter, shared with k_head_bwd_dual32 (t4k_common.h)
             static int l32d = -1; if (l32d < 0) { const char *e = getenv("T4K_GEMM_DUAL_L32"); l32d = e ? atoi(e) : 1; }
-            if (l32d && g.d_zero && N <= 512 && E0 <= 512) {             // coalesced operand blocks through LDS-DMA; a wave walks at most four 32-deep blocks
+            if (l32d && g.d_zero && N <= 1024 && E0 <= 1024 && (a1 > 128 || (N <= 512 && E0 <= 512))) {   // coalesced operand blocks through LDS-DMA; a wave walks at most four 32-deep blocks
                 q1.Z = q2.Z = g.d_zero;
                 const dim3 gd((unsigned)(a1 + ar + a2));
-#define T4K_DL32(R_) do { static bool attr_done = false; \
-                    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_dual_l32<R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_done = true; } \
-                    T4K_LAUNCH(k_gemm_dual_l32<R_>, gd, dim3(256), (size_t)65536, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32); } while (0)
-                if (N > 256 || E0 > 256) T4K_DL32(true); else T4K_DL32(false);
+#define T4K_DL32(R_, W_) do { static bool attr_done = false; \
+                    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_dual_l32<R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, W_ * 16384); attr_done = true; } \
+                    T4K_LAUNCH((k_gemm_dual_l32<R_, W_>), gd, dim3(64 * W_), (size_t)W_ * 16384, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32); } while (0)
+                if (N > 512 || E0 > 512) T4K_DL32(true, 8);      // deep K: 8 k-groups (per-workgroup arrival slots: a1 > 128)
+                else if (N > 256 || E0 > 256) T4K_DL32(true, 4); else T4K_DL32(false, 4);
 #undef T4K_DL32
                 return true;
             }

@@ -431,18 +431,89 @@ __global__ void __launch_bounds__(256) k_linthin_bwd(const float *X, const float
     if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // re-armed for the next launch on this stream
     for (int i = tid; i < E0 * E1; i += 256) {                  // every partial's load is independent: one round trip, then the sum in row order
         float s_ = 0.f;
-        int g = 0;
-        for (; g + 8 <= G; g += 8) {
-            float v[8];
+        for (int g = 0; g < G; g += 32) {                       // 32 row groups per trip (N = 256: all of them)
+            float v[32];
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = __hip_atomic_load(part + (long)(g + j) * E0 * E1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < 32; j++) v[j] = g + j < G ? __hip_atomic_load(part + (long)(g + j) * E0 * E1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; j++) s_ += v[j];
+            for (int j = 0; j < 32; j++) s_ += v[j];
         }
-        for (; g < G; g++) s_ += __hip_atomic_load(part + (long)g * E0 * E1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         DW[i] += s_;
     }
     if (tid < E0) { float b = 0.f; for (int g = 0; g < G; g++) b += __hip_atomic_load(part + (long)G * E0 * E1 + (long)g * E0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); DB[tid] += b; }
+}
+
+// Trained thin head: a workgroup owns CW columns of the layer input and ALL batch rows (thread = column x row group, rows interleaved so a
+// wave's load covers whole CW-float runs).  dW[:, c] and dX[:, c] need nothing from other columns, the thread that loaded X[n, c] is the
+// one that overwrites it with dX[n, c] - no arrival gate, no partials in memory, no ticket on the critical path (the row-group kernel
+// above pays three dependent agent-scope round trips for its fold: 11 us; it stays for frozen layers, where nothing crosses workgroups).
+// The one shared store is the in-place `out -= target`: every workgroup reads all of out / target, so the LAST one to have staged them
+// (a ticket taken after the staging barrier, looked at when the rest of the work is done) stores the difference.
+template <int CW>
+__global__ void __launch_bounds__(256) k_linthin_bwd_cols(const float *X, const float *__restrict__ W, const float *DY, float *DX, float *DW, float *DB,
+                                                          int N, int E0, int E1, int *ticket,
+                                                          const float *__restrict__ MASK, float *__restrict__ DXM,
+                                                          const float *__restrict__ TGT, float *DYW, float *DY2,
+                                                          const float *__restrict__ MASKB, float *__restrict__ DXMB) {
+    extern __shared__ float sm[];
+    constexpr int NG = 256 / CW, RPT = 8;
+    float *dys = sm, *red = sm + N * 4;                         // dY [N][4]; partial dW [NG][CW][4]
+    __shared__ int tk_s;
+    const int tid = threadIdx.x, c = tid % CW, g = tid / CW, col = blockIdx.x * CW + c;
+    const bool hc = col < E1;
+    float w[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) w[e] = (e < E0 && hc) ? W[(long)e * E1 + col] : 0.f;
+    float xv[RPT], mv[RPT], mbv[RPT];
+    auto loads = [&](int nb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            const int n = nb + g + NG * i; const bool ok = hc && n < N; const long o = (long)(ok ? n : 0) * E1 + (hc ? col : 0);
+            xv[i] = ok ? X[o] : 0.f; mv[i] = (ok && DXM) ? MASK[o] : 0.f; mbv[i] = (ok && DXMB) ? MASKB[o] : 0.f;
+        }
+    };
+    loads(0);                                                    // in flight while dY is staged
+    for (int i = tid; i < N * E0; i += 256) { const float d = DY[i] - (TGT ? TGT[i] : 0.f); dys[(i / E0) * 4 + i % E0] = d; }
+    __syncthreads();
+    if (TGT && tid == 0) tk_s = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < N; nb += NG * RPT) {
+        if (nb) loads(nb);
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            const int n = nb + g + NG * i;
+            if (n >= N || !hc) continue;
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (e < E0) { const float dy = dys[n * 4 + e]; d = fmaf(dy, w[e], d); acc[e] = fmaf(dy, xv[i], acc[e]); }
+            if (DX) {
+                const long o = (long)n * E1 + col;
+                DX[o] = d;
+                if (DXM) { const float g1 = d * mv[i]; DXM[o] = g1; if (DXMB) DXMB[o] = g1 * mbv[i]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[(g * CW + c) * 4 + e] = acc[e];
+    __syncthreads();
+    if (tid < CW * E0) {                                         // row groups in order: deterministic
+        const int cc = tid % CW, e = tid / CW, oc = blockIdx.x * CW + cc;
+        float a = 0.f;
+        for (int gg = 0; gg < NG; gg++) a += red[(gg * CW + cc) * 4 + e];
+        if (oc < E1) DW[(long)e * E1 + oc] += a;
+    } else if (blockIdx.x == 0 && tid >= 192 && tid - 192 < E0) {      // dB[e] = sum_n dY[n, e] (k_dlinear_db nmath.cu:274-280)
+        const int e = tid - 192;
+        float b = 0.f;
+        for (int n = 0; n < N; n++) b += dys[n * 4 + e];
+        DB[e] += b;
+    }
+    if (TGT) {
+        __syncthreads();
+        if (tk_s == (int)gridDim.x - 1) {                        // everybody has staged out / target: the difference lands in place
+            if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = tid; i < N * E0; i += 256) { const float d = dys[(i / E0) * 4 + i % E0]; DYW[i] = d; if (DY2) DY2[i] = d; }
+        }
+    }
 }
 
 } // namespace
@@ -494,11 +565,18 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
                       const float *MASKB, float *DXMB) {
     {   // thin head (E0 <= 4): row-group workgroups, no arrival gate, the last one folds the dW | dB partials
         static int thin = -1; if (thin < 0) { const char *e = getenv("T4K_LINTHIN"); thin = e ? atoi(e) : 1; }
-        constexpr int RA = 4;
+        constexpr int RA = 8;
         const int G = (N + RA - 1) / RA;
         const bool tr = train && DW;
         int *tk = gate_for(hs, 2);                               // ints 8.. of the stream's gate block: the ticket (zero between launches)
         float *part = ws_for(hs) ? ws_for(hs) + st().ws_bytes / 8 : nullptr;      // second half of the stream's workspace (transient column-sum partials; the first half may hold a conv stack's deferred dF partials)
+        static int tcw = -1; if (tcw < 0) { const char *e = getenv("T4K_LINTHIN_CW"); tcw = e ? atoi(e) : 8; }
+        if (thin && tr && tcw && E0 <= 4 && N >= 1 && N <= 1024 && DB && (!TGT || tk) && E1 >= 8) {          // trained: column stripes, nothing crosses workgroups
+            const size_t ldsb = sizeof(float) * ((size_t)N * 4 + 256 * 4);
+            if (tcw == 16) T4K_LAUNCH(k_linthin_bwd_cols<16>, dim3((E1 + 15) / 16), dim3(256), ldsb, hs, X, W, DY, DX, DW, DB, N, E0, E1, tk, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
+            else           T4K_LAUNCH(k_linthin_bwd_cols<8>,  dim3((E1 + 7) / 8),   dim3(256), ldsb, hs, X, W, DY, DX, DW, DB, N, E0, E1, tk, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
+            return true;
+        }
         if (thin && E0 <= 4 && E1 <= 512 && N >= 1 && (DX || tr) && (!tr || (DB && tk && part && (size_t)(G + 1) * E0 * E1 * sizeof(float) <= st().ws_bytes / 2))) {
             T4K_LAUNCH(k_linthin_bwd<RA>, dim3(G), dim3(256), 0, hs, X, W, DY, DX, DW, DB, N, E0, E1, tr ? 1 : 0, tk, part,
                        MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
