@@ -458,6 +458,11 @@ int t4k_opt_step(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *ta
                  float lr, float b1, float b2, float wd, t4k_stream_t s);
 /* the data-parallel form: with the one-shot exchange connected (t4k_xchg_connect, world > 1) every gradient element is summed over all
  * ranks inside the same launch (slab / slab_n: the model's gradient slab, holding every DG of the table); otherwise t4k_opt_step. */
+/* One-shot request: the NEXT t4k_opt_chunked / t4k_opt_step / t4k_opt_step_dp on stream order also stores the PRE-update values of the
+ * parameter tensor G (a record's G pointer) into G_PREV - the copy rides in the update launch.  Model::backprop defers dX of a first
+ * linear layer (`in = dX`, backprop.cu:240, is read by no training loop) and needs the weights of that backward should a word ask for
+ * it after the step.  G == NULL cancels a pending request. */
+int t4k_opt_snapshot(const float *G, float *G_PREV);
 int t4k_opt_step_dp(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
                     float lr, float b1, float b2, float wd, float *slab, long slab_n, t4k_stream_t s);
 

@@ -253,9 +253,12 @@ int t4k_conv2d_block_fwd(const float *I, float *IC, float *O, const float *F, co
     int r = t4k_conv2d_fwd2(I, IC, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, st); if (r) return r;
     return t4k_poolblock_fwd(O, blk, N, H0, W0, H0 / blk->KS, W0 / blk->KS, C0, st);
 }
+static const float *g_keep_src = nullptr; static float *g_keep_dst = nullptr;
+int t4k_opt_snapshot(const float *G, float *G_PREV) { g_keep_src = G; g_keep_dst = G ? G_PREV : nullptr; return T4K_OK; }
 int t4k_opt_multi(int kind, const t4k_param_rec *tab, int nt, long, float lr, float b1, float b2, float wd, t4k_stream_t) {
     for (int i = 0; i < nt; i++) {
         const t4k_param_rec &r = tab[i];
+        if (g_keep_src && r.G == g_keep_src) { memcpy(g_keep_dst, r.G, sizeof(float) * (size_t)r.n); g_keep_src = nullptr; g_keep_dst = nullptr; }
         if (kind == 0) t4o_sgd(r.G, r.DG, r.M, r.Nw, lr, b1, r.n);
         else if (kind == 1) t4o_adam(r.G, r.DG, r.M, r.V, lr, b1, b2, r.n);
         else t4o_adamw(r.G, r.DG, r.M, r.V, lr, b1, b2, wd, r.n);

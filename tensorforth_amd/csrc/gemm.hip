@@ -477,6 +477,18 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
 #pragma unroll
         for (int q = 0; q < QN; q++) { const int r = QN * w + q, gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h; if (gm < M && gn < N) oprev[q] = p.O[(long)gm * N + gn]; }
     }
+    // every read-only operand of the epilogue is requested here, with the K loop's first loads: fetched behind the reduction barrier, the
+    // bias and the masks of the chain would each add a memory round trip to a launch that is little else
+    float bias_v = 0.f, mk1[QN], mk2[QN];
+    if (p.bias && p.nsplit == 1 && gn < N) bias_v = p.bias[gn];
+#pragma unroll
+    for (int q = 0; q < QN; q++) {
+        mk1[q] = 0.f; mk2[q] = 0.f;
+        if (mc && mc->d1 && p.nsplit == 1) {
+            const int r = QN * w + q, gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (gm < M && gn < N) { const long z = (long)gm * N + gn; mk1[q] = mc->m1[z]; if (mc->d2) mk2[q] = mc->m2[z]; }
+        }
+    }
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -668,9 +680,9 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
             if (p.nsplit > 1) { p.part[(long)by * M * N + z] = v; continue; }       // split-K slab: the consumer folds (XFold / k_splitk_fold)
             float o = v * alpha;
             if (beta != 0.f) o += oprev[q] * beta;
-            if (p.bias) o += p.bias[gn];
+            if (p.bias) o += bias_v;
             p.O[z] = o;
-            if (mc && mc->d1) { const float g1 = o * mc->m1[z]; mc->d1[z] = g1; if (mc->d2) mc->d2[z] = g1 * mc->m2[z]; }
+            if (mc && mc->d1) { const float g1 = o * mk1[q]; mc->d1[z] = g1; if (mc->d2) mc->d2[z] = g1 * mk2[q]; }
             if (ep1 && ep1->layer) {                                              // element-wise layer(s) behind a linear layer: as k_splitk_fold
                 const bool d1 = ep1->layer == T4K_L_DROPOUT, d2 = fe && fe->ep2.layer == T4K_L_DROPOUT;
                 float u = 0.f;

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(BLK) k_opt_multi(int kind, const t4k_param_rec
 // the same step with the grid sized to the parameters: workgroup b owns 1024-element chunk b of the concatenation of all tensors; the
 // record's `pad` field holds the tensor's first chunk (host-filled prefix), found by a short scan of the table (uniform -> scalar loads)
 __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_rec *__restrict__ tab, int nt,
-                                                     float lr, float b1, float b2, float wd) {
+                                                     float lr, float b1, float b2, float wd, const float *keep_src, float *keep_dst) {   // keep_*: t4k_opt_snapshot
     int i = 0;
     while (i + 1 < nt && (int)blockIdx.x >= tab[i + 1].pad) i++;
     const t4k_param_rec r = tab[i];
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_r
         const long j = j0 + q * BLK + threadIdx.x;
         if (j >= r.n) break;
         float g = r.G[j], dg = r.DG[j];
+        if (r.G == keep_src) keep_dst[j] = g;                   // the pre-update value of a snapshotted tensor
         if (kind == 0) {
             float m = mom ? r.M[j] : 0.f;
             sgd1(g, dg, m, r.Nw, lr, b1, mom);
@@ -104,8 +105,10 @@ __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_r
 // tensors the fold workgroups handle alone (`skip`: bit i = table record i).  One launch instead of k_cs_fold + k_opt_chunked; the
 // result is bit-identical to the two launches (dg = DG + fold either way).
 struct FoldRecs { t4k_param_rec r[6]; };                   // the table record behind each fold segment
-__device__ __forceinline__ void opt1(int kind, const t4k_param_rec &r, long j, float dg, float lr, float b1, float b2, float wd, bool mom) {
+__device__ __forceinline__ void opt1(int kind, const t4k_param_rec &r, long j, float dg, float lr, float b1, float b2, float wd, bool mom,
+                                     const float *keep_src = nullptr, float *keep_dst = nullptr) {
     float g = r.G[j];
+    if (keep_src && r.G == keep_src) keep_dst[j] = g;
     if (kind == 0) {
         float m = mom ? r.M[j] : 0.f;
         sgd1(g, dg, m, r.Nw, lr, b1, mom);
@@ -124,7 +127,8 @@ T4K_SPIN_DECL
 __global__ void k_opt_set_err(int *p) { g_spin_err_dev = p; }
 template <bool XCHG>
 __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec *__restrict__ tab, int nt, float lr, float b1, float b2, float wd,
-                                                   const CsFoldArgs fa, const FoldRecs fr, int nfold, unsigned long long skip, const float *slab, const XchgDev xd) {
+                                                   const CsFoldArgs fa, const FoldRecs fr, int nfold, unsigned long long skip, const float *slab, const XchgDev xd,
+                                                   const float *keep_src, float *keep_dst) {
     __shared__ CsFoldSm sm;
     const bool mom = !(fabsf(b1) < DU_EPS);
     if ((int)blockIdx.x < nfold) {
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec
         if (cs_fold16(fa, blockIdx.x, sm, v, q, k)) {
             float dg = fa.seg[q].dst[k] + v;
             if (XCHG) { const long z = (long)(fa.seg[q].dst - slab) + k; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev); }
-            opt1(kind, fr.r[q], k, dg, lr, b1, b2, wd, mom);
+            opt1(kind, fr.r[q], k, dg, lr, b1, b2, wd, mom, keep_src, keep_dst);
         }
         return;
     }
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec
     if (j < r.n) {
         float dg = r.DG[j];
         if (XCHG) { const long z = (long)(r.DG - slab) + j; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev); }
-        opt1(kind, r, j, dg, lr, b1, b2, wd, mom);
+        opt1(kind, r, j, dg, lr, b1, b2, wd, mom, keep_src, keep_dst);
     }
 }
 
@@ -232,11 +236,19 @@ int t4k_opt_multi(int kind, const t4k_param_rec *tab_dev, int n_tensors, long ma
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
+// one pending snapshot request (t4k_opt_snapshot): consumed by the next chunked / step launch
+static const float *g_keep_src = nullptr; static float *g_keep_dst = nullptr;
+int t4k_opt_snapshot(const float *G, float *G_PREV) {
+    if (G && !G_PREV) return fail(T4K_ERR_ARG, "t4k_opt_snapshot: null destination");
+    g_keep_src = G; g_keep_dst = G ? G_PREV : nullptr;
+    return T4K_OK;
+}
 int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n_chunks,
                     float lr, float b1, float b2, float wd, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n_tensors <= 0 || n_chunks <= 0) return T4K_OK;
     if (!tab_dev || kind < 0 || kind > 2) return fail(T4K_ERR_ARG, "t4k_opt_chunked: bad argument");
-    T4K_LAUNCH(k_opt_chunked, dim3((unsigned)n_chunks), dim3(BLK), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd);
+    const float *ks = g_keep_src; float *kd = g_keep_dst; g_keep_src = nullptr; g_keep_dst = nullptr;
+    T4K_LAUNCH(k_opt_chunked, dim3((unsigned)n_chunks), dim3(BLK), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, ks, kd);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
 
@@ -274,12 +286,13 @@ static int opt_step_impl(int kind, const t4k_param_rec *tab_dev, const t4k_param
     }
     static bool err_set = false;
     if (!err_set && g.spin_err) { T4K_LAUNCH(k_opt_set_err, dim3(1), dim3(1), 0, S(s), g.spin_err); err_set = true; }
+    const float *ks = g_keep_src; float *kd = g_keep_dst; g_keep_src = nullptr; g_keep_dst = nullptr;
     if (dp) {
         const XchgDev xd = xchg_begin(false);
-        T4K_LAUNCH(k_opt_step<true>, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, fa, fr, nfold, skip, slab, xd);
+        T4K_LAUNCH(k_opt_step<true>, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, fa, fr, nfold, skip, slab, xd, ks, kd);
     } else {
         XchgDev xd; memset((void *)&xd, 0, sizeof(xd));
-        T4K_LAUNCH(k_opt_step<false>, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, fa, fr, nfold, skip, slab, xd);
+        T4K_LAUNCH(k_opt_step<false>, dim3((unsigned)(nfold + n_chunks)), dim3(1024), 0, S(s), kind, tab_dev, n_tensors, lr, b1, b2, wd, fa, fr, nfold, skip, slab, xd, ks, kd);
     }
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }

@@ -113,13 +113,29 @@ bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : fa
 // two tensors carry a mark; the first word that resolves one of them (Store::du2obj: `0 n@`, `0 nn.ex`, ten4_fetch, a chained backprop ...)
 // has it produced from the dO and the filter copy that backward left.  The next forward overwrites layer 0 and ends the offer (after it
 // `0 nn.ex` would show an EARLIER backward's dX - the one observable difference; T4_LAZY_DX0=0 restores the eager store).
+// A first LINEAR layer (an MLP: the GAN discriminator's 784 -> 512 layer is a third of its backward launch) takes the same offer: the
+// backward computes dW | dB only; dX0 = dY W is produced on demand from the dY the backward left and the weights OF THAT BACKWARD - the
+// weight tensor and the tensor holding dY carry the mark as well, and an optimizer step in between snapshots the old weights inside its
+// own launch (t4k_opt_snapshot).
 void Model::clear_dx0_marks() {
     if (!dx0_stale_) return;
     dx0_stale_ = false;
     if (!layer.empty()) { at(0).stale_owner = nullptr; if (at(0).grad[4]) at(0).grad[4]->stale_owner = nullptr; }
+    if (dx0_lin_) {
+        if (!layer.empty() && at(0).grad[0]) at(0).grad[0]->stale_owner = nullptr;
+        if (dx0_dy_t_) dx0_dy_t_->stale_owner = nullptr;
+        dx0_lin_ = false; w0_saved_ = false; dx0_dy_ = nullptr; dx0_dy_t_ = nullptr;
+    }
 }
 void Model::materialize_dx0() {
     if (!dx0_stale_) return;
+    if (dx0_lin_) {
+        Tensor &in = at(0), &o = at(1);
+        const float *w = w0_saved_ ? w0_save_->data : in.grad[0]->data, *dy = dx0_dy_;
+        clear_dx0_marks();
+        chk(t4k_linear_bwd(in.data, w, dy, in.data, nullptr, nullptr, in.N(), (int)o.HWC(), (int)in.HWC(), 0, stream()), "nn#blinear dX0");
+        return;
+    }
     clear_dx0_marks();
     t4k_conv_stage stg[3]; int ops = 0;
     if (stack_at(0, stg, ops) > 0) chk(t4k_conv_stack_dx0(stg, at(0).N(), stream()), "nn#bstack dX0");
@@ -601,6 +617,7 @@ void Model::dp_finish() {                                // before the update: r
     dp_done_lo_ = dp_pend_lo_ = -1; dp_mixed_ = false;
 }
 void Model::run_backward(Tensor &tgt) {
+    if (dx0_stale_ && dx0_lin_) materialize_dx0();      // backprop twice without a forward: the layer tensors must hold what the reference's would
     dp_bn_mode(train);
     dp_begin_backward();
     Tensor &out = at(-1);
@@ -785,6 +802,18 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
             }
             if (tg) chk(t4k_loss_linear_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, in.data, nullptr, nullptr,
                                         in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#bprep+blinear");
+            else if (i == 0 && train && use_lazy_dx0 && fused && !capturing_ && !use_graphs && in.grad[2] && in.grad[3] && (long)E0 * E1 >= 65536) {
+                // the net's first layer: nobody reads dX0 in a training loop - dW | dB now, dX0 = dY W when a word asks (materialize_dx0)
+                Tensor *holder = nullptr;
+                for (int k = 1; k < (int)layer.size() && !holder; k++) if (at(k).data == dy) holder = &at(k);
+                if (holder) {
+                    chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, nullptr, in.grad[2]->data, in.grad[3]->data, N, E0, E1, 1, s), "nn#blinear dW");
+                    dx0_stale_ = true; dx0_lin_ = true; w0_saved_ = false; dx0_dy_ = dy; dx0_dy_t_ = holder;
+                    in.stale_owner = this; in.grad[0]->stale_owner = this; holder->stale_owner = this;
+                    return in.data;
+                }
+                chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, in.data, in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#blinear");
+            }
             else chk(t4k_linear_bwd(in.data, in.grad[0]->data, dy, in.data, in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#blinear");
             return in.data;
         }
@@ -857,6 +886,11 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     // data parallel: every rank holds a shard of the batch; SUM the gradient slab (raw batch sums, quirk a-19) in-order
     // on the VM stream right before the update, so N ranks x batch B reproduce one rank x batch N*B
     dp_finish();
+    if (dx0_stale_ && dx0_lin_ && !w0_saved_) {          // a deferred dX0 = dY W needs the weights of its backward: the update launch leaves them in w0_save_
+        Tensor &w0 = *at(0).grad[0];
+        if (!w0_save_) w0_save_ = &T4(w0.N(), w0.H(), w0.W(), w0.C());
+        t4k_opt_snapshot(w0.data, w0_save_->data); w0_saved_ = true;
+    }
     if (!replay(g_opt_, tab_dev, (int)op, p)) {
         const bool cap = capturing_;
         if (dp_in_opt_) chk(t4k_opt_step_dp(kind, (const t4k_param_rec *)tab_dev, tab_host_.data(), tab_n, tab_chunks, lr, b1, b2, wd, gslab->data, (long)gslab->numel, stream()), nm);
@@ -940,6 +974,7 @@ void Model::free_all() {
     for (Tensor *t : gx_) if (t) Store::get().free(*t);
     gx_.clear();
     if (gslab) { Store::get().free(*gslab); gslab = nullptr; }
+    if (w0_save_) { Store::get().free(*w0_save_); w0_save_ = nullptr; }
     for (int i = 0; i + 1 < (int)layer.size(); i++) if (at(i).grad_fn == T4K_L_CONV) t4k_conv_stack_release(at(i + 1).data);   // what a stack forward saved for its banded backward
     for (int i = (int)layer.size() - 1; i >= 0; i--) Store::get().free(*layer[i]);
     layer.clear();

@@ -303,6 +303,12 @@ private:
     static bool use_stack;                     // T4_STACK=0: no sample-resident conv stacks (csrc/conv_stack.hip)
     static bool use_lazy_dx0;                  // T4_LAZY_DX0=0: a conv stack's backward always computes the first layer's dX (default: on demand, materialize_dx0)
     bool dx0_stale_ = false;
+    // ... of a first LINEAR layer (dX0 = dY W, backprop.cu:240): the backward runs dW | dB only and remembers where dY lives; the weight
+    // tensor and the tensor holding dY carry the mark too (a word that could change either produces dX0 first), and an optimizer step in
+    // between leaves the pre-update weights in w0_save_ (t4k_opt_snapshot: the copy rides in the update launch)
+    bool dx0_lin_ = false, w0_saved_ = false;
+    const float *dx0_dy_ = nullptr;
+    Tensor *dx0_dy_t_ = nullptr, *w0_save_ = nullptr;
     bool dp_in_opt_ = false;                   // this optimizer call sums the gradient slab over the ranks itself (one-shot peer exchange, t4k_opt_step_dp)
     void clear_dx0_marks();
     static bool use_opt_fold;                  // T4_OPT_FOLD=0: the conv stack's dF | dB partial fold as a launch of its own (default: inside the optimizer launch, t4k_opt_step)

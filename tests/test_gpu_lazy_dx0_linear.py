@@ -1,0 +1,48 @@
+"""The deferred dX of a first LINEAR layer (host/model.cpp: bstep i == 0, materialize_dx0, t4k_opt_snapshot).  `in = dX`
+(/root/reference/src/nn/backprop.cu:240) leaves dX0 = dY W in layer 0; the product computes it when a word asks.  Whatever the script does
+between the backward and the read - nothing, an optimizer step (the weights of the BACKWARD must be used), a second backward, a look at the
+weight tensor - layer 0 must print what the oracle VM (eager, CPU) prints, and T4_LAZY_DX0=0 must change nothing."""
+import numpy as np
+import pytest
+
+from vm_util import TEN4, TEN4_ORACLE, run_vm, tokens
+
+pytestmark = pytest.mark.gpu
+
+NET = """0 trace
+64 constant N
+N 16 16 1 nn.model 256 linear 0.2 leakyrelu 0.3 dropout 64 linear 0.2 leakyrelu 1 linear sigmoid constant D
+N 16 16 1 tensor rand constant x
+N 1 1 1 tensor ones constant T
+: show ( -- ) D 0 n@ dup sum . dup max . min . drop ;
+"""
+CASES = {
+    "read-after-backprop": "D x forward T backprop show",
+    "read-after-adam": "D x forward T backprop 0.001 0.5 nn.adam show",
+    "read-after-sgd": "D x forward T backprop 0.01 0.0 nn.sgd show",
+    "two-backprops-then-adam": "D x forward T backprop x forward T backprop 0.001 0.5 nn.adam show",
+    "second-step-keeps-first-offer-closed": "D x forward T backprop 0.001 0.5 nn.adam x forward T backprop 0.001 0.5 nn.adam show",
+    "weights-inspected-first": "D x forward T backprop D 0 nn.w sum . drop 0.001 0.5 nn.adam show",
+    "frozen": "D 0 trainable x forward T backprop show",
+}
+
+
+def _nums(txt):
+    out = []
+    for t in tokens(txt):
+        try:
+            out.append(float(t))
+        except ValueError:
+            pass
+    return np.array(out)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_layer0_gradient_matches_the_oracle_vm_whenever_it_is_read(name):
+    src = NET + CASES[name] + "\nbye\n"
+    ref = _nums(run_vm(TEN4_ORACLE, source=src, seed=7))
+    for env in ({}, {"T4_LAZY_DX0": "0"}):
+        got = _nums(run_vm(TEN4, source=src, seed=7, env_extra=env))
+        assert got.shape == ref.shape and got.size >= 3, (name, env, got, ref)
+        scale = np.maximum(np.abs(ref), 1e-3)
+        assert np.all(np.abs(got - ref) <= 2e-3 * scale + 1e-4), (name, env, got, ref)     # printed at 4 decimals / 6 significant digits
