@@ -345,7 +345,7 @@ def main():
     k.lib.t4k_conv_stack_stats.restype = None
     k.lib.t4k_conv_stack_stats(ctypes.byref(cj), ctypes.byref(cd), ctypes.byref(cf))
     stack_mode = "off" if (cj.value + cd.value == 0) else ("jit" if cj.value else "prebuilt")
-    want = {"nn_f": 4, "nn_c": 4}[args.net] + (1 if (dp and native and not xchg) else 0)     # cs_fwd(+head), head backward + linear, cs_bwd_b, optimizer (+ fold [+ exchange]); with RCCL between them the fold keeps its launch
+    want = {"nn_f": 5, "nn_c": 5}[args.net] + (1 if (dp and native and not xchg) else 0)     # cs_fwd(+head), head backward, linear backward (dW || dX), cs_bwd_b, optimizer (+ fold [+ exchange]); with RCCL between them the fold keeps its launch
     if not args.allow_fallback and os.environ.get("T4_STACK", "1") != "0" and (stack_mode == "off" or cf.value or launches > want + 0.01):
         sys.stderr.write("bench: the timed step is NOT the described path: conv_stack=%s (jit %d, cache %d, failed %d), %.2f launches per step (expected <= %d); "
                          "%s\n(--allow-fallback prints the line anyway)\n" % (stack_mode, cj.value, cd.value, cf.value, launches, want, k.lib.t4k_last_error().decode(errors="replace")[-600:]))

@@ -268,10 +268,27 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd_cols(const float *X, const
         const long o = (long)n * E1 + c0 + c;
         mk[k] = ok ? MASK[o] : 0.f; mkb[k] = (ok && DXMB) ? MASKB[o] : 0.f;
     }
-    for (int i = tid; i < N * E0; i += 256) dys[i] = DY[i] - (TGT ? TGT[i] : 0.f);
-    for (int i = tid; i < E0 * CW; i += 256) { const int e0 = i / CW, c = i - e0 * CW; Ws[i] = c < cw ? W[(long)e0 * E1 + c0 + c] : 0.f; }
-    if (train)
-        for (int i = tid; i < N * CW; i += 256) { const int n = i / CW, c = i - n * CW; Xs[i] = c < cw ? X[(long)n * E1 + c0 + c] : 0.f; }
+    {   // staging: EVERY global load of the first PRE x 256 elements of each operand goes out before the first LDS store - a loop per operand
+        // (load, store, next operand) made three dependent memory round trips out of what is one
+        constexpr int PRE = 6;
+        float pd[PRE], pt[PRE], px[PRE], pw = 0.f;
+#pragma unroll
+        for (int q = 0; q < PRE; q++) { const int i = tid + q * 256; const bool ok = i < N * E0; pd[q] = ok ? DY[i] : 0.f; pt[q] = (ok && TGT) ? TGT[i] : 0.f; }
+        if (tid < E0 * CW) { const int e0 = tid / CW, c = tid - e0 * CW; pw = c < cw ? W[(long)e0 * E1 + c0 + c] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < PRE; q++) { const int i = tid + q * 256, n = i / CW, c = i - n * CW; px[q] = (train && i < N * CW && c < cw) ? X[(long)n * E1 + c0 + c] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < PRE; q++) { const int i = tid + q * 256; if (i < N * E0) dys[i] = pd[q] - pt[q]; }
+        if (tid < E0 * CW) Ws[tid] = pw;
+        if (train) {
+#pragma unroll
+            for (int q = 0; q < PRE; q++) { const int i = tid + q * 256; if (i < N * CW) Xs[i] = px[q]; }
+        }
+        for (int i = tid + PRE * 256; i < N * E0; i += 256) dys[i] = DY[i] - (TGT ? TGT[i] : 0.f);
+        for (int i = tid + 256; i < E0 * CW; i += 256) { const int e0 = i / CW, c = i - e0 * CW; Ws[i] = c < cw ? W[(long)e0 * E1 + c0 + c] : 0.f; }
+        if (train)
+            for (int i = tid + PRE * 256; i < N * CW; i += 256) { const int n = i / CW, c = i - n * CW; Xs[i] = c < cw ? X[(long)n * E1 + c0 + c] : 0.f; }
+    }
     __syncthreads();
     if (TGT && tid == 0) __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // dY (and the target) staged here
     const int nout = E0 * CW, G = min(4, 256 / nout);           // thread groups splitting the batch of one dW output (contiguous ranges, summed in order)
