@@ -1165,7 +1165,13 @@ def test_gemm_large_plain_products_exact_on_integer_operands(t4k, dev, M, N, K):
                                          # 65..128 tiles, K in 256s: two workgroups per tile, combined in the epilogue (k_gemm_nn_plain<.., PAIR>)
                                          (512, 1024, 1024, 0, 0), (512, 1024, 1024, 0, 1), (1024, 512, 512, 1, 0), (576, 832, 768, 1, 1),
                                          # interior tiles, every layout, on the lean kernel (one tile per CU and several)
-                                         (1024, 1024, 1024, 0, 1), (1024, 1024, 512, 1, 0), (1024, 1024, 256, 1, 1), (1088, 1024, 384, 0, 1)])
+                                         (1024, 1024, 1024, 0, 1), (1024, 1024, 512, 1, 0), (1024, 1024, 256, 1, 1), (1088, 1024, 384, 0, 1),
+                                         # round 4: slivers on LDS-DMA operand blocks (k_gemm_l32) - the GAN's 256-row layers in the layouts of forward / dX / dW,
+                                         # K tails of half a block (784 = 24.5 x 32) and of 4 (100, 980, 772), 4 and 8 k-groups, ranges with blocks 2-3 held in
+                                         # registers (K > 256 with 4 waves, K > 512 with 8), ragged M / N edge tiles in every layout
+                                         (256, 512, 784, 0, 1), (256, 784, 512, 0, 0), (512, 784, 256, 1, 0), (256, 256, 128, 0, 1), (256, 100, 980, 0, 1),
+                                         (128, 980, 100, 0, 0), (100, 980, 128, 1, 0), (252, 500, 772, 0, 1), (252, 500, 772, 0, 0), (252, 500, 260, 1, 0),
+                                         (260, 36, 516, 1, 1), (256, 512, 832, 0, 1), (64, 2000, 416, 0, 0), (256, 1, 256, 0, 1)])
 def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N, K, tA, tB):
     """Ragged M / N (not multiples of the tile) on the LDS-DMA kernel with clamped source rows, and sliver shapes on the 32x32
     register-fetch kernel, every operand layout: entries in {-2..2} keep fp32 sums exact, so the product must equal numpy's bit for bit
@@ -1301,3 +1307,27 @@ def test_logsoftmax_layer_as_the_reference_writes_it(t4k, dev, N, C):
     d = dev.zeros((N, C))
     t4k.call("t4k_logsoftmax", p(dev.up(X)), p(d), N, C, None)
     np.testing.assert_allclose(dev.down(d), want, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("N,E0,E1", [(256, 512, 784), (256, 256, 512), (256, 784, 512), (128, 100, 980), (256, 512, 256), (252, 260, 516), (64, 36, 132)])
+def test_linear_backward_dual_launch_on_lds_dma_blocks_exact_on_integer_operands(t4k, dev, N, E0, E1):
+    """dW += dY^T X (+ dB) and dX = dY W of one linear layer in ONE launch on LDS-DMA operand blocks (k_gemm_dual_l32: 4 waves, 8 waves for the
+    deep 784 -> 512 dX, blocks 2-3 in registers for K > 256), dX over X in place behind the arrival slots and apart, twice in a row (epochs):
+    entries in {-2..2} keep every fp32 sum exact, so dW, dB and dX must equal numpy's integer products bit for bit - a reader that reported
+    early, a k block counted twice or a clamped edge row leaking into a stored element would show."""
+    rng = np.random.default_rng(N + 3 * E0 + 7 * E1)
+    X = rng.integers(-2, 3, (N, E1)).astype(np.float32); W = rng.integers(-2, 3, (E0, E1)).astype(np.float32)
+    G = rng.integers(-2, 3, (N, E0)).astype(np.float32)
+    DW0 = rng.integers(-3, 4, (E0, E1)).astype(np.float32); DB0 = rng.integers(-3, 4, E0).astype(np.float32)
+    wdw = (G.astype(np.int64).T @ X.astype(np.int64)).astype(np.float32); wdb = G.astype(np.int64).sum(0).astype(np.float32)
+    wdx = (G.astype(np.int64) @ W.astype(np.int64)).astype(np.float32)
+    dW, dG = dev.up(W), dev.up(G)
+    for rep in range(2):
+        dX, dDW, dDB = dev.up(X), dev.up(DW0), dev.up(DB0)
+        t4k.call("t4k_linear_bwd", p(dX), p(dW), p(dG), p(dX), p(dDW), p(dDB), N, E0, E1, 1, None)      # in place
+        assert np.array_equal(dev.down(dX), wdx), rep
+        assert np.array_equal(dev.down(dDW), DW0 + wdw) and np.array_equal(dev.down(dDB), DB0 + wdb), rep
+        dX2, dDX, dDW2, dDB2 = dev.up(X), dev.zeros((N, E1)), dev.up(DW0), dev.up(DB0)
+        t4k.call("t4k_linear_bwd", p(dX2), p(dW), p(dG), p(dDX), p(dDW2), p(dDB2), N, E0, E1, 1, None)  # apart
+        assert np.array_equal(dev.down(dDX), wdx) and np.array_equal(dev.down(dX2), X), rep
+        assert np.array_equal(dev.down(dDW2), DW0 + wdw) and np.array_equal(dev.down(dDB2), DB0 + wdb), rep
