@@ -362,6 +362,11 @@ typedef struct t4k_stack_head {
     float *mid_mask, *mid_out;                  /* derivative mask and output [N][E0a]                                      */
     const float *W2, *B2; float *Y2, *P;        /* second linear layer W2[E0b][E0a], bias, output [N][E0b]; softmax output  */
     int E1, E0a, E0b;
+    /* optional (all NULL / 0: off).  The batch came from a dataset: Model::forward then turns the labels into one-hot rows and counts the hits
+     * (Model::onehot(Dataset&) loss.cpp:47-72 + hit forward.cu:57-60).  The last band of image n has P[n] in hand: it writes hot[n][0..E0b)
+     * (label >= E0b counts as class 0, loss.cpp:66) and hit_flag[n] = (first arg-max of P[n] == label) for n < n_label, 0 behind it - one
+     * byte per image in device-visible memory (pinned host memory: the host adds them up, no atomics, no extra launch). */
+    const unsigned *label; float *hot; unsigned char *hit_flag; int n_label;
 } t4k_stack_head;
 /* t4k_conv_stack_release: frees what the forward left behind for the banded backward of the stack whose first conv output tensor is
  * `first_conv_out` (the owner of that tensor calls it when the model is freed - Model::~Model in the reference, src/nn/model.h; unknown

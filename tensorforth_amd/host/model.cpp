@@ -282,13 +282,14 @@ Model &Model::forward(Tensor &input) {
         return *this;
     }
     finalize(); current = this;
+    hit_flags_pending_ = false;
     NLOG("\nModel::forward starts trace=%d {", *trace);
     if (!replay(g_fwd_, input.data, (int)train, nullptr)) {
         const bool cap = capturing_;
         run_forward(input);
         end_capture(g_fwd_, cap);
     }
-    if (input.type == T_DATASET) onehot_hit((Dataset &)input);   // labels -> one-hot rows and the hit count, one launch
+    if (input.type == T_DATASET && !hit_flags_pending_) onehot_hit((Dataset &)input);   // labels -> one-hot rows and the hit count, one launch (or none: they rode in the conv stack's head forward)
     NLOG("\n} Model::forward\n");
     return *this;
 }
@@ -299,6 +300,7 @@ static void dp_bn_mode(bool train) {
     if (t4k_comm_world() > 0) t4k_comm_sync_batchnorm(train && want);
 }
 void Model::run_forward(Tensor &input) {
+    hit_flags_pending_ = false;
     clear_dx0_marks();                                   // this pass overwrites layer 0: a skipped dX of the previous backward is gone for good
     dp_bn_mode(train);
     const int L = (int)layer.size();
@@ -385,8 +387,24 @@ void Model::run_forward(Tensor &input) {
                     hd.mid_layer = y1.grad_fn; hd.mid_alpha = y1.xparm; hd.mid_mask = y1.grad[4]->data; hd.mid_out = act.data;
                     hd.W2 = act.grad[0]->data; hd.B2 = act.grad[1]->data; hd.Y2 = y2.data; hd.P = prob.data;
                     hd.E1 = (int)l1.HWC(); hd.E0a = (int)y1.HWC(); hd.E0b = (int)y2.HWC();
+                    // a dataset batch: the one-hot rows and the hit flags of Model::onehot(Dataset&) + hit (forward.cu:57-60) ride in the same launch
+                    bool rider = false;
+                    if (input.type == T_DATASET && j + 4 == L - 1 && !capturing_ && !use_graphs) {
+                        Dataset &ds = (Dataset &)input;
+                        const uint32_t E = (uint32_t)prob.HWC();
+                        if (ds.label && ds.batch_sz >= 1 && (uint32_t)ds.batch_sz <= prob.N()) {
+                            if (!hot) hot = &T4(prob.N(), 1, E, 1);
+                            if ((uint32_t)ds.batch_sz < prob.N()) hot->zeros();     // short last batch: the rows past it stay zero and count nothing
+                            if (!hit_flags_ || hit_flags_n_ < (int)prob.N()) {
+                                if (hit_flags_) { t4k_sync(stream()); t4k_host_free(hit_flags_); }
+                                void *pp; chk(t4k_host_alloc(&pp, prob.N()), "nn#hit flags"); hit_flags_ = (unsigned char *)pp; hit_flags_n_ = (int)prob.N();
+                            }
+                            hd.label = ds.label; hd.hot = hot->data; hd.hit_flag = hit_flags_; hd.n_label = ds.batch_sz; rider = true;
+                        }
+                    }
                     if (t4k_conv_stack_head_ok(stg, ns, in.N(), &hd)) {
                         chk(t4k_conv_stack_head_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, stg, ns, in.N(), &hd, stream()), "nn#fstack+head");
+                        if (rider) { hit_flags_pending_ = true; hit_pending_ = false; }
                         stack_fresh_[i] = 1;
                         x = prob.data; i = j + 3;
                         continue;
@@ -505,7 +523,14 @@ DU Model::dp_sum(DU v) {
     return r;
 }
 int Model::hit(bool recalc) {                           // loss.cpp:75-107
-    if (recalc) hit_lazy();
+    if (recalc) { hit_flags_pending_ = false; hit_lazy(); }
+    if (hit_flags_pending_) {                             // the forward left one byte per image in pinned memory: add them up here
+        t4k_sync(stream());
+        int c = 0; const int n = (int)at(-1).N();
+        for (int i = 0; i < n && i < hit_flags_n_; i++) c += ((volatile unsigned char *)hit_flags_)[i] ? 1 : 0;
+        hit_ = (int)dp_sum((DU)c); hit_flags_pending_ = false; hit_pending_ = false;
+        return hit_;
+    }
     if (hit_pending_) {
         t4k_sync(stream());                                // kernel completion makes its store to the pinned word visible (no copy command)
         const int c = *(volatile int *)hit_pin;
@@ -983,6 +1008,7 @@ void Model::free_all() {
     if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }
     if (hit_dev) { t4k_free(hit_dev); hit_dev = nullptr; }
     if (hit_pin) { t4k_sync(stream()); t4k_host_free(hit_pin); hit_pin = nullptr; }
+    if (hit_flags_) { t4k_sync(stream()); t4k_host_free(hit_flags_); hit_flags_ = nullptr; hit_flags_n_ = 0; }
 }
 
 Model &Store::model(int *trace) { Model *m = new Model(); m->type = T_MODEL; m->trace = trace; put(m); return *m; }

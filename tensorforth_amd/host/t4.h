@@ -227,6 +227,7 @@ struct Model : Obj {
     DU   max_norm = 0;
     int *trace = nullptr;
     Tensor *hot = nullptr, *loss_t = nullptr;
+    unsigned char *hit_flags_ = nullptr; int hit_flags_n_ = 0; bool hit_flags_pending_ = false;   // per-image hit flags the conv stack's head forward wrote (pinned host bytes): `nn.hit` adds them up
     int  *hit_dev = nullptr, *hit_pin = nullptr;          // scalar all-reduce scratch (HBM); hit counter (pinned host, written by k_hit)
 
     Tensor &at(int i) { return *layer[i < 0 ? (int)layer.size() + i : i]; }

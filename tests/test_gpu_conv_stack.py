@@ -312,7 +312,8 @@ def test_backprop_after_a_traced_forward_ignores_what_an_earlier_stack_forward_s
 class StackHead(ctypes.Structure):
     _fields_ = [("W1", ctypes.c_void_p), ("B1", ctypes.c_void_p), ("Y1", ctypes.c_void_p), ("mid_layer", ctypes.c_int), ("mid_alpha", ctypes.c_float),
                 ("mid_mask", ctypes.c_void_p), ("mid_out", ctypes.c_void_p), ("W2", ctypes.c_void_p), ("B2", ctypes.c_void_p), ("Y2", ctypes.c_void_p),
-                ("P", ctypes.c_void_p), ("E1", ctypes.c_int), ("E0a", ctypes.c_int), ("E0b", ctypes.c_int)]
+                ("P", ctypes.c_void_p), ("E1", ctypes.c_int), ("E0a", ctypes.c_int), ("E0b", ctypes.c_int),
+                ("label", ctypes.c_void_p), ("hot", ctypes.c_void_p), ("hit_flag", ctypes.c_void_p), ("n_label", ctypes.c_int)]
 
 
 @pytest.mark.parametrize("case,EA,EB,mid", [(0, 100, 10, "dropout"), (0, 100, 10, "relu"), (2, 37, 5, "dropout"), (3, 64, 16, None), (2, 130, 3, "tanh")])
