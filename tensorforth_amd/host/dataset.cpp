@@ -61,7 +61,7 @@ static void reader_main(Corpus *c, Reader *r) {
         r->busy = true;
         const bool wait_ev = c->pin_wait[slot]; c->pin_wait[slot] = false;
         lk.unlock();
-        if (wait_ev) t4k_event_sync(c->pin_done[slot]);  // the staging launch of the batch this slot held
+        if (wait_ev) t4k_event_sync(c->pin_ev[slot]);    // the staging launch of the batch this slot held
         const int n = c->read_into(bid, slot);
         lk.lock();
         c->slot_n[slot] = n; r->queue[q] = -1; r->busy = false;
@@ -76,7 +76,7 @@ void Corpus::ensure_slots() {
 }
 void Corpus::idle() {                                    // wait for outstanding reads and forget what the slots hold
     if (worker) { Reader *r = (Reader *)worker; std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r] { return !r->busy && r->queue[0] < 0 && r->queue[1] < 0; }); }
-    for (int s = 0; s < 2; s++) { if (pin_wait[s] && pin_done[s]) t4k_event_sync(pin_done[s]); pin_wait[s] = false; slot_bid[s] = -1; slot_n[s] = 0; }
+    for (int s = 0; s < 2; s++) { if (pin_wait[s] && pin_ev[s]) t4k_event_sync(pin_ev[s]); pin_wait[s] = false; slot_bid[s] = -1; slot_n[s] = 0; }
 }
 void Corpus::request(int bid) {                          // the staging launch of the batch the slot holds now must have been ISSUED
     if (bid < 0 || bid >= n_batches() || slot_bid[bid & 1] == bid) return;
@@ -95,7 +95,7 @@ int Corpus::wait_batch(int bid) {
     Reader *r = (Reader *)worker;
     if (slot_bid[slot] != bid) {                         // nobody was asked to: cold start / after a rewind - read here
         if (r) { std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r, slot] { return r->queue[slot] < 0; }); }
-        if (pin_wait[slot]) { t4k_event_sync(pin_done[slot]); pin_wait[slot] = false; }
+        if (pin_wait[slot]) { t4k_event_sync(pin_ev[slot]); pin_wait[slot] = false; }
         slot_bid[slot] = bid; slot_n[slot] = read_into(bid, slot);
         return slot_n[slot];
     }
@@ -130,12 +130,14 @@ int Corpus::read_into(int bid, int slot) {               // returns the number o
     return (int)n;
 }
 
-// The feed.  Batch b of an epoch lives in dbuf[b % 3] / lbuf[b % 3].  fetch(b) makes batch b current (swaps `data` / `label`: a pointer
-// swap once the pipeline runs), then issues the staging launch of batch b + 1 - (x - mean) * scale and the labels, read straight out of
-// the pinned slot over the fabric - on a side stream, and asks the reader thread for batch b + 2.  Ordering:
-//   * the side stream writes dbuf[(b+1) % 3] = the buffer of batch b - 2: it waits for the main-stream mark recorded at fetch(b - 1),
-//     which stands behind every launch that read batches <= b - 2 (a wait on the SIDE stream: nothing is added to the step's stream);
-//   * the model must not read dbuf[b % 3] before its staging launch is done: the HOST waits for that launch's event - issued one whole
+// The feed.  Batch b of an epoch lives in dbuf[b % RING] / lbuf[b % RING].  fetch(b) makes batch b current (swaps `data` / `label`: a
+// pointer swap once the pipeline runs), then issues the staging launch of batch b + 1 - (x - mean) * scale and the labels, read straight out
+// of the pinned slot over the fabric - on a side stream, and asks the reader thread for batch b + 2.  Ordering, with as few runtime calls
+// as it takes (the fed step is 5 launches of ~50 us: every event call on the host shows):
+//   * the side stream overwrites the buffer of batch b + 1 - RING: every MARK_EVERY-th fetch records a mark on the main stream (it stands
+//     behind every launch that read batches below that fetch's) and the side stream waits for it ONCE (stream order carries it to all later
+//     staging launches).  The newest mark is at most MARK_EVERY fetches old, so it covers batches <= b - MARK_EVERY - 1 >= b + 1 - RING;
+//   * the model must not read dbuf[b % RING] before its staging launch is done: the HOST waits for that launch's event - issued one whole
 //     step earlier, so the wait is a query; no cross-stream edge on the step's stream (measured in round 3: +8 us per edge);
 //   * the reader refills pinned slot b & 1 after the event of the launch that read it (waited for on the reader thread).
 static t4k_stream_t feed_stream() {
@@ -145,11 +147,12 @@ static t4k_stream_t feed_stream() {
 }
 static const bool g_prefetch = getenv("T4_FEED_PREFETCH") ? atoi(getenv("T4_FEED_PREFETCH")) != 0 : true;
 void Dataset::release_ring() {
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < RING; i++) {
         if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]);
         if (dbuf[i]) t4k_free(dbuf[i]); if (lbuf[i]) t4k_free(lbuf[i]);
-        dbuf[i] = nullptr; lbuf[i] = nullptr; dev_bid[i] = -1; mark_set[i] = false;
+        dbuf[i] = nullptr; lbuf[i] = nullptr; dev_bid[i] = -1;
     }
+    mark_bid = -1;
     data = nullptr; label = nullptr; ring_numel = 0;
 }
 int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
@@ -167,55 +170,57 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     die_if_no_backend();
     if (rewind) {                                        // also after `normalize`: whatever was staged ahead is void
         cp->idle();
-        for (int i = 0; i < 3; i++) { if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]); dev_bid[i] = -1; }
+        for (int i = 0; i < RING; i++) { if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]); dev_bid[i] = -1; }
+        mark_bid = -1;
         batch_id = done = 0;
     }
     const int b = batch_id, nb = cp->n_batches();
     if (done || b >= nb) { hprintf("%s::fetch EOF reached (needs rewind)\n", cp->cifar ? "Cifar10" : "Mnist"); done = 1; hprintf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
     if (ring_numel != numel) {
         if (ring_numel) { t4k_sync(stream()); release_ring(); }
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < RING; i++) {
             void *p; t4k_malloc(&p, sizeof(float) * numel); dbuf[i] = (float *)p; t4k_memset(p, 0, sizeof(float) * numel, stream());
             t4k_malloc(&p, sizeof(uint32_t) * N()); lbuf[i] = (uint32_t *)p;
-            if (!staged[i]) { t4k_event_create(&staged[i]); t4k_event_create(&mark[i]); }
+            if (!staged[i]) t4k_event_create(&staged[i]);
         }
+        if (!mark) t4k_event_create(&mark);
         ring_numel = numel;
     }
     const long cell = HWC();
     t4k_stream_t side = g_prefetch ? feed_stream() : nullptr;     // none on a backend without streams (the oracle's): every batch then takes the in-stream path
     // ---- batch b becomes current
-    const int r = b % 3;
+    const int r = b % RING;
     if (dev_bid[r] == b) t4k_event_sync(staged[r]);      // staged ahead (issued a step ago)
     else {
         const int n = cp->wait_batch(b);
         if (n <= 0) { hprintf("  } dataset#fetch => corpus fetch failed\n"); return -3; }
         chk(t4k_stage_batch(cp->pix[b & 1], dbuf[r], (long)n * cell, mean, scale, cp->lab[b & 1], lbuf[r], n, stream()), "dataset#load");   // (x - mean) * scale and the labels, one launch
-        t4k_event_record(cp->pin_done[b & 1], stream()); cp->pin_wait[b & 1] = true;
+        t4k_event_record(cp->pin_done[b & 1], stream()); cp->pin_ev[b & 1] = cp->pin_done[b & 1]; cp->pin_wait[b & 1] = true;
         // a short last batch leaves the previous batch's samples behind it (Dataset::_load copies batch_sz samples into ONE buffer, dataset.cu:142-158)
-        if (n < cp->N && b > 0) t4k_memcpy_d2d(dbuf[r] + (long)n * cell, dbuf[(b + 2) % 3] + (long)n * cell, sizeof(float) * (size_t)(cp->N - n) * cell, stream());
+        if (n < cp->N && b > 0) t4k_memcpy_d2d(dbuf[r] + (long)n * cell, dbuf[(b - 1) % RING] + (long)n * cell, sizeof(float) * (size_t)(cp->N - n) * cell, stream());
         dev_bid[r] = b; dev_n[r] = n;
     }
     data = dbuf[r]; label = lbuf[r]; batch_sz = dev_n[r];
     done = ((long)b * cp->N + batch_sz >= cp->corpus_sz) ? 1 : 0;
     if (!done) {
         // ---- batch b + 1 goes to its buffer on the side stream if the reader already holds it (full batches only); a cold start just asks for it
-        const int b1 = b + 1, r1 = b1 % 3;
+        const int b1 = b + 1, r1 = b1 % RING;
         if (side && dev_bid[r1] != b1 && cp->slot_bid[b1 & 1] == b1 && (long)(b1 + 1) * cp->N <= cp->corpus_sz) {
             const int n1 = cp->wait_batch(b1);
             if (n1 == cp->N) {
-                const int pm = (b + 2) % 3;              // the mark of fetch(b - 1)
-                if (!mark_set[pm]) { t4k_event_record(mark[pm], stream()); mark_set[pm] = true; }      // pipeline start: behind everything issued so far
-                t4k_stream_wait_event(side, mark[pm]);
+                if (mark_bid < 0 || b - mark_bid >= MARK_EVERY) {          // a fresh mark: behind everything issued so far; the side stream waits for it once
+                    t4k_event_record(mark, stream()); mark_bid = b;
+                    t4k_stream_wait_event(side, mark);
+                }
                 chk(t4k_stage_batch(cp->pix[b1 & 1], dbuf[r1], (long)n1 * cell, mean, scale, cp->lab[b1 & 1], lbuf[r1], n1, side), "dataset#prefetch");
                 t4k_event_record(staged[r1], side);
-                t4k_event_record(cp->pin_done[b1 & 1], side); cp->pin_wait[b1 & 1] = true;
+                cp->pin_ev[b1 & 1] = staged[r1]; cp->pin_wait[b1 & 1] = true;
                 dev_bid[r1] = b1; dev_n[r1] = n1;
             }
         }
         cp->request(b1);                                 // no-op when the slot holds (or is being filled with) that batch
         cp->request(b + 2);                              // slot b & 1: batch b's staging launch has been issued, the reader waits for its event
     }
-    if (side) { t4k_event_record(mark[r], stream()); mark_set[r] = true; }
     batch_id++;
     return 0;
 }

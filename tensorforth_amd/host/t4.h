@@ -188,7 +188,8 @@ struct Corpus {
     // reader thread fills a slot (after the event of the launch that last read it) while the GPU works on earlier batches
     uint8_t  *pix[2] = {nullptr, nullptr};
     uint32_t *lab[2] = {nullptr, nullptr};
-    t4k_event_t pin_done[2] = {nullptr, nullptr};   // recorded behind the staging launch that reads the slot
+    t4k_event_t pin_done[2] = {nullptr, nullptr};   // recorded behind the staging launch that reads the slot (in-stream path)
+    t4k_event_t pin_ev[2] = {nullptr, nullptr};     // the event that guards the slot now: pin_done[s], or the prefetch ring's `staged` event of that launch
     bool pin_wait[2] = {false, false};              // the event has been recorded since the slot was last filled
     int  slot_bid[2] = {-1, -1}, slot_n[2] = {0, 0};   // batch a slot holds (or is being filled with) and its sample count
     void *worker = nullptr;                    // persistent reader thread (dataset.cpp)
@@ -204,15 +205,17 @@ struct Dataset : Tensor {
     uint32_t *label = nullptr;                 // device: labels of the current batch (one of lbuf)
     DU mean = 0.0f, scale = 1.0f / 256.0f;     // src/mu/dataset.h:36-37
     Corpus *cp = nullptr;
-    // prefetch ring (the reference's TODO, src/mu/dataset.cu:112): batch b lives in dbuf[b % 3]; while the model works on batch b the
+    // prefetch ring (the reference's TODO, src/mu/dataset.cu:112): batch b lives in dbuf[b % RING]; while the model works on batch b the
     // staging launch of batch b + 1 runs on a side stream, so `fetch` / `next` only swap `data` / `label`
-    float    *dbuf[3] = {nullptr, nullptr, nullptr};
-    uint32_t *lbuf[3] = {nullptr, nullptr, nullptr};
-    int       dev_bid[3] = {-1, -1, -1}, dev_n[3] = {0, 0, 0};
-    t4k_event_t staged[3] = {nullptr, nullptr, nullptr};   // side stream: batch is in its buffer
-    t4k_event_t mark[3] = {nullptr, nullptr, nullptr};     // main stream: recorded at fetch(b), i.e. behind everything that read batches < b
-    bool mark_set[3] = {false, false, false};
+    static constexpr int RING = 8, MARK_EVERY = 4;         // RING >= MARK_EVERY + 2: see Dataset::fetch
+    float    *dbuf[RING] = {};
+    uint32_t *lbuf[RING] = {};
+    int       dev_bid[RING], dev_n[RING] = {};
+    t4k_event_t staged[RING] = {};             // side stream: batch is in its buffer (also what the reader waits for before refilling the pinned slot)
+    t4k_event_t mark = nullptr;                // main stream: recorded every MARK_EVERY fetches, behind everything that read earlier batches
+    int  mark_bid = -1;                        // the fetch it was recorded at (-1: none)
     uint64_t ring_numel = 0;
+    Dataset() { for (int i = 0; i < RING; i++) dev_bid[i] = -1; }
     void set_norm(DU m, DU s) { mean = m; scale = 1.0f / s; }
     int  fetch(const char *ds_name, bool rewind);
     void release_ring();
