@@ -80,22 +80,28 @@ __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_r
     const t4k_param_rec r = tab[i];
     const bool mom = !(fabsf(b1) < DU_EPS);
     const long j0 = ((long)blockIdx.x - r.pad) * 1024;
+    // all four elements' loads go out before the first update (the chunk is one memory round trip, not four)
+    float g[4], dg[4], m[4], v[4]; bool in[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const long j = j0 + q * BLK + threadIdx.x;
-        if (j >= r.n) break;
-        float g = r.G[j], dg = r.DG[j];
-        if (r.G == keep_src) keep_dst[j] = g;                   // the pre-update value of a snapshotted tensor
+        in[q] = j < r.n;
+        g[q] = in[q] ? r.G[j] : 0.f; dg[q] = in[q] ? r.DG[j] : 0.f;
+        m[q] = (in[q] && (kind != 0 || mom)) ? r.M[j] : 0.f; v[q] = (in[q] && kind != 0) ? r.V[j] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (!in[q]) continue;
+        const long j = j0 + q * BLK + threadIdx.x;
+        if (r.G == keep_src) keep_dst[j] = g[q];                // the pre-update value of a snapshotted tensor
         if (kind == 0) {
-            float m = mom ? r.M[j] : 0.f;
-            sgd1(g, dg, m, r.Nw, lr, b1, mom);
-            if (mom) r.M[j] = m;
+            sgd1(g[q], dg[q], m[q], r.Nw, lr, b1, mom);
+            if (mom) r.M[j] = m[q];
         } else {
-            float m = r.M[j], v = r.V[j];
-            if (kind == 1) adam1(g, dg, m, v, lr, b1, b2); else adamw1(g, dg, m, v, lr, b1, b2, wd);
-            r.M[j] = m; r.V[j] = v;
+            if (kind == 1) adam1(g[q], dg[q], m[q], v[q], lr, b1, b2); else adamw1(g[q], dg[q], m[q], v[q], lr, b1, b2, wd);
+            r.M[j] = m[q]; r.V[j] = v[q];
         }
-        r.G[j] = g; r.DG[j] = 0.f;
+        r.G[j] = g[q]; r.DG[j] = 0.f;
     }
 }
 
@@ -285,7 +291,7 @@ static int opt_step_impl(int kind, const t4k_param_rec *tab_dev, const t4k_param
         else { g.pending &= ~1; fa = pf.fa; nfold = pf.fa.total / 16; }
     }
     static bool err_set = false;
-    if (!err_set && g.spin_err) { T4K_LAUNCH(k_opt_set_err, dim3(1), dim3(1), 0, S(s), g.spin_err); err_set = true; }
+    if (!err_set && g.spin_err) { hipLaunchKernelGGL(k_opt_set_err, dim3(1), dim3(1), 0, S(s), g.spin_err); err_set = true; }   // once per process: set-up, not a launch of the step (not counted)
     const float *ks = g_keep_src; float *kd = g_keep_dst; g_keep_src = nullptr; g_keep_dst = nullptr;
     if (dp) {
         const XchgDev xd = xchg_begin(false);
