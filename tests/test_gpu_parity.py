@@ -188,7 +188,8 @@ def test_reductions(t4k, dev, oracle):
 # ------------------------------------------------------------------------------- nn
 @pytest.mark.parametrize("K,S,P_", [(1, 1, 0), (3, 1, 1), (4, 2, 1), (5, 1, 2)])
 @pytest.mark.parametrize("N,H1,C1,C0", [(2, 6, 2, 3), (3, 14, 10, 20), (4, 28, 1, 10), (2, 8, 40, 72), (2, 10, 3, 16), (1, 12, 64, 33),
-                                        (2, 8, 32, 64), (3, 10, 64, 32), (2, 6, 96, 128), (2, 9, 32, 20)])   # last four: LDS-staged many-channel kernels
+                                        (2, 8, 32, 64), (3, 10, 64, 32), (2, 6, 96, 128), (2, 9, 32, 20),    # these four: LDS-staged many-channel kernels
+                                        (2, 8, 64, 128), (3, 8, 128, 64), (1, 12, 128, 256), (5, 6, 64, 68)])   # round 4: 8-wave LDS-DMA kernel (64-channel stages; 128- and 64-wide tiles, ragged pixel / channel edges)
 def test_conv2d(t4k, dev, oracle, K, S, P_, N, H1, C1, C0):
     o = oracle.lib(); P = oracle.P
     rng = np.random.default_rng(K + N)

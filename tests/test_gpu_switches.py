@@ -70,7 +70,8 @@ print("FAILS", fails)
 sys.exit(1 if fails else 0)
 '''
 
-SWITCHES = [{}, {"T4K_GEMM_DUAL": "0"}, {"T4K_GEMM_DUAL32": "0"}, {"T4K_GEMM_S32": "0"}, {"T4K_GEMM_DUAL": "0", "T4K_GEMM_DUAL32": "0", "T4K_GEMM_S32": "0"},
+SWITCHES = [{}, {"T4K_GEMM_L32": "0"}, {"T4K_GEMM_DUAL_L32": "0"}, {"T4K_GEMM_L32": "0", "T4K_GEMM_DUAL_L32": "0"}, {"T4K_LINTHIN": "0"}, {"T4K_LINTHIN_CW": "0"}, {"T4K_LINTHIN_CW": "16"},
+            {"T4K_GEMM_DUAL": "0"}, {"T4K_GEMM_DUAL32": "0"}, {"T4K_GEMM_S32": "0"}, {"T4K_GEMM_DUAL": "0", "T4K_GEMM_DUAL32": "0", "T4K_GEMM_S32": "0"},
             {"T4K_GEMM_FULLK": "0"}, {"T4K_GEMM_FASTPRO": "0"}, {"T4K_GEMM_RAGGED_DMA": "0"}, {"T4K_GEMM_PLAIN_BIG": "0"}, {"T4K_GEMM_BIG_DMA": "0"},
             {"T4K_GEMM_BIG_FULLK": "0"}, {"T4K_GEMM_DUAL_FULL": "0"}, {"T4K_GEMM_DUAL_FULLK": "0"}, {"T4K_GEMM_SPLIT_DIV": "2"}, {"T4K_GEMM_S32_NW8": "0"},
             {"T4K_GEMM_S32_MAXK": "256"}, {"T4K_GEMM_DUAL_MAXK": "256"}, {"T4K_GEMM_DUAL32_MAXK": "128"}, {"T4K_HEAD_FOLD": "0"}, {"T4K_LINSMALL_GATE": "0"}, {"T4K_LINSMALL_COLS": "0"}, {"T4K_LINSMALL_COLS": "2"},
@@ -91,3 +92,12 @@ def test_integer_exact_products_under_every_dispatch_switch(tmp_path, sw):
 
 def test_gated_kernels_while_another_stream_hogs_the_device(tmp_path):
     _run(tmp_path, {"HOG": "1"})
+
+
+def test_opt_in_conv_kernel_on_the_lean_pipeline_matches_the_oracle():
+    """k_convbig8 (csrc/conv_big.hip: forward / dX of many-channel layers on the dense GEMM's 8-wave LDS-DMA pipeline) is off by default
+    (measured no gain on the CIFAR layers); T4K_CONVBIG8=1 routes every qualifying layer of the conv parity tests through it."""
+    env = dict(os.environ, T4K_CONVBIG8="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "test_conv2d or many_channels or random_shapes"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
