@@ -56,6 +56,7 @@ struct GemmP {
     // optional rider (generic 64x64 kernel only): workgroups beyond the tile grid add the column sums of a [rows, E] matrix
     // into cs_out - the bias gradient of a linear layer shares the launch of its weight-gradient GEMM
     const float *cs_X; float *cs_out; int cs_rows, cs_E;
+    int xmap;                          // 32x32 kernels: 0 = tiles in launch order; 1 / 2 = XCD x (workgroup id % 8) owns a contiguous run of the row-major / column-major tile order
     const float *Z;                    // 4 KiB of zeros (State::d_zero): source of LDS-DMA lanes past the K range / the matrix edge (DMA variants of the 32x32 kernels)
 };
 
@@ -460,7 +461,16 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         if (ry == 0 && e < p.cs_E) p.cs_out[e] += (red[ex] + red[64 + ex]) + (red[128 + ex] + red[192 + ex]);
         return;
     }
-    const int tm = bx / p.tiles_n, tn = bx - tm * p.tiles_n;
+    // XCD-aware tile order (xmap): workgroup id % 8 is the XCD a workgroup runs on (private L2s).  In launch order neighbouring tiles - which share
+    // an operand - sit on eight different XCDs and every L2 pulls both operands whole; a contiguous run of the column-major order gives an XCD
+    // its own slice of B (2: outputs wider than tall), of the row-major order its own slice of A (1).
+    int tm, tn;
+    {
+        int Lt = bx;                                           // (bx may be offset by a constant from the physical id - second GEMM of a dual launch: the groups bx % 8 are still the XCDs)
+        if (p.xmap) { const int q8 = T >> 3, r8 = T & 7, x = bx & 7, i = bx >> 3; Lt = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; }
+        if (p.xmap == 2) { tn = Lt / p.tiles_m; tm = Lt - tn * p.tiles_m; } else { tm = Lt / p.tiles_n; tn = Lt - tm * p.tiles_n; }
+    }
+    const int tile = tm * p.tiles_n + tn;                  // logical id: the arrival slots are indexed by it
     const int m0 = tm * 32, n0 = tn * 32;
     const int arow = Alds ? l31 : min(m0 + l31, M - 1), bcol = min(n0 + l31, N - 1);      // clamped: rows / columns past the edge are never stored
     const float *Ap = Alds ? Alds : p.A; const int Am = Alds ? 32 : M, Ald_ = Alds ? Ald : K;
@@ -508,7 +518,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     auto arrive = [&]() __attribute__((always_inline)) {
         if (!early) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(slots + 4 * bx + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(slots + 4 * tile + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     constexpr int RS = DMA ? 4096 : 1024;                         // floats between two k-groups' partial accumulators in `red`
     if constexpr (DMA) {
@@ -646,7 +656,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     // agent-scope loads until all of them carry the epoch - one store and one load round trip on the critical path, nothing to re-arm.
     if (gate_mode == 1) {
         __syncthreads();
-        if (!early && tid == 0) __hip_atomic_store(slots + bx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!early && tid == 0) __hip_atomic_store(slots + tile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (gate_mode == 2) {
         if (w == 0) {
             // only the readers of the columns this tile overwrites matter: dW tiles (e0t, tn), e0t = 0 .. gate_n / tiles_n - 1 (both GEMMs
@@ -1912,7 +1922,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
                 p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
                 p.tiles_m = (M + 31) / 32; p.tiles_n = (Nn + 31) / 32; p.kchunk = K; p.nsplit = 1;
-                p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+                p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0; p.xmap = 0; p.Z = nullptr;
             };
             fill32(q1, DY, X, DW, E0, E1, N, 1.0f);
             q1.cs_X = DY; q1.cs_out = DB; q1.cs_rows = N; q1.cs_E = E0;
@@ -1925,11 +1935,14 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             static int l32d = -1; if (l32d < 0) { const char *e = getenv("T4K_GEMM_DUAL_L32"); l32d = e ? atoi(e) : 1; }
             if (l32d && g.d_zero && N <= 1024 && E0 <= 1024 && (a1 > 128 || (N <= 512 && E0 <= 512))) {   // coalesced operand blocks through LDS-DMA; a wave walks at most four 32-deep blocks
                 q1.Z = q2.Z = g.d_zero;
+                static int xm = -1; if (xm < 0) { const char *e = getenv("T4K_GEMM_XMAP"); xm = e ? atoi(e) : 0; }   // measured: no effect on the GAN layers (the Infinity Cache serves all eight L2s), off
+                if (xm) { q1.xmap = a1 >= 16 ? (E1 >= E0 ? 2 : 1) : 0; q2.xmap = a2 >= 16 ? (E1 >= N ? 2 : 1) : 0; }
                 const dim3 gd((unsigned)(a1 + ar + a2));
 #define T4K_DL32(R_, W_) do { static bool attr_done = false; \
                     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_dual_l32<R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, W_ * 16384); attr_done = true; } \
                     T4K_LAUNCH((k_gemm_dual_l32<R_, W_>), gd, dim3(64 * W_), (size_t)W_ * 16384, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32); } while (0)
-                if (N > 512 || E0 > 512) T4K_DL32(true, 8);      // deep K: 8 k-groups (per-workgroup arrival slots: a1 > 128)
+                static int nw8d = -1; if (nw8d < 0) { const char *e = getenv("T4K_GEMM_DUAL_L32_NW8"); nw8d = e ? atoi(e) : 1; }
+                if ((N > 512 || E0 > 512) && nw8d) T4K_DL32(true, 8);      // deep K: 8 k-groups (per-workgroup arrival slots: a1 > 128)
                 else if (N > 256 || E0 > 256) T4K_DL32(true, 4); else T4K_DL32(false, 4);
 #undef T4K_DL32
                 return true;
@@ -1943,7 +1956,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     auto fill = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
         p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
         p.tiles_m = (M + 63) / 64; p.tiles_n = (Nn + 63) / 64; p.kchunk = ((K + 63) / 64) * 64; p.nsplit = 1;
-        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0; p.xmap = 0; p.Z = nullptr;
     };
     fill(p1, DY, X, DW, E0, E1, N, 1.0f);                    // A = dY^T ([K][M]), B = X ([K][N])
     p1.cs_X = DY; p1.cs_out = DB; p1.cs_rows = N; p1.cs_E = E0;
@@ -1970,7 +1983,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     if (M == 0 || N == 0) return T4K_OK;
     GemmP p;
     p.A = A; p.B = B; p.O = O; p.bias = bias; p.part = ws_for(s);
-    p.M = M; p.N = N; p.K = K; p.C = C; p.alpha = alpha; p.beta = beta;
+    p.M = M; p.N = N; p.K = K; p.C = C; p.alpha = alpha; p.beta = beta; p.xmap = 0; p.Z = nullptr;
 
     // 16-byte loads need: C == 1, aligned bases, contiguous extents divisible by 4
     const int a_contig = tA ? M : K, b_contig = tB ? K : N;
@@ -2030,6 +2043,8 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             static int l32 = -1; if (l32 < 0) { const char *e = getenv("T4K_GEMM_L32"); l32 = e ? atoi(e) : 1; }
             if (l32 && st().d_zero && aligned16(A) && aligned16(B) && (akc ? K % 4 == 0 : M % 4 == 0) && (bkc ? K % 4 == 0 : N % 4 == 0)) {
                 p.Z = st().d_zero;
+                static int xm = -1; if (xm < 0) { const char *e = getenv("T4K_GEMM_XMAP"); xm = e ? atoi(e) : 0; }   // measured: no effect on the GAN layers (the Infinity Cache serves all eight L2s), off
+                p.xmap = (xm && t32 >= 16) ? (N >= M ? 2 : 1) : 0;       // XCD-aware tile order: an XCD's L2 pulls its own slice of the wider operand only
                 const int nblk = (kc + 31) / 32;
                 // waves per workgroup (= k-groups) and whether a wave walks more than two blocks (RST: blocks 2, 3 wait in registers)
                 const bool w8 = nblk > 16 || (nblk >= 6 && t32 * ns <= (long)st().cu_count);
@@ -2441,7 +2456,7 @@ static int head_bwd_launch(float *X2, const float *W2, float *P, const float *TG
     auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
         p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
         p.tiles_m = (M + 31) / 32; p.tiles_n = (Nn + 31) / 32; p.kchunk = K; p.nsplit = 1;
-        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
+        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0; p.xmap = 0; p.Z = nullptr;
     };
     fill32(q1, DY1, X1, DW1, EA, E1, N, 1.0f);                    // dW1 += dY1^T X1   (A comes from LDS: the pointer is not read)
     fill32(q2, DY1, W1, X1, N, E1, EA, 0.0f);                     // dX1 = dY1 W1, over X1 (backprop.cu:240)

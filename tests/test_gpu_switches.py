@@ -70,7 +70,7 @@ print("FAILS", fails)
 sys.exit(1 if fails else 0)
 '''
 
-SWITCHES = [{}, {"T4K_GEMM_L32": "0"}, {"T4K_GEMM_DUAL_L32": "0"}, {"T4K_GEMM_L32": "0", "T4K_GEMM_DUAL_L32": "0"}, {"T4K_LINTHIN": "0"}, {"T4K_LINTHIN_CW": "0"}, {"T4K_LINTHIN_CW": "16"},
+SWITCHES = [{}, {"T4K_GEMM_L32": "0"}, {"T4K_GEMM_DUAL_L32": "0"}, {"T4K_GEMM_L32": "0", "T4K_GEMM_DUAL_L32": "0"}, {"T4K_LINTHIN": "0"}, {"T4K_LINTHIN_CW": "0"}, {"T4K_LINTHIN_CW": "16"}, {"T4K_GEMM_XMAP": "1"}, {"T4K_GEMM_DUAL_L32_NW8": "0"},
             {"T4K_GEMM_DUAL": "0"}, {"T4K_GEMM_DUAL32": "0"}, {"T4K_GEMM_S32": "0"}, {"T4K_GEMM_DUAL": "0", "T4K_GEMM_DUAL32": "0", "T4K_GEMM_S32": "0"},
             {"T4K_GEMM_FULLK": "0"}, {"T4K_GEMM_FASTPRO": "0"}, {"T4K_GEMM_RAGGED_DMA": "0"}, {"T4K_GEMM_PLAIN_BIG": "0"}, {"T4K_GEMM_BIG_DMA": "0"},
             {"T4K_GEMM_BIG_FULLK": "0"}, {"T4K_GEMM_DUAL_FULL": "0"}, {"T4K_GEMM_DUAL_FULLK": "0"}, {"T4K_GEMM_SPLIT_DIV": "2"}, {"T4K_GEMM_S32_NW8": "0"},
