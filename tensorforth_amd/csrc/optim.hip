@@ -80,28 +80,22 @@ __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_r
     const t4k_param_rec r = tab[i];
     const bool mom = !(fabsf(b1) < DU_EPS);
     const long j0 = ((long)blockIdx.x - r.pad) * 1024;
-    // all four elements' loads go out before the first update (the chunk is one memory round trip, not four)
-    float g[4], dg[4], m[4], v[4]; bool in[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const long j = j0 + q * BLK + threadIdx.x;
-        in[q] = j < r.n;
-        g[q] = in[q] ? r.G[j] : 0.f; dg[q] = in[q] ? r.DG[j] : 0.f;
-        m[q] = (in[q] && (kind != 0 || mom)) ? r.M[j] : 0.f; v[q] = (in[q] && kind != 0) ? r.V[j] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if (!in[q]) continue;
-        const long j = j0 + q * BLK + threadIdx.x;
-        if (r.G == keep_src) keep_dst[j] = g[q];                // the pre-update value of a snapshotted tensor
+        if (j >= r.n) break;
+        float g = r.G[j], dg = r.DG[j];
+        if (r.G == keep_src) keep_dst[j] = g;                   // the pre-update value of a snapshotted tensor
         if (kind == 0) {
-            sgd1(g[q], dg[q], m[q], r.Nw, lr, b1, mom);
-            if (mom) r.M[j] = m[q];
+            float m = mom ? r.M[j] : 0.f;
+            sgd1(g, dg, m, r.Nw, lr, b1, mom);
+            if (mom) r.M[j] = m;
         } else {
-            if (kind == 1) adam1(g[q], dg[q], m[q], v[q], lr, b1, b2); else adamw1(g[q], dg[q], m[q], v[q], lr, b1, b2, wd);
-            r.M[j] = m[q]; r.V[j] = v[q];
+            float m = r.M[j], v = r.V[j];
+            if (kind == 1) adam1(g, dg, m, v, lr, b1, b2); else adamw1(g, dg, m, v, lr, b1, b2, wd);
+            r.M[j] = m; r.V[j] = v;
         }
-        r.G[j] = g[q]; r.DG[j] = 0.f;
+        r.G[j] = g; r.DG[j] = 0.f;
     }
 }
 
