@@ -827,7 +827,7 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
             }
             if (tg) chk(t4k_loss_linear_bwd(in.data, in.grad[0]->data, (float *)dy, tg, at(-2).data, in.data, nullptr, nullptr,
                                         in.grad[2]->data, in.grad[3]->data, N, E0, E1, train, s), "nn#bprep+blinear");
-            else if (i == 0 && train && use_lazy_dx0 && fused && !capturing_ && !use_graphs && in.grad[2] && in.grad[3] && (long)E0 * E1 >= 65536) {
+            else if (i == 0 && train && use_lazy_dx0 && fused && !capturing_ && !use_graphs && in.grad[2] && in.grad[3] && (long)E0 * E1 >= 16384) {
                 // the net's first layer: nobody reads dX0 in a training loop - dW | dB now, dX0 = dY W when a word asks (materialize_dx0)
                 Tensor *holder = nullptr;
                 for (int k = 1; k < (int)layer.size() && !holder; k++) if (at(k).data == dy) holder = &at(k);
