@@ -149,7 +149,8 @@ static const bool g_prefetch = getenv("T4_FEED_PREFETCH") ? atoi(getenv("T4_FEED
 void Dataset::release_ring() {
     for (int i = 0; i < RING; i++) {
         if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]);
-        if (dbuf[i]) t4k_free(dbuf[i]); if (lbuf[i]) t4k_free(lbuf[i]);
+        if (dbuf[i]) t4k_free(dbuf[i]);
+        if (lbuf[i]) t4k_free(lbuf[i]);
         dbuf[i] = nullptr; lbuf[i] = nullptr; dev_bid[i] = -1;
     }
     mark_bid = -1;
