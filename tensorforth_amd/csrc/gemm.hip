@@ -1504,6 +1504,16 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
     }
     const int gn = n0 + wn * 32 + l31;
     float add[16];
+    // the epilogue's operands (bias, the old C of a beta != 0 product) are requested here, in front of the k-groups' meeting: behind it they
+    // were a memory round trip of their own at the very end of a single-wave launch (alpha / beta at 1024^3: 69.5 % of the MFMA peak)
+    float bv_ = 0.f, old[16];
+    if (EPI && kg == 0) {
+        bv_ = p.bias ? p.bias[gn] : 0.f;
+        if (p.beta != 0.f) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) old[r] = p.O[(long)(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + gn];
+        }
+    }
     __syncthreads();
     if (kg == 1) {
 #pragma unroll
@@ -1549,12 +1559,6 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
     }
     if (EPI) {
         const float alpha = p.alpha, beta = p.beta;
-        const float bv_ = p.bias ? p.bias[gn] : 0.f;
-        float old[16];
-        if (beta != 0.f) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) old[r] = p.O[(long)(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + gn];
-        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
