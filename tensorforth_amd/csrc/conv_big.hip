@@ -618,13 +618,13 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
                      int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f) {
     const long npix = (long)N * Hy * Wy;
     {   // stride 1, "same" padding, whole 64-channel stages: the 8-wave LDS-DMA kernel (k_convbig8)
-        // OFF by default: measured no gain over k_convbig on the CIFAR layers (N = 256: 64 -> 128 @ 16x16 forward 99.5 vs 96.0 us, dX 96.7 vs 97.7;
-        // 64 -> 64 @ 32x32 forward 234 vs 218 us - one 8-wave workgroup per CU hides a 9-stage loop's barriers worse than three 4-wave ones); kept for
-        // the parity tests that exercise it (T4K_CONVBIG8=1) and as the starting point for deeper (K >= 1152) layers
-        static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONVBIG8"); on = e ? atoi(e) : 0; }
+        // 1 (default): layers of at least 16 stages (K K Cin >= 1024) - measured on the CIFAR net (N = 256): the step 1.261 -> 1.220 ms with the 18- and
+        // 36-stage layers here (conv 128 -> 256 forward, the dX of both), while the 9-stage layers lose (64 -> 128 @ 16x16 forward 99.5 vs 96.0 us,
+        // 64 -> 64 @ 32x32 234 vs 218: one 8-wave workgroup per CU hides a short loop's barriers worse than three 4-wave ones); 2: every qualifying layer; 0: off
+        static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONVBIG8"); on = e ? atoi(e) : 1; }
         const bool shape = S == 1 && P == K / 2 && (K == 1 || K == 3 || K == 5) && Cin % 64 == 0 && Cout % 4 == 0 && Hx == Hy && Wx == Wy &&
                            aligned16(X) && aligned16(F) && st().d_zero && npix >= 128;
-        if (on && shape) {
+        if (on && shape && (on >= 2 || (long)K * K * Cin >= 1024)) {
             const int tiles_m = (int)((npix + 127) / 128);
             // 128-wide tiles when they still give every CU a workgroup, 64-wide otherwise (CIFAR conv3 dX: 128 -> 256 workgroups) and for 64 output channels
             const bool wide = Cout > 64 && (long)tiles_m * ((Cout + 127) / 128) >= (long)st().cu_count;

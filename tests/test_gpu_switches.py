@@ -95,9 +95,14 @@ def test_gated_kernels_while_another_stream_hogs_the_device(tmp_path):
 
 
 def test_opt_in_conv_kernel_on_the_lean_pipeline_matches_the_oracle():
-    """k_convbig8 (csrc/conv_big.hip: forward / dX of many-channel layers on the dense GEMM's 8-wave LDS-DMA pipeline) is off by default
-    (measured no gain on the CIFAR layers); T4K_CONVBIG8=1 routes every qualifying layer of the conv parity tests through it."""
-    env = dict(os.environ, T4K_CONVBIG8="1")
+    """k_convbig8 (csrc/conv_big.hip: forward / dX of many-channel layers on the dense GEMM's 8-wave LDS-DMA pipeline) takes layers of at least
+    16 stages by default; T4K_CONVBIG8=2 routes every qualifying layer of the conv parity tests through it, 0 none."""
+    for v in ("2", "0"):
+        _conv_tests(v)
+
+
+def _conv_tests(v):
+    env = dict(os.environ, T4K_CONVBIG8=v)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
                         "-k", "test_conv2d or many_channels or random_shapes"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
