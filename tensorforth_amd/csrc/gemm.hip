@@ -1349,7 +1349,7 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
 // The plain product O = A @ B (word `matmul`, tA = tB = 0, alpha = 1, beta = 0, no bias, interior 64x64 tiles, K % 128 == 0) has its own
 // copy of the 8-wave kernel with nothing else in it: the same loop inside the general template above measures 20.1 us at 1024^3, this
 // one 19.4 (tools/gemm_lab.hip: every variant with in-kernel cycle stamps; the loop is sensitive to the code around it).
-struct PlainP { const float *A, *B; float *O; int M, N, K; float alpha, beta; const float *bias; int *sync; float *part; };
+struct PlainP { const float *A, *B; float *O; int M, N, K; float alpha, beta; const float *bias; int *sync; float *part; int swap; };   // swap: tile order with the roles of M and N exchanged (lab: T4K_GEMM_TT_SWAP)
 // The other operand layouts (word `matmul` on transposed views; Tensor::linear tensor.cu:79-87 = X @ W^T + b with alpha / beta) get the same
 // lean kernel instead of the general template: AKC / BKC pick the operand layout (K-contiguous rows, read with ds_read_b128 through the
 // XOR swizzle, or k-major rows read per k), EPI adds alpha / beta / bias to the store.  Interior 64x64 tiles, K % 128 == 0, unsplit.
@@ -1373,9 +1373,10 @@ __global__ void __launch_bounds__(512) k_gemm_nn_plain(PlainP p) {
     const int tiles_m = M / BM, tiles_n = N / BN, T = tiles_m * tiles_n;
     int tm, tn;
     if (POW2) {                                             // power-of-two tile grid with T % 32 == 0 (1024^2: 16 x 16): the XCD-aware tile order in shifts -
-        const int tnb = 31 - __builtin_clz(tiles_n), b = blockIdx.x;     // the general form below costs three integer divisions (~400 cycles) before the first DMA
+        const int tnb = 31 - __builtin_clz(p.swap ? tiles_m : tiles_n), b = blockIdx.x;     // the general form below costs three integer divisions (~400 cycles) before the first DMA
         const int L = (b & 7) * (T >> 3) + (b >> 3), pg = 2 + tnb, r = L & ((1 << pg) - 1);
-        tm = ((L >> pg) << 2) + (r & 3); tn = r >> 2;
+        const int u = ((L >> pg) << 2) + (r & 3), v = r >> 2;
+        tm = p.swap ? v : u; tn = p.swap ? u : v;
     } else {
         int L;
         {
@@ -1597,6 +1598,7 @@ void launch_nn_plain(const GemmP &p, dim3 grid, hipStream_t s) {
 // any layout, alpha / beta / bias: interior tiles, K % 128 == 0, unsplit - or, pair = true, K % 256 == 0 and two workgroups per tile (the caller checks)
 void launch_plain_any(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s, bool pair = false, bool ragk = false) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, p.sync, p.part };
+    { static int sw = -1; if (sw < 0) { const char *e = getenv("T4K_GEMM_TT_SWAP"); sw = e ? atoi(e) : 0; } q.swap = (sw && tA && tB) ? 1 : 0; }
     const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias;
     const int tmq = p.M / 64, tnq = p.N / 64;
 #define T4K_PL(A_, B_) do { if (ragk) { if (epi) launch_plain_<A_, B_, true, false, true>(q, tmq, tnq, grid.x, s); else launch_plain_<A_, B_, false, false, true>(q, tmq, tnq, grid.x, s); } \
