@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) k_linsmall_bwd(const float *X, const floa
 // multiplies behind it.  No arrival gate stands between the dW readers and the dX writers any more (k_linsmall_bwd above: two dependent
 // agent-scope round trips on the critical path).  Only the in-place `out -= target` store of the loss preparation is shared: every workgroup
 // reports once it has staged dY, workgroup 0 stores it when all have (off everybody else's critical path; bounded spin).
-constexpr int LSC_CW = 8;
+constexpr int LSC_CW = 4;
 __global__ void __launch_bounds__(256) k_linsmall_bwd_cols(const float *X, const float *__restrict__ W, const float *DY, float *DX, float *DW, float *DB,
                                                            int N, int E0, int E1, int train, int *sync,
                                                            const float *__restrict__ MASK, float *__restrict__ DXM,
