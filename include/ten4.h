@@ -30,6 +30,11 @@ void *ten4_stream(ten4_vm *vm);
  * move the position (in elements) between evals - a data-parallel launcher that draws only its shard of a replicated tensor. */
 unsigned long long ten4_rand_tell(ten4_vm *vm);
 void ten4_rand_seek(ten4_vm *vm, unsigned long long element_offset);
+/* NOTE for hosts that also call the kernel library directly: because ten4_eval installs the VM's own (seed, position) on entry, a
+ * t4k_rand_init / t4k_rand_set_offset made between two evals is OVERRIDDEN by the next eval (and draws made through t4k_* entry points
+ * between evals do not advance the VM's position).  To change the VM's stream use ten4_rand_reseed (new seed, position 0) or
+ * ten4_rand_seek; the shard set by t4k_rand_set_shard is process-global and is not swapped. */
+void ten4_rand_reseed(ten4_vm *vm, unsigned long long seed);
 /* Copy the tensor on top of the data stack to host memory as fp32 (synchronises the VM stream).  Returns its element count (-1
  * when the top of stack is not a tensor); nothing is copied when cap < count or dst is NULL; shape = {H, W, C, N} if non-NULL.
  * Full-precision read-back for hosts and tests - the printer rounds to 4 decimals, `bin save` to 8 bits (aio_tensor.cpp:240-255). */

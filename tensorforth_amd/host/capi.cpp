@@ -46,6 +46,7 @@ int ten4_grad_slab(ten4_vm *, float **p, long *n) {
 void *ten4_stream(ten4_vm *) { return (void *)t4k_default_stream(); }
 unsigned long long ten4_rand_tell(ten4_vm *h) { return h->off; }
 void ten4_rand_seek(ten4_vm *h, unsigned long long off) { h->off = off; }
+void ten4_rand_reseed(ten4_vm *h, unsigned long long seed) { h->seed = seed; h->off = 0; }   // installed by the next ten4_eval (rng_enter)
 long ten4_fetch(ten4_vm *h, float *dst, long cap, int shape[4]) {
     t4::Tensor *t = h->vm.tos_tensor();
     if (!t) return -1;

@@ -43,6 +43,7 @@ class VM:
         so.ten4_rand_tell.restype = ctypes.c_ulonglong
         so.ten4_rand_tell.argtypes = [ctypes.c_void_p]
         so.ten4_rand_seek.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
+        so.ten4_rand_reseed.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]
         so.ten4_fetch.restype = ctypes.c_long
         so.ten4_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_int * 4)]
         so.ten4_store.restype = ctypes.c_long
@@ -66,6 +67,10 @@ class VM:
 
     def rand_seek(self, off):
         self._so.ten4_rand_seek(self._h, int(off))
+
+    def rand_reseed(self, seed):
+        """give the VM a new Philox stream (seed, position 0): what a t4k_rand_init between evals cannot do (ten4.h)"""
+        self._so.ten4_rand_reseed(self._h, int(seed))
 
     def fetch(self, expr=None):
         """Full-precision copy of the tensor `expr` leaves on top of the stack, as a numpy array shaped (N, H, W, C); the

@@ -131,3 +131,19 @@ def test_overlapped_slab_reduction_equals_in_order_training(tmp_path):
         outs.append(line[line.index("W6"):])
     assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0], outs
     assert all(np.isfinite(_num(outs[0], lab)) for lab in ("W6", "W8", "W0", "W3", "CE"))
+
+
+def test_reseeding_a_vm_restarts_its_own_stream():
+    """ten4_rand_reseed (include/ten4.h): the embedded VM's Philox stream is (seed, position) of the VM, installed by every ten4_eval - a host
+    that wants another stream says so to the VM (a t4k_rand_init between evals would be overridden)."""
+    import numpy as np
+    from tensorforth_amd.vm import VM
+    vm = VM(device=0, seed=77)
+    a = vm.fetch("64 vector rand"); vm.eval("drop\n")
+    b = vm.fetch("64 vector rand"); vm.eval("drop\n")
+    assert not np.array_equal(a, b)                      # the stream moved on
+    vm.rand_reseed(77)
+    assert np.array_equal(vm.fetch("64 vector rand"), a); vm.eval("drop\n")     # same seed, position 0 again
+    vm.rand_reseed(78)
+    assert not np.array_equal(vm.fetch("64 vector rand"), a); vm.eval("drop\n")
+    vm.close()
