@@ -8,24 +8,29 @@ using namespace t4k;
 
 namespace {
 
+// The update arithmetic is spelled out operation by operation (__fmul_rn / __fadd_rn ... : no fused multiply-add, IEEE division and root), in
+// the order of the reference's expressions as the oracle evaluates them (k_sgd / k_adam / k_adamw, nmath.cu:419-472; oracle built with
+// -ffp-contract=off).  Left to the compiler (-ffp-contract=fast) the same source contracted differently in different kernels - the fold-inside-
+// optimizer launch and the chunked launch must agree bit for bit (tests/test_gpu_deferred.py) - and differently from the oracle; spelled out,
+// every kernel that updates a parameter produces the oracle's bits.
 __device__ __forceinline__ void sgd1(float &g, float &dg, float &m, int Nw, float lr, float b, bool mom) {
-    const float d = dg / Nw;                               // Nw = parameter tensor's N, not batch (quirk a-19)
-    if (!mom) g -= lr * d;
-    else { m = b * m + (1.0f - b) * d; g -= lr * m; }
+    const float d = __fdiv_rn(dg, (float)Nw);              // Nw = parameter tensor's N, not batch (quirk a-19)
+    if (!mom) g = __fsub_rn(g, __fmul_rn(lr, d));
+    else { m = __fadd_rn(__fmul_rn(b, m), __fmul_rn(__fsub_rn(1.0f, b), d)); g = __fsub_rn(g, __fmul_rn(lr, m)); }
     dg = 0.0f;
 }
 __device__ __forceinline__ void adam1(float &g, float &dg, float &m, float &v, float lr, float b1, float b2) {
     const float d = dg;
-    m = b1 * m + (1.0f - b1) * d;
-    v = b2 * v + (1.0f - b2) * d * d;
-    g -= lr * m / (sqrtf(v) + DU_EPS);                     // no bias correction, eps outside sqrt
+    m = __fadd_rn(__fmul_rn(b1, m), __fmul_rn(__fsub_rn(1.0f, b1), d));
+    v = __fadd_rn(__fmul_rn(b2, v), __fmul_rn(__fmul_rn(__fsub_rn(1.0f, b2), d), d));
+    g = __fsub_rn(g, __fdiv_rn(__fmul_rn(lr, m), __fadd_rn(__fsqrt_rn(v), DU_EPS)));   // no bias correction, eps outside sqrt
     dg = 0.0f;
 }
 __device__ __forceinline__ void adamw1(float &g, float &dg, float &m, float &v, float lr, float b1, float b2, float wd) {
     const float d = dg;
-    m = b1 * m + (1.0f - b1) * d;
-    v = b2 * v + (1.0f - b2) * d * d;
-    g -= lr * (m / (sqrtf(v) + DU_EPS) - wd * d);
+    m = __fadd_rn(__fmul_rn(b1, m), __fmul_rn(__fsub_rn(1.0f, b1), d));
+    v = __fadd_rn(__fmul_rn(b2, v), __fmul_rn(__fmul_rn(__fsub_rn(1.0f, b2), d), d));
+    g = __fsub_rn(g, __fmul_rn(lr, __fsub_rn(__fdiv_rn(m, __fadd_rn(__fsqrt_rn(v), DU_EPS)), __fmul_rn(wd, d))));
     dg = 0.0f;
 }
 

@@ -345,7 +345,15 @@ def test_optimizers_and_multi_tensor_step(t4k, dev, oracle):
             o.t4o_adam(P(W), P(G), P(M), P(V), 1e-3, 0.9, 0.999, n); t4k.call("t4k_adam", p(dW), p(dG), p(dM), p(dV), 1e-3, 0.9, 0.999, n, None)
         else:
             o.t4o_adamw(P(W), P(G), P(M), P(V), 1e-3, 0.9, 0.999, 0.01, n); t4k.call("t4k_adamw", p(dW), p(dG), p(dM), p(dV), 1e-3, 0.9, 0.999, 0.01, n, None)
-        assert rel(dev.down(dW), W) < 1e-5 and rel(dev.down(dM), M) < 1e-5 and rel(dev.down(dV), V) < 1e-5
+        # optim.hip is compiled without floating-point contraction and spells the update out in the oracle's operation order: SGD (with and without
+        # momentum) and both moment tensors of Adam agree bit for bit; Adam's weights differ on a few elements per thousand by a rounding of the quotient (root / division)
+        got_w, got_m, got_v = dev.down(dW), dev.down(dM), dev.down(dV)
+        assert np.array_equal(got_m, M) and np.array_equal(got_v, V)
+        if kind in ("sgd0", "sgdm"):
+            assert np.array_equal(got_w, W)
+        else:
+            ulp = np.abs(got_w.view(np.int32).astype(np.int64) - W.view(np.int32).astype(np.int64))
+            assert (ulp != 0).mean() < 0.01 and rel(got_w, W) < 1e-6     # (an element that cancels to near zero shows a rounding of the quotient as many of ITS ulps)
         assert not dev.down(dG).any()                               # gradients zeroed by the step
     # multi-tensor launch == per-tensor launches
     sizes = [90, 10, 196000, 100, 1000, 10]
@@ -361,7 +369,7 @@ def test_optimizers_and_multi_tensor_step(t4k, dev, oracle):
     tab = dev.up(np.frombuffer(recs, np.uint8))
     t4k.call("t4k_opt_multi", 1, p(tab), len(sizes), max(sizes), 1e-3, 0.9, 0.999, 0.0, None)
     for dW, dG, dM, dV, W in bufs:
-        assert rel(dev.down(dW), W) < 1e-5 and not dev.down(dG).any()
+        assert rel(dev.down(dW), W) < 1e-6 and not dev.down(dG).any()
     # launch sized to the parameters (t4k_opt_chunked): `pad` = the tensor's first 1024-element chunk; SGD with momentum, second step
     bufs = []; recs = b""; chunk = 0
     for i, sz in enumerate(sizes):
@@ -373,7 +381,7 @@ def test_optimizers_and_multi_tensor_step(t4k, dev, oracle):
     tab = dev.up(np.frombuffer(recs, np.uint8))
     t4k.call("t4k_opt_chunked", 0, p(tab), len(sizes), chunk, 0.01, 0.9, 0.0, 0.0, None)
     for dW, dG, dM, W, M in bufs:
-        assert rel(dev.down(dW), W) < 1e-5 and rel(dev.down(dM), M) < 1e-5 and not dev.down(dG).any()
+        assert np.array_equal(dev.down(dW), W) and np.array_equal(dev.down(dM), M) and not dev.down(dG).any()
 
 
 def test_onehot_hit_u8(t4k, dev, oracle):
