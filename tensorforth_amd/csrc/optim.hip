@@ -85,12 +85,36 @@ __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_r
     const t4k_param_rec r = tab[i];
     const bool mom = !(fabsf(b1) < DU_EPS);
     const long j0 = ((long)blockIdx.x - r.pad) * 1024;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const long jv = j0 + 4 * threadIdx.x;
+    const bool vec = ((((uintptr_t)r.G | (uintptr_t)r.DG | (uintptr_t)r.M | (uintptr_t)r.V) & 15) == 0) && jv + 3 < r.n;
+    if (vec) {                                              // four consecutive elements per thread: 16-byte loads and stores, a quarter of the instructions
+        v4 g = *reinterpret_cast<const v4 *>(r.G + jv), dg = *reinterpret_cast<const v4 *>(r.DG + jv);
+        v4 m = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+        if (kind != 0 || mom) m = *reinterpret_cast<const v4 *>(r.M + jv);
+        if (kind != 0) v = *reinterpret_cast<const v4 *>(r.V + jv);
+        if (r.G == keep_src) *reinterpret_cast<v4 *>(keep_dst + jv) = g;        // the pre-update values of a snapshotted tensor
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const long j = j0 + q * BLK + threadIdx.x;
+        for (int q = 0; q < 4; q++) {
+            float gq = g[q], dq = dg[q], mq = m[q], vq = v[q];
+            if (kind == 0) sgd1(gq, dq, mq, r.Nw, lr, b1, mom);
+            else if (kind == 1) adam1(gq, dq, mq, vq, lr, b1, b2);
+            else adamw1(gq, dq, mq, vq, lr, b1, b2, wd);
+            g[q] = gq; m[q] = mq; v[q] = vq;
+        }
+        *reinterpret_cast<v4 *>(r.G + jv) = g;
+        const v4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<v4 *>(r.DG + jv) = z;
+        if (kind != 0 || mom) *reinterpret_cast<v4 *>(r.M + jv) = m;
+        if (kind != 0) *reinterpret_cast<v4 *>(r.V + jv) = v;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                           // ragged end of a tensor / unaligned tensors: element by element
+        const long j = jv + q;
         if (j >= r.n) break;
         float g = r.G[j], dg = r.DG[j];
-        if (r.G == keep_src) keep_dst[j] = g;                   // the pre-update value of a snapshotted tensor
+        if (r.G == keep_src) keep_dst[j] = g;
         if (kind == 0) {
             float m = mom ? r.M[j] : 0.f;
             sgd1(g, dg, m, r.Nw, lr, b1, mom);
