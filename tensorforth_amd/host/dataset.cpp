@@ -152,7 +152,9 @@ void Dataset::release_ring() {
         if (dbuf[i]) t4k_free(dbuf[i]);
         if (lbuf[i]) t4k_free(lbuf[i]);
         dbuf[i] = nullptr; lbuf[i] = nullptr; dev_bid[i] = -1;
+        if (staged[i]) { t4k_event_destroy(staged[i]); staged[i] = nullptr; }      // (Corpus::idle has dropped every reference to them)
     }
+    if (mark) { t4k_event_destroy(mark); mark = nullptr; }
     mark_bid = -1;
     data = nullptr; label = nullptr; ring_numel = 0;
 }
