@@ -154,6 +154,17 @@ def extras(vm_cls, local, ms_step, args, torch):
     t0 = time.perf_counter(); b.eval("100 steps\n"); torch.cuda.synchronize()
     out["batch1024_1gpu_ms_per_step"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
     b.close()
+    # ---- the net BASELINE config #4 names literally (examples/t4_40a.4th:10-13 `nn_c`: conv10-pool-relu-flatten-lin100-relu-lin10-softmax, N = 256, nn.adam):
+    # single-stage conv stack with the classifier head inside its forward, HBM-resident batch (its TensorBoard words are not part of the step)
+    c = vm_cls(device=local, seed=40)
+    txt = c.eval("0 trace\n256 28 28 1 nn.model 0.5 10 conv2d 2 maxpool relu flatten 100 linear relu 10 linear softmax constant net\n"
+                 "256 28 28 1 tensor rand constant img\n: hot ( T -- T ) 256 0 do 1 i 10 * i 7 * 10 mod + t! loop ;\n2560 vector zeros hot 256 1 10 1 reshape4 constant lbl\n"
+                 ": steps ( N n -- N ) 1- for img forward lbl backprop 0.001 nn.adam next ;\nnet 5 steps\n")
+    assert "?" not in txt.replace("-> ok", ""), txt
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); c.eval("200 steps\n"); torch.cuda.synchronize()
+    out["t4_40a_net_ms_per_step"] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
+    c.close()
     # ---- dataset-fed step: IDX file -> pinned double buffer (reader thread) -> one staging launch -> forward backprop nn.sgd
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as d:
