@@ -124,7 +124,7 @@ void Model::clear_dx0_marks() {
     if (dx0_lin_) {
         if (!layer.empty() && at(0).grad[0]) at(0).grad[0]->stale_owner = nullptr;
         if (dx0_dy_t_) dx0_dy_t_->stale_owner = nullptr;
-        dx0_lin_ = false; w0_saved_ = false; dx0_dy_ = nullptr; dx0_dy_t_ = nullptr;
+        dx0_lin_ = false; dx0_conv_ = false; w0_saved_ = false; dx0_dy_ = nullptr; dx0_dy_t_ = nullptr;
     }
 }
 void Model::materialize_dx0() {
@@ -132,7 +132,13 @@ void Model::materialize_dx0() {
     if (dx0_lin_) {
         Tensor &in = at(0), &o = at(1);
         const float *w = w0_saved_ ? w0_save_->data : in.grad[0]->data, *dy = dx0_dy_;
+        const bool conv = dx0_conv_;
         clear_dx0_marks();
+        if (conv) {                                     // dX into the scratch tensor and over x, as the eager launch leaves them (backprop.cu:185)
+            chk(t4k_conv2d_bwd2(in.data, dy, in.grad[4]->data, in.data, w, nullptr, nullptr, in.N(), in.H(), in.W(), in.C(), o.H(), o.W(), o.C(),
+                                in.grad[0]->H(), in.stride[0], in.stride[2], 0, stream()), "nn#bconv dX0");
+            return;
+        }
         chk(t4k_linear_bwd(in.data, w, dy, in.data, nullptr, nullptr, in.N(), (int)o.HWC(), (int)in.HWC(), 0, stream()), "nn#blinear dX0");
         return;
     }
@@ -734,6 +740,18 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
         Tensor &dx = *in.grad[4];
         const int N = in.N(), H1 = in.H(), W1 = in.W(), C1 = in.C(), H0 = out.H(), W0 = out.W(), C0 = out.C();
         const int K = in.grad[0]->H(), S = in.stride[0], P = in.stride[2];
+        if (i == 0 && train && use_lazy_dx0 && use_fusion && !(trace && *trace) && !concurrent() && !capturing_ && !use_graphs && in.grad[2] && in.grad[3]) {
+            // the net's first layer: nobody reads dX0 in a training loop - dF | dB now, dX0 when a word asks (materialize_dx0)
+            Tensor *holder = nullptr;
+            for (int k = 1; k < (int)layer.size() && !holder; k++) if (at(k).data == dy) holder = &at(k);
+            if (holder) {
+                chk(t4k_conv2d_bwd(in.data, dy, nullptr, in.grad[0]->data, in.grad[2]->data, in.grad[3]->data,
+                                   N, H1, W1, C1, H0, W0, C0, K, S, P, 1, s), "nn#bconv dF");
+                dx0_stale_ = true; dx0_lin_ = true; dx0_conv_ = true; w0_saved_ = false; dx0_dy_ = dy; dx0_dy_t_ = holder;
+                in.stale_owner = this; dx.stale_owner = this; in.grad[0]->stale_owner = this; holder->stale_owner = this;
+                return in.data;
+            }
+        }
         if (!concurrent()) {                            // one stream: dF|dB read x first, then dX lands in the scratch tensor AND over x
             chk(t4k_conv2d_bwd2(in.data, dy, dx.data, in.data, in.grad[0]->data, train ? in.grad[2]->data : nullptr, train ? in.grad[3]->data : nullptr,
                                 N, H1, W1, C1, H0, W0, C0, K, S, P, train, s), "nn#bconv");

@@ -310,7 +310,7 @@ private:
     // ... of a first LINEAR layer (dX0 = dY W, backprop.cu:240): the backward runs dW | dB only and remembers where dY lives; the weight
     // tensor and the tensor holding dY carry the mark too (a word that could change either produces dX0 first), and an optimizer step in
     // between leaves the pre-update weights in w0_save_ (t4k_opt_snapshot: the copy rides in the update launch)
-    bool dx0_lin_ = false, w0_saved_ = false;
+    bool dx0_lin_ = false, dx0_conv_ = false, w0_saved_ = false;   // dx0_lin_: a per-layer first layer (LINEAR, or CONV with dx0_conv_) rather than a conv stack
     const float *dx0_dy_ = nullptr;
     Tensor *dx0_dy_t_ = nullptr, *w0_save_ = nullptr;
     bool dp_in_opt_ = false;                   // this optimizer call sums the gradient slab over the ranks itself (one-shot peer exchange, t4k_opt_step_dp)
