@@ -1349,6 +1349,9 @@ __global__ void __launch_bounds__(512) k_gemm_glds8(GemmP p) {
 // The plain product O = A @ B (word `matmul`, tA = tB = 0, alpha = 1, beta = 0, no bias, interior 64x64 tiles, K % 128 == 0) has its own
 // copy of the 8-wave kernel with nothing else in it: the same loop inside the general template above measures 20.1 us at 1024^3, this
 // one 19.4 (tools/gemm_lab.hip: every variant with in-kernel cycle stamps; the loop is sensitive to the code around it).
+#ifndef T4K_GEMM_EARLY_ISSUE
+#define T4K_GEMM_EARLY_ISSUE 1      // k_gemm_plain128: stage kt + 2 requested right behind stage kt's closing barrier (0: at the top of stage kt + 1; 2048^2 x 1024: 67.7 -> 66.7 us).
+#endif                              // Measured and dropped: the same in k_gemm_nn_plain (19.1 -> 19.9 us at 1024^3), and the DMA instructions spread between the MFMAs of either kernel (-2..3 %)
 struct PlainP { const float *A, *B; float *O; int M, N, K; float alpha, beta; const float *bias; int *sync; float *part; int swap; };   // swap: tile order with the roles of M and N exchanged (lab: T4K_GEMM_TT_SWAP)
 // The other operand layouts (word `matmul` on transposed views; Tensor::linear tensor.cu:79-87 = X @ W^T + b with alpha / beta) get the same
 // lean kernel instead of the general template: AKC / BKC pick the operand layout (K-contiguous rows, read with ds_read_b128 through the
@@ -1612,7 +1615,9 @@ void launch_plain_any(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s, 
 // wave owns a 64x64 block (2x2 accumulators of 32x32): one A fragment feeds two MFMAs and so does one B fragment - half the LDS reads and half
 // the L2 -> LDS bytes per MFMA of the 64x64 tile, which is what limits that kernel once the fixed costs are amortised (2048^3: 80 %).
 // 64-deep double-buffered stages (64 KiB each).  Interior tiles, K % 64 == 0, unsplit; layouts and epilogue as k_gemm_nn_plain.
-template <bool AKC, bool BKC, bool EPI>
+// RAGK: K >= 256 with a partial last stage (784 = 12 x 64 + 16), as k_gemm_nn_plain<RAGK>: one more DMA stage in which only the lanes inside the
+// tail move anything, its 8-deep chunks alternate between the k-groups, positions past the tail zeroed in registers (2048 x 2048 x 784: 58.5 -> measured below).
+template <bool AKC, bool BKC, bool EPI, bool RAGK = false>
 __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
     constexpr int BM = 128, BN = 128, BK = 64;
     constexpr int NC = BK / 8, CH = BK / 4, NCG = NC / 2;
@@ -1637,6 +1642,7 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
         tm = first_m + (L % per_group) % gsz; tn = (L % per_group) / gsz;
     }
     const int m0 = tm * BM, n0 = tn * BN, nst = K / BK;
+    const int tail = RAGK ? K - nst * BK : 0;
     unsigned voffA[NJ], voffB[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -1654,6 +1660,17 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
+        }
+    };
+    auto issue_tail = [&](int buf) __attribute__((always_inline)) {        // stage nst: same lane offsets, lanes past the tail switched off (nothing read out of bounds)
+        const float *ba = p.A + (AKC ? (long)nst * BK : (long)nst * BK * M), *bb = p.B + (BKC ? (long)nst * BK : (long)nst * BK * N);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int i = w * NJ + j;
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + i * 256) * 4));
+            const bool kin = ((((lane & 15) ^ ((i * 4 + (lane >> 4)) & (CH - 1)))) << 2) < tail, rin = i * 2 + (lane >> 5) < tail;
+            if (AKC ? kin : rin) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
+            if (BKC ? kin : rin) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
         }
     };
     f32x16 acc[2][2];
@@ -1694,11 +1711,18 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
     float ca[2][4], cb[2][4];
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if T4K_GEMM_EARLY_ISSUE
+    if (nst > 1) issue(1, 1);                              // stage kt + 2 is requested right behind stage kt's closing barrier (its buffer is free from there on)
+    else if (RAGK && tail > 0) issue_tail(1);
+#endif
     rd(lds, lds + BM * BK, c0, ca, cb);
     int buf = 0;
     for (int kt = 0; kt < nst; kt++) {
         const int b1 = buf ^ 1;
+#if !T4K_GEMM_EARLY_ISSUE
         if (kt + 1 < nst) issue(kt + 1, b1);
+        else if (RAGK && tail > 0) issue_tail(b1);
+#endif
         const float *a = lds + buf * STAGE, *b = a + BM * BK;
 #pragma unroll
         for (int ci = 0; ci + 1 < NCG; ci++) {
@@ -1713,6 +1737,10 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
                 for (int j = 0; j < 4; j++) { ca[t][j] = na[t][j]; cb[t][j] = nbv[t][j]; }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if T4K_GEMM_EARLY_ISSUE
+        if (kt + 2 < nst) issue(kt + 2, buf);
+        else if (RAGK && tail > 0 && kt + 2 == nst) issue_tail(buf);
+#endif
         float na[2][4], nbv[2][4];
         if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, c0, na, nbv);
         __builtin_amdgcn_sched_barrier(0);
@@ -1724,6 +1752,20 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
                 for (int j = 0; j < 4; j++) { ca[t][j] = na[t][j]; cb[t][j] = nbv[t][j]; }
         }
         buf = b1;
+    }
+    if (RAGK && tail > 0) {                                  // the partial stage sits in `buf`, visible since the last barrier
+        const float *a = lds + buf * STAGE, *b = a + BM * BK;
+        const int nct = (tail + 7) >> 3;
+        for (int c = kg; c < nct; c += 2) {
+            float ta[2][4], tb[2][4];
+            rd(a, b, c, ta, tb);
+            const int k0 = c * 8 + 4 * h;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) { if (k0 + j >= tail) { ta[t][j] = 0.f; tb[t][j] = 0.f; } }
+            mm(ta, tb);
+        }
     }
     // the two k-groups meet in LDS (64 KiB: 4 waves x 64 accumulator registers x 64 lanes), group 0 stores
     __syncthreads();
@@ -1758,17 +1800,18 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
             }
         }
 }
-template <bool AKC, bool BKC, bool EPI>
+template <bool AKC, bool BKC, bool EPI, bool RAGK = false>
 void launch_plain128_(const PlainP &q, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)2 * 256 * 64 * sizeof(float);
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain128<AKC, BKC, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
-    T4K_LAUNCH((k_gemm_plain128<AKC, BKC, EPI>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain128<AKC, BKC, EPI, RAGK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
+    T4K_LAUNCH((k_gemm_plain128<AKC, BKC, EPI, RAGK>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
 }
 void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, nullptr, nullptr };
-    const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias;
-#define T4K_PL(A_, B_) do { if (epi) launch_plain128_<A_, B_, true>(q, s); else launch_plain128_<A_, B_, false>(q, s); } while (0)
+    const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias, ragk = p.K % 64 != 0;
+#define T4K_PL(A_, B_) do { if (ragk) { if (epi) launch_plain128_<A_, B_, true, true>(q, s); else launch_plain128_<A_, B_, false, true>(q, s); } \
+                            else if (epi) launch_plain128_<A_, B_, true>(q, s); else launch_plain128_<A_, B_, false>(q, s); } while (0)
     if (!tA && !tB) T4K_PL(true, false); else if (!tA) T4K_PL(true, true); else if (!tB) T4K_PL(false, false); else T4K_PL(false, true);
 #undef T4K_PL
 }
@@ -2138,9 +2181,10 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     // T4K_GEMM_PLAIN128: 0 off, 1 (default) where it wins, 2 every eligible shape (tests).  A workgroup per CU at a time either way, so the
     // choice is wave quantisation: tiles / (rounds x CUs) of each tiling, the 128x128 pipeline being ~3.5 % faster per FLOP (2048^3: 136 -> 131 us)
     static int p128 = -1; if (p128 < 0) { const char *e = getenv("T4K_GEMM_PLAIN128"); p128 = e ? atoi(e) : 1; }
+    static int p128rag = -1; if (p128rag < 0) { const char *e = getenv("T4K_GEMM_PLAIN128_RAGK"); p128rag = e ? atoi(e) : 1; }   // 0: a partial last K stage keeps the product on 64x64 tiles
     auto fill_of = [](long tiles_, long cu_) { return (double)tiles_ / (double)(((tiles_ + cu_ - 1) / cu_) * cu_); };
     const long t128i = (long)(M / 128) * (N / 128), t64i = (long)((M + 63) / 64) * ((N + 63) / 64);
-    if (p128 > 0 && vec && C == 1 && nsplit == 1 && !p.pair && !p.cs_X && (var & 4) && (var & 16) && (var & 32) && !(var & 64) && M % 128 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 256 &&
+    if (p128 > 0 && vec && C == 1 && nsplit == 1 && !p.pair && !p.cs_X && (var & 4) && (var & 16) && (var & 32) && !(var & 64) && M % 128 == 0 && N % 128 == 0 && (K % 64 == 0 || (p128rag && ragk_on && K % 4 == 0)) && K >= 256 &&
         (p128 >= 2 || (t128i >= st().cu_count && fill_of(t128i, st().cu_count) * 1.035 > fill_of(t64i, st().cu_count))) &&
         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
         p.kchunk = K;

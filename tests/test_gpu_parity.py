@@ -1199,7 +1199,9 @@ def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N,
 
 @pytest.mark.parametrize("M,N,K,tA,tB", [(2048, 2048, 2048, 0, 1), (1024, 4096, 2048, 1, 0), (2040, 2048, 2112, 1, 1),
                                          # 128x128 tiles on the lean pipeline (k_gemm_plain128): every layout, K in 64s, several tiles per CU, non-square tile grids
-                                         (2048, 2048, 512, 0, 0), (2048, 2048, 320, 1, 1), (2176, 4096, 256, 1, 0), (4096, 2304, 448, 0, 1)])
+                                         (2048, 2048, 512, 0, 0), (2048, 2048, 320, 1, 1), (2176, 4096, 256, 1, 0), (4096, 2304, 448, 0, 1),
+                                         # ... with a partial last K stage (k_gemm_plain128<RAGK>): tails of 16, 8 (one k-group idle), 44 (a partial chunk), 60
+                                         (2048, 2048, 784, 0, 1), (2048, 2048, 328, 1, 0), (2048, 2304, 300, 0, 0), (2304, 2048, 444, 1, 1), (2048, 2048, 784, 0, 0)])
 def test_gemm_large_transposed_products_exact_on_integer_operands(t4k, dev, M, N, K, tA, tB):
     """Large products with transposed operands and alpha / beta (the linear layers of an MLP) on the 8-wave LDS-DMA kernel, several 64x64
     tiles per CU, one shape with a ragged M: small-integer entries keep every fp32 sum exact, so the result equals the float64 product."""

@@ -40,7 +40,7 @@ def ints(*shape): return rng.integers(-2, 3, shape).astype(np.float32)
 fails = []
 for (M, N, K, tA, tB, al, be) in [(1024, 1024, 1024, 0, 0, 1.0, 0.0), (1024, 1024, 784, 0, 1, 1.0, 0.0), (512, 1024, 1024, 0, 1, 2.0, -1.0), (1000, 1028, 256, 0, 1, 2.0, -1.0),
                                   (996, 1000, 384, 1, 0, 1.0, 1.0), (40, 72, 64, 0, 1, 1.0, 0.0), (200, 100, 832, 0, 1, 2.0, -1.0), (256, 512, 784, 0, 1, 1.0, 0.0),
-                                  (2048, 2048, 256, 0, 0, 1.0, 0.0), (128, 100, 980, 0, 1, 1.0, 0.0),
+                                  (2048, 2048, 256, 0, 0, 1.0, 0.0), (2048, 2048, 328, 0, 1, 2.0, -1.0), (128, 100, 980, 0, 1, 1.0, 0.0),
                                   (1024, 1024, 784, 0, 0, 1.0, 0.0), (1024, 1024, 1004, 1, 1, 2.0, -1.0), (512, 512, 1812, 0, 1, 1.0, 0.0), (448, 512, 1050, 1, 0, 1.0, 1.0)]:
     A, B, O0 = ints(M, K), ints(K, N), rng.integers(-3, 4, (M, N)).astype(np.float32)
     want = al * (A.astype(np.float64) @ B.astype(np.float64)) + be * O0        # float64 BLAS: exact on these integers, and fast
@@ -75,7 +75,7 @@ SWITCHES = [{}, {"T4K_GEMM_L32": "0"}, {"T4K_GEMM_DUAL_L32": "0"}, {"T4K_GEMM_L3
             {"T4K_GEMM_FULLK": "0"}, {"T4K_GEMM_FASTPRO": "0"}, {"T4K_GEMM_RAGGED_DMA": "0"}, {"T4K_GEMM_PLAIN_BIG": "0"}, {"T4K_GEMM_BIG_DMA": "0"},
             {"T4K_GEMM_BIG_FULLK": "0"}, {"T4K_GEMM_DUAL_FULL": "0"}, {"T4K_GEMM_DUAL_FULLK": "0"}, {"T4K_GEMM_SPLIT_DIV": "2"}, {"T4K_GEMM_S32_NW8": "0"},
             {"T4K_GEMM_S32_MAXK": "256"}, {"T4K_GEMM_DUAL_MAXK": "256"}, {"T4K_GEMM_DUAL32_MAXK": "128"}, {"T4K_HEAD_FOLD": "0"}, {"T4K_LINSMALL_GATE": "0"}, {"T4K_LINSMALL_COLS": "0"}, {"T4K_LINSMALL_COLS": "2"},
-            {"T4K_GEMM_PLAIN_PAIR": "0"}, {"T4K_GEMM_PLAIN128": "0"}, {"T4K_GEMM_PLAIN128": "2"}, {"T4K_GEMM_PLAIN_RAGK": "0"}, {"T4K_GEMM_PLAIN_RAGK": "1"}, {"T4K_GEMM_PLAIN_ANY": "0"}, {"T4K_GEMM_PLAIN_ANY": "1"}, {"T4K_GEMM_RAGGED_K": "0"}, {"T4K_GEMM_RAGGED_K": "2"}, {"T4K_GEMM_RAGGED_K": "2", "T4K_GEMM_S32": "0"}, {"T4K_GEMM_VARIANT": "21"}, {"T4K_GEMM_VARIANT": "37"}, {"T4K_GEMM_VARIANT": "61"}, {"T4K_GEMM_VARIANT": "5"}]
+            {"T4K_GEMM_PLAIN_PAIR": "0"}, {"T4K_GEMM_PLAIN128": "0"}, {"T4K_GEMM_PLAIN128": "2"}, {"T4K_GEMM_PLAIN128_RAGK": "0"}, {"T4K_GEMM_PLAIN_RAGK": "0"}, {"T4K_GEMM_PLAIN_RAGK": "1"}, {"T4K_GEMM_PLAIN_ANY": "0"}, {"T4K_GEMM_PLAIN_ANY": "1"}, {"T4K_GEMM_RAGGED_K": "0"}, {"T4K_GEMM_RAGGED_K": "2"}, {"T4K_GEMM_RAGGED_K": "2", "T4K_GEMM_S32": "0"}, {"T4K_GEMM_VARIANT": "21"}, {"T4K_GEMM_VARIANT": "37"}, {"T4K_GEMM_VARIANT": "61"}, {"T4K_GEMM_VARIANT": "5"}]
 
 
 def _run(tmp_path, env_extra):
