@@ -17,6 +17,7 @@
 #include "t4k_common.h"
 #include <float.h>
 
+namespace t4k { bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs); }
 namespace t4k { bool conv_img_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
                                         int N, int H, int W, int C1, int C0, hipStream_t hs); }
 using namespace t4k;
@@ -804,6 +805,8 @@ int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, cons
         T4K_LAUNCH_CHECK();
         return T4K_OK;
     }
+    // image in, a full MFMA tile or two of channels out (3 -> 64): filter in registers, the layer-0 copy from the same launch (conv_img.hip)
+    if (K == 3 && S == 1 && P == 1 && H0 == H1 && W0 == W1 && ICOPY != O && conv_thin_fwd(I, ICOPY, O, F, B, N, H0, W0, C1, C0, t4k::S(s))) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (ICOPY) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, t4k::S(s)));
     if (conv_big_on() && conv_big_ok(C1, C0) && aligned16(I) && aligned16(F)) {       // many channels: LDS-staged GEMM tiling
         launch_conv_big<false>(K, S, P, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
@@ -889,7 +892,8 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         // enough slices that ~2000 waves are in flight (each wave then issues only a few batches of loads) without
         // inflating the partial slab the fold has to read: 512 workgroups in total across the (tap, c0) tiles
         const int tiles = ((nrow1 + 31) / 32) * ((C0 + 31) / 32);
-        int nslice = (512 + tiles - 1) / tiles; if (nslice > (rows + 3) / 4) nslice = (rows + 3) / 4; if (nslice < 1) nslice = 1;
+        static int dfwg = -1; if (dfwg < 0) { const char *e = getenv("T4K_CONV_DF_WG"); dfwg = e ? atoi(e) : 512; if (dfwg < 1) dfwg = 1; }
+        int nslice = (dfwg + tiles - 1) / tiles; if (nslice > (rows + 3) / 4) nslice = (rows + 3) / 4; if (nslice < 1) nslice = 1;
         while (nslice > 1 && (size_t)nslice * nrow1 * C0 * sizeof(float) > st().ws_bytes / 8) nslice >>= 1;
         const int rpw = (rows + nslice * 4 - 1) / (nslice * 4);
         nslice = (rows + rpw * 4 - 1) / (rpw * 4);

@@ -189,7 +189,8 @@ def test_reductions(t4k, dev, oracle):
 @pytest.mark.parametrize("K,S,P_", [(1, 1, 0), (3, 1, 1), (4, 2, 1), (5, 1, 2)])
 @pytest.mark.parametrize("N,H1,C1,C0", [(2, 6, 2, 3), (3, 14, 10, 20), (4, 28, 1, 10), (2, 8, 40, 72), (2, 10, 3, 16), (1, 12, 64, 33),
                                         (2, 8, 32, 64), (3, 10, 64, 32), (2, 6, 96, 128), (2, 9, 32, 20),    # these four: LDS-staged many-channel kernels
-                                        (2, 8, 64, 128), (3, 8, 128, 64), (1, 12, 128, 256), (5, 6, 64, 68)])   # round 4: 8-wave LDS-DMA kernel (64-channel stages; 128- and 64-wide tiles, ragged pixel / channel edges)
+                                        (2, 8, 64, 128), (3, 8, 128, 64), (1, 12, 128, 256), (5, 6, 64, 68),
+                                        (2, 10, 3, 64), (3, 9, 4, 64), (5, 7, 1, 64), (2, 11, 2, 64)])   # ... and the image-input layer with a full tile or two of output channels (k_conv_thin_fwd), odd grids, ragged last tile; the four before: round 4: 8-wave LDS-DMA kernel (64-channel stages; 128- and 64-wide tiles, ragged pixel / channel edges)
 def test_conv2d(t4k, dev, oracle, K, S, P_, N, H1, C1, C0):
     o = oracle.lib(); P = oracle.P
     rng = np.random.default_rng(K + N)
@@ -801,7 +802,7 @@ def test_plu_and_second_destination_entries(t4k, dev, oracle):
     dO, dO2 = dev.zeros(1000), dev.zeros(1000)
     t4k.call("t4k_tt_op2", oracle.SUB, p(dev.up(A)), p(dev.up(B)), p(dO), p(dO2), 1000, None)
     assert np.array_equal(dev.down(dO), A - B) and np.array_equal(dev.down(dO2), A - B)
-    for (N, H, C1, C0) in ((4, 12, 1, 10), (2, 8, 16, 8)):                       # direct image-input kernel / gather-MFMA kernel (+ copy launch)
+    for (N, H, C1, C0) in ((4, 12, 1, 10), (2, 8, 16, 8), (3, 10, 3, 64), (2, 9, 4, 64)):   # direct image-input kernel / gather-MFMA kernel (+ copy launch) / thin-input MFMA kernel (copy from its registers)
         X = rng.standard_normal((N, H, H, C1)).astype(np.float32); F = rng.standard_normal((C1, 3, 3, C0)).astype(np.float32)
         Bv = rng.standard_normal(C0).astype(np.float32); Y = np.zeros((N, H, H, C0), np.float32)
         o.t4o_conv2d_fwd(P(X), P(Y), P(F), P(Bv), N, H, H, C1, H, H, C0, 3, 1, 1)

@@ -101,8 +101,15 @@ def test_opt_in_conv_kernel_on_the_lean_pipeline_matches_the_oracle():
         _conv_tests(v)
 
 
-def _conv_tests(v):
-    env = dict(os.environ, T4K_CONVBIG8=v)
+def test_conv_parity_without_the_thin_input_kernel_and_with_other_grids():
+    """k_conv_thin_fwd (csrc/conv_img.hip: image in, 32 / 64 channels out) off -> the generic gather kernel takes those layers again; a workgroup cap of 1
+    makes one workgroup walk every tile (the pipelined loop at its longest), 100000 gives every wave a single tile (prologue + epilogue only)."""
+    for env in ({"T4K_CONV_THIN": "0"}, {"T4K_CONV_THIN_WG": "1"}, {"T4K_CONV_THIN_WG": "100000"}, {"T4K_CONV_THIN_NT": "0"}, {"T4K_CONV_DF_WG": "2048"}):
+        _conv_tests(None, env)
+
+
+def _conv_tests(v, extra=None):
+    env = dict(os.environ, **({"T4K_CONVBIG8": v} if v is not None else {}), **(extra or {}))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
-                        "-k", "test_conv2d or many_channels or random_shapes"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                        "-k", "test_conv2d or many_channels or random_shapes or second_destination"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
