@@ -17,6 +17,7 @@
 #include "t4k_common.h"
 #include <float.h>
 
+namespace t4k { bool conv_thin_df(const float *I, const float *DO, float *part, size_t part_bytes, int N, int H, int W, int C1, int C0, int *nslice, hipStream_t hs); }
 namespace t4k { bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs); }
 namespace t4k { bool conv_img_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
                                         int N, int H, int W, int C1, int C0, hipStream_t hs); }
@@ -887,7 +888,13 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
                 int rc = colsum_add(DO, DB, (long)N * H0 * W0, C0, hs); if (rc) return rc;
             }
         }
-        if (nbig == 0) {
+        int nthin = 0;
+        if (nbig == 0 && K == 3 && S == 1 && P == 1 && H0 == H1 && W0 == W1 &&          // image in, a tile or two of channels out: 32 pixels per wave and trip (conv_img.hip)
+            conv_thin_df(I, DO, ws_for(s), st().ws_bytes / 2, N, H0, W0, C1, C0, &nthin, hs)) {
+            const int ntot = nrow1 * C0;
+            fa.part = ws_for(s); fa.DF = DF; fa.DB = DB; fa.nslice = nthin; fa.ndf = ntaps * C0; fa.ntot = ntot; fa.nfold = (ntot + 3) / 4;
+        }
+        if (nbig == 0 && nthin == 0) {
         const int rows = N * H0;
         // enough slices that ~2000 waves are in flight (each wave then issues only a few batches of loads) without
         // inflating the partial slab the fold has to read: 512 workgroups in total across the (tap, c0) tiles

@@ -315,6 +315,63 @@ __global__ void __launch_bounds__(256) k_conv_thin_fwd(const float *__restrict__
     }
 }
 
+// ---- dF | dB of the same layer: dF[c1][tap][c0] += sum over pixels of x[pixel + tap][c1] * dO[pixel][c0], a 28 x 64 output reduced over N*H*W pixels.
+// The generic kernel (conv.hip, k_conv_df_mfma) walks an image row per wave in trips of 7 pixel pairs, each trip a dependent memory round trip
+// (38 us for 256 x 32 x 32 x 3 -> 64).  Here a wave takes 32 pixels at a time: all 16 gathers of its A row (lane = filter row c1 * 9 + tap, row
+// 9 * CIN fed 1.0 = dB; the MFMA's k pair = two adjacent pixels) and the 16 * NT loads of dO go out together, then 16 * NT MFMAs; the accumulators
+// live in registers across all of the wave's tiles, the four waves meet in LDS, one slab row per workgroup for k_conv_df_fold.
+template <int CIN, int NT>
+__global__ void __launch_bounds__(256) k_conv_thin_df(const float *__restrict__ X, const float *__restrict__ DO, float *__restrict__ part,
+                                                      int N, int H, int W, long ntile) {
+    constexpr int NTAP = 9 * CIN, COUT = NT * 32, NROW = NTAP + 1;
+    static_assert(NROW <= 32, "one MFMA row tile");
+    __shared__ float red[4][32][COUT];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, w = threadIdx.x >> 6;
+    const long gw = (long)blockIdx.x * 4 + w, GW = (long)gridDim.x * 4;
+    const long npix = (long)N * H * W;
+    const bool is_tap = l31 < NTAP, is_bias = l31 == NTAP;
+    const int ci = l31 / 9, tap = l31 - ci * 9, ky = tap / 3, kx = tap - ky * 3;
+    const int dko = is_tap ? ((ky - 1) * W + (kx - 1)) * CIN + ci : 0;
+    f32x16i acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    for (long T = gw; T < ntile; T += GW) {
+        const long p0 = T * 32 + h;                          // this lane half's pixels: p0, p0 + 2, ...
+        const unsigned q = (unsigned)(p0 < npix ? p0 : npix - 1), tq = q / (unsigned)W;
+        unsigned x = q - tq * (unsigned)W, y = tq % (unsigned)H;
+        float a[16], b[NT][16]; unsigned deadm = 0, okm = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const long pj = p0 + 2 * j;
+            const bool ok = pj < npix;
+            const bool dead = !ok || !is_tap || (ky == 0 && y == 0) || (ky == 2 && y == (unsigned)H - 1) || (kx == 0 && x == 0) || (kx == 2 && x == (unsigned)W - 1);
+            a[j] = X[dead ? 0 : pj * CIN + dko];
+            deadm |= (dead ? 1u : 0u) << j; okm |= (ok ? 1u : 0u) << j;
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t][j] = DO[(ok ? pj : 0) * COUT + t * 32 + l31];
+            x += 2; if (x >= (unsigned)W) { x -= (unsigned)W; y = y + 1 == (unsigned)H ? 0u : y + 1; }     // W >= 2 (the launcher checks)
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const bool ok = (okm >> j) & 1u;
+            const float av = is_bias ? (ok ? 1.f : 0.f) : ((deadm >> j) & 1u ? 0.f : a[j]);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ok ? b[t][j] : 0.f, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][t * 32 + l31] = acc[t][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NROW * COUT; e += 256) {
+        const int gt = e / COUT, gc = e - gt * COUT;
+        part[((long)blockIdx.x * NROW + gt) * COUT + gc] = (red[0][gt][gc] + red[1][gt][gc]) + (red[2][gt][gc] + red[3][gt][gc]);
+    }
+}
+
 } // namespace
 
 namespace t4k {
@@ -339,6 +396,27 @@ bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const
     }
 #undef T4K_THIN
 #undef T4K_THIN2
+    return true;
+}
+// dF | dB partial slabs of the same layer: true when launched here, *nslice = slab rows ((9 C1 + 1) x C0 floats each) for k_conv_df_fold
+bool conv_thin_df(const float *I, const float *DO, float *part, size_t part_bytes, int N, int H, int W, int C1, int C0, int *nslice, hipStream_t hs) {
+    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_THIN_DF"); on = e ? atoi(e) : 1; }
+    if (!on || C1 < 1 || C1 > 3 || (C0 != 32 && C0 != 64) || W < 2 || (long)N * H * W >= 0x7fffff00L) return false;
+    const long ntile = ((long)N * H * W + 31) / 32;
+    static int cap = -1; if (cap < 0) { const char *e = getenv("T4K_CONV_THIN_DF_WG"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 1; }
+    long wg = (ntile + 3) / 4; if (wg > cap) wg = cap;
+    while (wg > 1 && (size_t)wg * (9 * C1 + 1) * C0 * sizeof(float) > part_bytes) wg >>= 1;
+    if ((size_t)wg * (9 * C1 + 1) * C0 * sizeof(float) > part_bytes) return false;
+    const dim3 g((unsigned)wg), b(256);
+#define T4K_TDF(C_, T_) T4K_LAUNCH((k_conv_thin_df<C_, T_>), g, b, 0, hs, I, DO, part, N, H, W, ntile)
+    switch (C1 * 4 + C0 / 32) {
+    case 5: T4K_TDF(1, 1); break; case 6: T4K_TDF(1, 2); break;
+    case 9: T4K_TDF(2, 1); break; case 10: T4K_TDF(2, 2); break;
+    case 13: T4K_TDF(3, 1); break; case 14: T4K_TDF(3, 2); break;
+    default: return false;
+    }
+#undef T4K_TDF
+    *nslice = (int)wg;
     return true;
 }
 // true when the block was launched here (t4k_conv2d_block_fwd falls through to its other kernels otherwise)

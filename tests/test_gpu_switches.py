@@ -102,9 +102,10 @@ def test_opt_in_conv_kernel_on_the_lean_pipeline_matches_the_oracle():
 
 
 def test_conv_parity_without_the_thin_input_kernel_and_with_other_grids():
-    """k_conv_thin_fwd (csrc/conv_img.hip: image in, 32 / 64 channels out) off -> the generic gather kernel takes those layers again; a workgroup cap of 1
-    makes one workgroup walk every tile (the pipelined loop at its longest), 100000 gives every wave a single tile (prologue + epilogue only)."""
-    for env in ({"T4K_CONV_THIN": "0"}, {"T4K_CONV_THIN_WG": "1"}, {"T4K_CONV_THIN_WG": "100000"}, {"T4K_CONV_THIN_NT": "0"}, {"T4K_CONV_DF_WG": "2048"}):
+    """k_conv_thin_fwd / k_conv_thin_df (csrc/conv_img.hip: image in, 32 / 64 channels out) off -> the generic gather kernels take those layers again; a
+    workgroup cap of 1 makes one workgroup walk every tile (the pipelined loop at its longest), 100000 gives every wave a single tile."""
+    for env in ({"T4K_CONV_THIN": "0"}, {"T4K_CONV_THIN_WG": "1"}, {"T4K_CONV_THIN_WG": "100000"}, {"T4K_CONV_THIN_NT": "0"}, {"T4K_CONV_DF_WG": "2048", "T4K_CONV_THIN_DF": "0"},
+                {"T4K_CONV_THIN_DF_WG": "1"}, {"T4K_CONV_THIN_DF_WG": "100000"}):
         _conv_tests(None, env)
 
 
