@@ -379,6 +379,7 @@ namespace t4k {
 bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs) {
     static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_THIN"); on = e ? atoi(e) : 1; }
     if (!on || C1 < 1 || C1 > 4 || (C0 != 32 && C0 != 64) || (long)N * H * W >= 0x7fffff00L) return false;
+    if (!aligned16(I) || !aligned16(O) || (ICOPY && !aligned16(ICOPY))) return false;       // 16-byte pieces of the batch copy and of the output rows
     const long ntile = ((long)N * H * W + 31) / 32;
     static int cap = -1; if (cap < 0) { const char *e = getenv("T4K_CONV_THIN_WG"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 1; }
     long wg = (ntile + 3) / 4; if (wg > cap) wg = cap;         // a wave walks ntile / (4 wg) tiles with its filter in registers
