@@ -24,7 +24,9 @@ N 12 12 3 tensor rand constant x
 N 10 1 1 tensor rand constant T
 : show ( -- ) D 0 n@ dup sum . dup max . min . drop ;
 """
-NETS = {"linear": NET, "conv": NET_CONV}
+# the same with a full MFMA tile of output channels: forward / dF | dB on the thin-input kernels (csrc/conv_img.hip), layer-0 copy from the conv launch
+NET_CONV64 = NET_CONV.replace("0.5 8 conv2d", "0.5 64 conv2d")
+NETS = {"linear": NET, "conv": NET_CONV, "conv64": NET_CONV64}
 CASES = {
     "read-after-backprop": "D x forward T backprop show",
     "read-after-adam": "D x forward T backprop 0.001 0.5 nn.adam show",
