@@ -40,7 +40,7 @@ def ints(*shape): return rng.integers(-2, 3, shape).astype(np.float32)
 fails = []
 for (M, N, K, tA, tB, al, be) in [(1024, 1024, 1024, 0, 0, 1.0, 0.0), (1024, 1024, 784, 0, 1, 1.0, 0.0), (512, 1024, 1024, 0, 1, 2.0, -1.0), (1000, 1028, 256, 0, 1, 2.0, -1.0),
                                   (996, 1000, 384, 1, 0, 1.0, 1.0), (40, 72, 64, 0, 1, 1.0, 0.0), (200, 100, 832, 0, 1, 2.0, -1.0), (256, 512, 784, 0, 1, 1.0, 0.0),
-                                  (2048, 2048, 256, 0, 0, 1.0, 0.0), (2048, 2048, 328, 0, 1, 2.0, -1.0), (128, 100, 980, 0, 1, 1.0, 0.0),
+                                  (2048, 2048, 256, 0, 0, 1.0, 0.0), (2048, 2048, 328, 0, 1, 2.0, -1.0), (1024, 512, 256, 1, 1, 1.0, 0.0), (320, 1088, 384, 1, 1, 1.0, 0.0), (2048, 1024, 512, 1, 1, 1.0, 0.0), (128, 100, 980, 0, 1, 1.0, 0.0),
                                   (1024, 1024, 784, 0, 0, 1.0, 0.0), (1024, 1024, 1004, 1, 1, 2.0, -1.0), (512, 512, 1812, 0, 1, 1.0, 0.0), (448, 512, 1050, 1, 0, 1.0, 1.0)]:
     A, B, O0 = ints(M, K), ints(K, N), rng.integers(-3, 4, (M, N)).astype(np.float32)
     want = al * (A.astype(np.float64) @ B.astype(np.float64)) + be * O0        # float64 BLAS: exact on these integers, and fast
