@@ -18,6 +18,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include "t4k.h"
 #include "ten4_config.h"
 #include "sys.h"                    // t4base.h, util.h, io/aio.h, mu/mmu.h (tensor.h, dataset.h)
@@ -140,29 +141,46 @@ DU Tensor::loss(t4_loss op, Tensor &tgt) {
 }
 U32 Tensor::has_nan() { int *c = (int *)(scratch() + 8); warn(t4k_nan_inf(data, (long)numel, c, nullptr), "tensor#has_nan"); return (U32)read_int(c); }
 // :344-429  linear algebra: the reference's host loops over pivots run inside one launch each
-Tensor &Tensor::inverse(Tensor &A, Tensor &I) {
+Tensor &Tensor::inverse(Tensor &A, Tensor &I) {          // :344-369 (status word = failing column + 1, 0 = fine)
+    if (!A.is_square("A") || !I.is_square("I")) return A;
+    const int K = A.W();
+    INFO("  tensor#inverse [%d,%d]\n", K, K);
     int *st = (int *)(scratch() + 8);
-    warn(t4k_inverse(A.data, I.data, (int)A.H(), st, nullptr), "tensor#inverse");
-    if (read_int(st)) ERROR("tensor#inverse sigular!\n");
+    warn(t4k_inverse(A.data, I.data, K, st, nullptr), "tensor#inverse");
+    if (int z = read_int(st)) { ERROR("  tensor#inverse: singular matrix at column %d\n", z - 1); return A; }
     return I;
 }
-Tensor &Tensor::plu(Tensor &A, Tensor &I, int *d_piv) {
+Tensor &Tensor::plu(Tensor &A, Tensor &I, int *d_piv) {  // :371-398; A == I: no permutation matrix is produced (Tensor::det)
+    if (!A.is_square("A")) return A;
     int *st = (int *)(scratch() + 8);
-    warn(t4k_plu(A.data, I.data, d_piv, (int)A.H(), st, nullptr), "tensor#plu");
-    if (read_int(st)) ERROR("tensor#lu sigular!\n");
-    return A;
-}
-Tensor &Tensor::lu_inverse(Tensor &A, Tensor &I, int *d_piv) {
-    int *st = (int *)(scratch() + 8);
-    warn(t4k_lu_inverse(A.data, I.data, d_piv, (int)A.H(), st, nullptr), "tensor#lu_inverse");
+    warn(t4k_plu(A.data, (&A == &I) ? nullptr : I.data, d_piv, (int)A.W(), st, nullptr), "tensor#plu");
+    if (int z = read_int(st)) { ERROR("  tensor#plu: singular at column %d\n", z - 1); return A; }
     return I;
 }
-Tensor &Tensor::lu(Tensor &LU, bool get_u) { warn(t4k_lu_extract(LU.data, get_u, (int)LU.H(), nullptr), "tensor#lu"); return LU; }
-DU Tensor::det() {                                       // :432-452: log-sum of the pivots of a packed L\U copy
+Tensor &Tensor::lu_inverse(Tensor &A, Tensor &I, int *d_piv) {   // :400-417
+    if (!A.is_square("A") || !I.is_square("I")) return I;
+    const int K = A.W();
+    INFO("  tensor#lu_inverse [%d,%d]\n", K, K);
+    int *st = (int *)(scratch() + 8);
+    warn(t4k_lu_inverse(A.data, I.data, d_piv, K, st, nullptr), "tensor#lu_inverse");
+    if (int z = read_int(st)) ERROR("  tensor#plu: singular at column %d\n", z - 1);
+    return I;
+}
+Tensor &Tensor::lu(Tensor &LU, bool get_u) { if (!LU.is_square("LU")) return LU; warn(t4k_lu_extract(LU.data, get_u, (int)LU.H(), nullptr), "tensor#lu"); return LU; }
+DU Tensor::det() {                                       // :431-456: in-place P.L.U, sign of the permutation x sign of the pivots x exp(sum ln|u_jj|)
+    const int K = (int)H();
+    int *d_piv = nullptr; warn(t4k_malloc((void **)&d_piv, sizeof(int) * K), "tensor#det");
+    plu(*this, *this, d_piv);
+    std::vector<int> piv(K);
+    t4k_memcpy_d2h(piv.data(), d_piv, sizeof(int) * K, nullptr); t4k_sync(nullptr);
+    int cnt = 0; for (int i = 0; i < K; i++) if (piv[i] != i) cnt++;
+    const int sign = (cnt % 2 == 0) ? 1 : -1;
     float *ld = scratch() + 1; int *sg = (int *)(scratch() + 9);
-    warn(t4k_logdet(data, (int)H(), ld, sg, nullptr), "tensor#det");
+    warn(t4k_logdet(data, K, ld, sg, nullptr), "tensor#det");
     float l = 0.0f; t4k_memcpy_d2h(&l, ld, sizeof(float), nullptr); t4k_sync(nullptr);
-    DU v = (DU)read_int(sg) * expf(l);
+    const int dsign = read_int(sg);
+    t4k_free(d_piv);
+    DU v = expf(l) * sign * dsign;
     return SCALAR(v);
 }
 Tensor &Tensor::triu() { warn(t4k_lu_extract(data, 1, (int)H(), nullptr), "tensor#triu"); return *this; }
@@ -184,19 +202,35 @@ Tensor &MMU::tensor(U64 sz) {
 }
 Tensor &MMU::tensor(U32 h, U32 w) { Tensor &t = tensor((U64)h * w); t.reshape(h, w); return t; }
 Tensor &MMU::tensor(U32 n, U32 h, U32 w, U32 c) { Tensor &t = tensor((U64)n * h * w * c); t.reshape(n, h, w, c); return t; }
-void MMU::free(Tensor &t) { t4k_sync(nullptr); warn(t4k_free(t.data), "mmu#free"); t.data = nullptr; }
-Tensor &MMU::copy(Tensor &t0) {
-    Tensor &t1 = tensor(t0.numel);
-    DU *d = t1.data;
-    memcpy((void *)&t1, (void *)&t0, sizeof(Tensor));    // shape / rank / attributes of the source, own data block
-    t1.data = d; t1.nref = 1;
-    warn(t4k_memcpy_d2d(t1.data, t0.data, sizeof(DU) * t0.numel, nullptr), "mmu#copy");
-    return t1;
+void MMU::free(Tensor &t) {                              // mmu.cu:246-268: data block, the layer's parameter / moment / mask tensors, then the header
+    t4k_sync(nullptr);
+    if (t.data) warn(t4k_free(t.data), "mmu#free");
+    t.data = nullptr;
+    if (t.grad_fn != L_NONE) {
+        for (int i = 0; i < 4 && t.mtum[i]; i++) { if (t.mtum[i] == t.grad[i]) continue; free(*t.mtum[i]); }   // SGD's placeholders alias w, b
+        if (t.mtum[4]) free(*t.mtum[4]);
+        for (int i = 0; i < 4 && t.grad[i]; i++) free(*t.grad[i]);
+        if (t.grad[4]) free(*t.grad[4]);
+    }
+    _mpool.free(&t);
+}
+Tensor &MMU::copy(Tensor &t0) {                          // mmu.cu:273-297: attributes copied, not a layer any more, own data block
+    if (!t0.is_tensor()) return t0;
+    Tensor *t1 = (Tensor *)_mpool.malloc();
+    memcpy((void *)t1, (void *)&t0, sizeof(Tensor));
+    for (int i = 0; i < 5; i++) t1->grad[i] = t1->mtum[i] = NULL;
+    t1->grad_fn = L_NONE; t1->nref = 1;
+    void *d = nullptr; warn(t4k_malloc(&d, sizeof(DU) * t0.numel), "mmu#copy");
+    t1->data = (DU *)d;
+    warn(t4k_memcpy_d2d(t1->data, t0.data, sizeof(DU) * t0.numel, nullptr), "mmu#copy");
+    return *t1;
 }
 
 // ===================================================================================================== mu/dataset.cu:123-158
 void Dataset::_load(U8 *cp_data, U8 *cp_label, int n) {  // the loader's host buffers -> one H2D copy + u8 -> f32 on the GPU
     const long bytes = (long)n * (long)HWC();
+    if (!data) { void *d = nullptr; warn(t4k_malloc(&d, sizeof(DU) * (numel + 1)), "dataset#_load"); data = (DU *)d; }   // :133-136: sized once the corpus is known
+    if (!label) H_ALLOC(&label, N() * sizeof(U32));
     static void *stage = nullptr; static long cap = 0;
     if (bytes > cap) { if (stage) t4k_free(stage); warn(t4k_malloc(&stage, (size_t)bytes), "dataset#_load"); cap = bytes; }
     warn(t4k_memcpy_h2d(stage, cp_data, (size_t)bytes, nullptr), "dataset#_load");

@@ -233,7 +233,8 @@ void Model::_fstep(Tensor &in, Tensor &out) {
     case L_CONV:    _fconv(in, out); break;
     case L_LINEAR:  _flinear(in, out); break;
     case L_FLATTEN: out = in; break;
-    case L_DROPOUT: { Tensor &m = *in.grad[4]; System::rand(m.data, m.numel, UNIFORM); }   /* fall through */
+    case L_DROPOUT:                                       // the mask (forward.cu:100-103 RAND) is drawn by _factivate through t4k_dropout_mask:
+                                                          // keyed by sample, so N ranks x B draw the masks of 1 x N.B (include/t4k.h)
     case L_RELU: case L_TANH: case L_SIGMOID: case L_SELU: case L_LEAKYRL: case L_ELU: _factivate(in, out, fn); break;
     case L_SOFTMAX: _fsoftmax(in, out); break;
     case L_LOGSMAX: _flogsoftmax(in, out); break;
@@ -301,16 +302,20 @@ void Model::_bstep(Tensor &in, Tensor &out, bool last_layer) {
 }
 
 // ===================================================================================================== nn/gradient.cu:20-126
-Model &Model::grad_alloc(t4_optimizer op) {                // momentum / second-moment tensors, by optimizer
-    for (int i = 0; i < (int)numel - 1; i++) {
+Model &Model::grad_alloc(t4_optimizer op) {                // :19-59 momentum / second-moment tensors, by optimizer (as written: a model that
+    for (int i = 0; i < (int)numel - 1; i++) {             // took its first step with nn.sgd keeps mtum[2] = NULL for a later nn.adam)
         Tensor &in = (*this)[i];
         Tensor *w = in.grad[0], *b = in.grad[1];
-        if (!w || in.mtum[0]) continue;
-        auto like = [this](Tensor *t) -> Tensor * { if (!t) return NULL; Tensor &z = T4(*t); z.zeros(); return &z; };
         switch (op) {
-        case OPTI_SGD:  in.mtum[0] = w; in.mtum[1] = b; in.mtum[2] = w; in.mtum[3] = b; break;       // placeholders: never read (beta == 0)
-        case OPTI_SGDM: in.mtum[0] = like(w); in.mtum[1] = like(b); in.mtum[2] = in.mtum[0]; in.mtum[3] = in.mtum[1]; break;
-        default:        in.mtum[0] = like(w); in.mtum[1] = like(b); in.mtum[2] = like(w); in.mtum[3] = like(b); break;
+        case OPTI_SGD:  in.mtum[0] = w; in.mtum[2] = NULL; in.mtum[1] = b; in.mtum[3] = NULL; break;
+        case OPTI_SGDM:
+            if (w && !in.mtum[0]) { in.mtum[0] = &T4(*w).zeros(); in.mtum[2] = NULL; }
+            if (b && !in.mtum[1]) { in.mtum[1] = &T4(*b).zeros(); in.mtum[3] = NULL; }
+            break;
+        case OPTI_ADAM: case OPTI_ADAMW:
+            if (w && !in.mtum[0]) { in.mtum[0] = &T4(*w).zeros(); in.mtum[2] = &T4(*w).zeros(); }
+            if (b && !in.mtum[1]) { in.mtum[1] = &T4(*b).zeros(); in.mtum[3] = &T4(*b).zeros(); }
+            break;
         }
     }
     return *this;

@@ -978,18 +978,17 @@ int model_load(Model &m, const char *fname) {
     if (!f) { hprintf("} => failed to open for input\n"); return 1; }
     auto getline_ = [&](std::string &line) { line.clear(); int c; bool any = false; while ((c = fgetc(f)) != EOF) { any = true; if (c == '\n') break; line.push_back((char)c); } return any; };
     std::string line;
-    if (m.layer.size() <= 1) {                           // nothing to load into: the reference would rebuild the layers by replaying the file's
-        hprintf(" model load: no layers - build the network first (the layer section of a .t4 file is not replayed)\n");   // layer section as Forth source
-        fclose(f); return 2;                             // (aio_model.cpp:183-204, unfinished there: it ends with an undefined word)
-    }
+    if (m.layer.size() <= 1) {                           // nothing to load into.  The reference copies the file's layer section + " nn.load <file>" into the
+        fclose(f); return 2;                             // input buffer (aio_model.cpp:183-204), which System::readline clears before any VM reads it (sys.cpp:101-108;
+    }                                                    // `nn.load` is no word either): nothing is printed, nothing is loaded - observed on the reference's own VM
     while (getline_(line) && line.length()) {}           // skip the layer section (model already built)
     std::vector<float> h;
     int err = 0;
     auto rd = [&](Tensor &t) {
         while (getline_(line) && !line.length()) {}      // skip blank lines
-        if (line.size() < 3 || line[0] != '-' || line[1] != '-' || line[2] != '-') { hprintf(" model format error\n"); err = 1; return; }
+        if (line.size() < 3 || line[0] != '-' || line[1] != '-' || line[2] != '-') { hprintf(" model format error"); err = 1; return; }   // aio_model.cpp:211 (no newline there either)
         h.resize(t.numel);
-        if (fread(h.data(), sizeof(float), t.numel, f) != t.numel) { hprintf(" model format error (short read)\n"); err = 1; return; }
+        if (fread(h.data(), sizeof(float), t.numel, f) != t.numel) { hprintf(" model format error"); err = 1; return; }
         t.from_host(h.data(), t.numel);
     };
     const int L = (int)m.layer.size();

@@ -4,7 +4,7 @@
 // src/sys.cpp:230-273.  The file format is TensorBoard's own (public): a sequence of records
 //     uint64 length | uint32 masked_crc32c(length) | bytes[length] | uint32 masked_crc32c(bytes)
 // each holding a serialized `Event` protobuf { 1: wall_time f64, 2: step i64, 3: file_version str | 5: Summary { 1: Value* } },
-// Value { 1: tag, 2: simple_value f32 | 4: Image | 5: HistogramProto | 8: TensorProto, 9: SummaryMetadata }.
+// Value { 1: tag, 2: simple_value f32 | 5: HistogramProto | 8: TensorProto (text, images), 9: SummaryMetadata }.
 // Written from scratch as one flat byte builder; what follows the reference is behaviour, not code: the log layout
 // <logdir>/<run_id>/events.out.tfevents.<time>.<host>.<pid>.0, the `brain.Event:2` header record, scalars as simple_value,
 // and the histogram bucketing of writer.h:178-208 (an empty underflow bin at min, n equal-width bins, last limit = max + 1e-10),
@@ -118,7 +118,8 @@ struct Sink {
         PB ev; ev.f64(1, now()); ev.i64(2, step); ev.msg(5, sum);
         record(ev.b);
     }
-    static PB meta(const char *plugin) { PB pd; pd.str(1, plugin); PB md; md.msg(1, pd); return md; }
+    // SummaryMetadata { 1: PluginData { 1: plugin_name }, 4: data_class } (schema.h:72-119; the histogram's carries no data_class)
+    static PB meta(const char *plugin, int data_class = 0) { PB pd; pd.str(1, plugin); PB md; md.msg(1, pd); if (data_class) md.i64(4, data_class); return md; }
 };
 Sink *g_tb = nullptr;
 
@@ -141,11 +142,10 @@ void tb_scalar(const char *tag, float v) {               // EventWriter::add_sca
     PB val; val.str(1, tag); val.f32(2, v);
     g_tb->value(val);
 }
-void tb_text(const char *tag, const char *txt) {         // add_text writer.h:68-75: string tensor + plugin "text"
+void tb_text(const char *tag, const char *txt) {         // add_text writer.h:59-67 + schema.h:37-45,88-98: scalar DT_STRING tensor (no shape), plugin "text", DATA_CLASS_TENSOR
     if (!tb_active()) return;
-    PB dim; dim.i64(1, 1); PB shape; shape.msg(2, dim);
-    PB ten; ten.i64(1, 7 /* DT_STRING */); ten.msg(2, shape); ten.str(8, txt);
-    PB val; val.str(1, tag); val.msg(9, Sink::meta("text")); val.msg(8, ten);
+    PB ten; ten.i64(1, 7 /* DT_STRING */); ten.str(8, txt);
+    PB val; val.str(1, tag); val.msg(9, Sink::meta("text", 2)); val.msg(8, ten);
     g_tb->value(val);
 }
 void tb_histo(const char *tag, Tensor &t, int nb) {      // Summary::histo summary.cpp:103-112 + add_histo / _buckets writer.h:90-118,178-208
@@ -168,9 +168,12 @@ void tb_histo(const char *tag, Tensor &t, int nb) {      // Summary::histo summa
     g_tb->value(val);
 }
 static void tb_png(const char *tag, int w, int h, const std::vector<uint8_t> &rgb) {
+    // add_image writer.h:69-80 + schema.h:47-68,100-110: the Time-Series form - DT_STRING tensor of shape [3] holding width, height (decimal
+    // text) and the PNG bytes, then plugin "images" with DATA_CLASS_BLOB_SEQUENCE (tensor in front of the metadata, as the reference writes it)
     const Bytes png = png_rgb(w, h, rgb.data());
-    PB img; img.i64(1, h); img.i64(2, w); img.i64(3, 3); img.bytes(4, png.data(), png.size());
-    PB val; val.str(1, tag); val.msg(4, img);
+    PB dim; dim.i64(1, 3); PB shape; shape.msg(2, dim);
+    PB ten; ten.i64(1, 7 /* DT_STRING */); ten.msg(2, shape); ten.str(8, std::to_string(w)); ten.str(8, std::to_string(h)); ten.bytes(8, png.data(), png.size());
+    PB val; val.str(1, tag); val.msg(8, ten); val.msg(9, Sink::meta("images", 3));
     g_tb->value(val);
 }
 void tb_tile(const char *tag, Tensor &t, int per_row) {   // Summary::tile summary.cpp:66-101: N images on a grid, 2-pixel border, x 256 grey / RGB

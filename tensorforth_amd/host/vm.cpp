@@ -88,7 +88,7 @@ void VM::ds_next(uint32_t target) {                      // ForthVM::_ds_next ef
     if (d.type != T_DATASET) { pstr("RTOS is not a dataset?\n"); return; }
     Dataset &ds = (Dataset &)d;
     if (ds.done) { DU v = rs_pop(); DROP(v); ((Model &)m).tick(); }
-    else { ds.fetch(nullptr, false); ip_ = target; }      // serviced inline (reference: OP_FETCH + HOLD)
+    else { ds.fetch(nullptr, false); ip_ = target; hold_ = true; }   // serviced inline (reference: OP_FETCH + HOLD)
 }
 void VM::nest() {
     query_ = false;
@@ -177,8 +177,14 @@ bool VM::eval(const std::string &line) {
             compile_ = false; pos_ = line_.size();
             break;
         }
+        if (hold_) {                                     // VM::outer `if (state==HOLD) break;` + the cleared input buffer
+            static const bool warn = getenv("T4_HOLD_WARN") != nullptr;   // script hygiene (tests): name what the reference would drop too
+            if (warn) { size_t p = line_.find_first_not_of(" \t", pos_); if (p != std::string::npos && line_[p] != '\\') fprintf(stderr, "HOLD drops: %s\n", line_.c_str() + p); }
+            hold_ = false; pos_ = line_.size(); break;
+        }
     }
-    if (!compile_ && !stop_) ss_dump();
+    hold_ = false;
+    if (!compile_) ss_dump();                            // ForthVM::post eforth.cpp:67-71 (after `bye` too)
     st().sweep();                                        // objects marked by `.` are released once per line
     return !stop_;
 }
@@ -189,7 +195,7 @@ void VM::dot_obj(DU v) {
     if (o.type == T_MODEL) pstr(fmt_model((Model &)o)); else pstr(fmt_tensor((Tensor &)o));
 }
 void VM::dot(DU v) {
-    if (IS_OBJ(v)) { dot_obj(v); pstr(" "); st().mark_free(v); return; }
+    if (IS_OBJ(v)) { dot_obj(v); pstr(" "); st().mark_free(v); hold_ = true; return; }   // ForthVM::_print eforth.cpp:559-567
     char buf[48]; snprintf(buf, sizeof(buf), "%g", v);   // ostream << float, default precision 6
     std::string s = buf;
     if (fmt_w_ > (int)s.size()) s = std::string(fmt_w_ - s.size(), ' ') + s;
@@ -468,7 +474,7 @@ void VM::init_core() {
         pstr(b);
     });
     CODE("ms",    [this] { std::this_thread::sleep_for(std::chrono::milliseconds(POPi())); });
-    CODE("flush", [] { fflush(stdout); });
+    CODE("flush", [this] { fflush(stdout); hold_ = true; });
     CODE("sprintf", [this] {                             // ( n1 [n2 ..] addr u -- addr' u' )  eforth.cpp:576-611
         POPi(); std::string buf = (const char *)&pmem_[(uint32_t)POP()];
         auto t2s = [this](char c) {

@@ -38,6 +38,8 @@ private:
     uint32_t here_ = 16;                      // user area: pmem[0] = base
     uint32_t ip_ = 0;
     bool compile_ = false, stop_ = false, query_ = true;
+    bool hold_ = false;                       // a word asked for host service (reference: state = HOLD, eforth.h:85-92): the outer interpreter
+                                              // drops the rest of the input line (sys.cpp:101-108 clears the buffer after resume(), vm.cpp:59)
     std::string line_; size_t pos_ = 0;
     std::string out_;
     int fmt_w_ = 0;

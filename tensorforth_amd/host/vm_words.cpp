@@ -204,10 +204,13 @@ void VM::init_tensor() {
     // sys.cpp:145-215); here it fills the tensor on the stack from a raw file of the same element count (v = byte / 256).
     auto tsave = [this](bool load) {
         int mode = 0;
-        if (SP() > 2 && IS_OBJ(SS(-3))) mode = POPi();
+        if (SP() > 1 && IS_OBJ(SS(-2))) { /* ( T adr len ) */ }
+        else if (SP() > 2 && IS_OBJ(SS(-3))) mode = POPi();   // the reference's order of the two tests (tenvm.cpp:393-395): an object deeper in the stack is no mode
+        else { pstr("tensor adr len [mode]?\n"); return; }
         POPi(); uint32_t adr = (uint32_t)POPi();
         const char *fn = (const char *)&pmem_[adr];
         if (!TOS1T()) { pstr("tensor adr len [mode]?\n"); return; }
+        hold_ = true;                                    // syscall(OP_TSAVE / OP_TLOAD), tenvm.cpp:408
         Tensor &t = TTOS();
         if (load) {
             FILE *f = fopen(fn, "rb"); if (!f) { pstr(" failed to open for input\n"); return; }
@@ -253,16 +256,17 @@ void VM::init_tensor() {
             else if (!strcmp(nm, "image") && t) tb_image(tag.c_str(), *t);
             else if (!strcmp(nm, "embed") && t) tb_embed(tag.c_str(), *t);
             else { char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%s, tag=%s): not written by this sink\n", nm, tag.c_str()); pstr(b); }
-        } else {
-            char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%s, n=%g, i=%d%s%s), check TensorBoard param -tlogdir -rrun_id\n", nm, IS_OBJ(n) ? 0.0f : n, i,
-                                  has_tag ? ", tag=" : "", tag.c_str());
+        } else {                                         // System::_process_tb sys.cpp:234-253 without -t: op as the TB_OP number, n as the raw cell (an object prints its handle)
+            static const char *ops[] = {"init", "step", "scalar", "text", "image", "tile", "histo", "graph", "embed"};
+            int op = 0; while (op < 9 && strcmp(nm, ops[op])) op++;
+            char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%d, n=%g, i=%d, tag=%s)\n", op, n, i, tag.c_str());
             pstr(b);
         }
-        if (IS_OBJ(n)) st().mark_free(n);
+        if (IS_OBJ(n)) { st().mark_free(n); hold_ = true; }   // tenvm.cpp:418-420
     };
     CODE(".tbinit", [tb] { tb("init", 0, true); });
     CODE(".tbstep", [this] { int i = POPi(); if (tb_active()) { tb_step(i); return; }
-                             char b[96]; snprintf(b, sizeof(b), "  sys#tbx(op=step, i=%d), check TensorBoard param -tlogdir -rrun_id\n", i); pstr(b); });
+                             char b[96]; snprintf(b, sizeof(b), "  sys#tbx(op=1, n=0, i=%d), check TensorBoard param -tlogdir -rrun_id\n", i); pstr(b); });
     CODE(".scalar", [tb] { tb("scalar", 1, true); });
     CODE(".text",   [tb] { tb("text", 3, true); });
     CODE(".image",  [tb] { tb("image", 1, true); });
@@ -271,7 +275,7 @@ void VM::init_tensor() {
     CODE(".embed",  [tb] { tb("embed", 1, true); });
     CODE(".graph",  [this] {                              // ( N -- ) tenvm.cpp:611 -> sys.cpp:241: the model's layer list as a GraphDef event
         DU n = POP();
-        if (!tb_active()) { pstr("  sys#tbx(op=graph), check TensorBoard param -tlogdir -rrun_id\n"); return; }
+        if (!tb_active()) { char b[120]; snprintf(b, sizeof(b), "  sys#tbx(op=7, n=%g, i=0), check TensorBoard param -tlogdir -rrun_id\n", n); pstr(b); return; }
         if (is_m(n)) tb_graph((Model &)st().du2obj(n)); else pstr("summary#graph requires model\n");
     });
     CODE(".png",    [this] { POPi(); POPi(); pstr("  .png: n/a\n"); });
@@ -450,6 +454,7 @@ void VM::init_nn() {
         Dataset &ds = st().dataset((uint32_t)POPi());
         PUSH(ds);
         ds.fetch(name.c_str(), false);                   // loads batch 0 immediately (sys.cpp:166-174)
+        hold_ = true;
     });
     CODE("normalize", [this] {                           // ( DS mean scale -- DS' ) on a dataset, else the tensor word
         if (SP() > 1 && is_d(SS(-2))) {
@@ -457,10 +462,11 @@ void VM::init_nn() {
             Dataset &ds = (Dataset &)st().du2obj(tos_);
             char b[96]; snprintf(b, sizeof(b), "  OP_NORM(mean=%d, scale=%g)\n", mean, scale); pstr(b);
             ds.set_norm((DU)mean, scale); ds.fetch(nullptr, true);
+            hold_ = true;
         } else { DU std = POP(), avg = POP(); if (TOS1T()) TTOS().normalize(std, avg); }
     });
-    CODE("fetch",  [this] { if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, false); });
-    CODE("rewind", [this] { if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, true); });
+    CODE("fetch",  [this] { if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, false); hold_ = true; });
+    CODE("rewind", [this] { if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, true); hold_ = true; });
     CODE("forward", [this] {                             // netvm.cpp:230-247
         if (is_m(SS(-1)) && TOS1D()) {
             DU x = POP();
@@ -500,10 +506,13 @@ void VM::init_nn() {
     CODE("nn.b=", [this] { set_parm(1); });
     CODE("flatten", [this] { nnop(T4K_L_FLATTEN); });
     auto pickle = [this](bool save) {                    // ( N adr len [mode] -- N )  model persistence is a "next" row
-        if (SP() > 2 && IS_OBJ(SS(-3))) POPi();          // optional mode (raw formats: TODO in the reference too)
+        if (SP() > 1 && IS_OBJ(SS(-2))) { /* ( N adr len ) */ }
+        else if (SP() > 2 && IS_OBJ(SS(-3))) POPi();     // optional mode (raw formats: TODO in the reference too); netvm.cpp:139-141, in that order
+        else { pstr("(model|tensor) adr len [mode]?\n"); return; }
         POPi(); const uint32_t adr = (uint32_t)POPi();
         const char *fn = (const char *)&pmem_[adr];
         if (!is_m(tos_)) return;
+        hold_ = true;                                    // syscall(OP_NSAVE / OP_NLOAD), netvm.cpp:148-152
         if (save) model_save(MTOS(), fn); else model_load(MTOS(), fn);
     };
     CODE("save", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(true); else { int w = 0; for (int i = 1; i < (int)dict_.size(); i++) if (dict_[i].name == "save") { w = i; break; } if (w) dict_[w].xt(); } });

@@ -23,6 +23,7 @@ net 3 steps
 ." w0_all " 0 nn.w .
 img forward ." ce " lbl loss.ce . ." hit " nn.hit .
 ." out " -1 n@ sum . drop
-fb ." dw10 " 10 nn.dw . ." db3 " 3 nn.db sum . drop ." dx " 0 n@ sum . drop
+fb ." dw10 " 10 nn.dw .
+." db3 " 3 nn.db sum . drop ." dx " 0 n@ sum . drop
 drop
 bye

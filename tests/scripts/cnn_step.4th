@@ -22,7 +22,16 @@ lbl backprop
 0.01 0.0 nn.sgd
 ." w0 " 0 nn.w .
 ." b8 " 8 nn.b .
-img forward lbl backprop 0.001 nn.adam
-." w0a " 0 nn.w .
+img forward lbl backprop 0.01 0.0 nn.sgd
 img forward ." probs2 " -1 n@ .
+drop
+\ Adam on a model of its own: the reference sizes the moment tensors at a model's FIRST optimizer step (gradient.cu:87), so one model keeps one optimizer
+4 28 28 1 nn.model
+0.5 10 conv2d 2 maxpool relu
+flatten 10 linear softmax
+constant net2
+net2 img forward lbl backprop 0.001 nn.adam
+." w0a " 0 nn.w .
+img forward lbl backprop 0.001 nn.adam
+img forward ." probs3 " -1 n@ .
 bye

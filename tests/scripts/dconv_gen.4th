@@ -8,7 +8,9 @@ gen network
 z forward ." mid " 1 n@ sum . drop ." out " -1 n@ sum . drop
 tgt loss.mse ." mse " .
 tgt backprop
-." g_b0 " 0 nn.db . ." g_w0 " 0 nn.dw sum . drop ." g_b2 " 2 nn.db . ." g_w2 " 2 nn.dw sum . drop ." dz " 0 n@ sum . drop
+." g_b0 " 0 nn.db .
+." g_w0 " 0 nn.dw sum . drop ." g_b2 " 2 nn.db .
+." g_w2 " 2 nn.dw sum . drop ." dz " 0 n@ sum . drop
 0.01 nn.adam
 ." w2 " 2 nn.w sum . drop ." b0 " 0 nn.b .
 z forward tgt loss.mse ." mse2 " .

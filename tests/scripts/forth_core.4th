@@ -1,4 +1,5 @@
 \ scalar eForth words (no tensor kernels): arithmetic, logic, loops, defining words, strings
+0 trace
 1 2 3 rot .s drop drop drop
 10 3 /mod . . 7 2 mod . -7 abs . 5 negate . 9 sqrt . 2 3 max . 2 3 min .
 1949 1461 4 */mod . .

@@ -25,7 +25,8 @@ drop
 4 1 6 1 tensor randn constant x
 4 vector{ 1 0 1 0 } constant t1
 reg x forward t1 broadcast ." hot " nn.onehot . 
-backprop ." reg_db " 2 nn.db . ." reg_dw0 " 0 nn.dw .
+backprop ." reg_db " 2 nn.db .
+." reg_dw0 " 0 nn.dw .
 drop
 \ upsample (nearest) in front of a conv: forward shape and values, backward gradient
 2 4 4 1 nn.model 2 upsample 0.5 2 conv2d constant up

@@ -65,9 +65,18 @@ def _cnn_step_vs_numpy(binary, oracle, env=None):
     m.sgd(0.01, 0.0)
     _close(numbers_after(out, "w0", 90), L[0].w)
     _close(numbers_after(out, "b8", 10), L[8].b)
-    m.forward(img); m.backprop(hot); m.adam(0.001)
-    _close(numbers_after(out, "w0a", 90), L[0].w)
+    m.forward(img); m.backprop(hot); m.sgd(0.01, 0.0)
     _close(numbers_after(out, "probs2", 40), m.forward(img), tol=1e-3)
+    # the script's second model (Adam from its first step on) is built later in the SAME random stream
+    import ctypes
+    lib = oracle.lib(); lib.t4o_rand_offset.restype = ctypes.c_uint64; lib.t4o_rand_set_offset.argtypes = [ctypes.c_uint64]
+    off = lib.t4o_rand_offset()
+    m2 = oracle.OracleModel(4, 28, 28, 1, seed=1); lib.t4o_rand_set_offset(off)
+    m2.conv2d(10, 0.5).maxpool(2).relu().flatten().linear(10).softmax()
+    m2.forward(img); m2.backprop(hot); m2.adam(0.001)
+    _close(numbers_after(out, "w0a", 90), m2.layers[0].w)
+    m2.forward(img); m2.backprop(hot); m2.adam(0.001)
+    _close(numbers_after(out, "probs3", 40), m2.forward(img), tol=1e-3)
 
 
 def test_train_loop_script_with_dropout_momentum_and_adam_equals_numpy_model(oracle_vm, oracle):

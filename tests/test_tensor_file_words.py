@@ -17,12 +17,13 @@ VALS = [0.5, 0.25, 0.125, 0.75, 0.999, 0.0, 0.00390625, 0.0039, 0.3333333, 0.999
 def _script(d):
     lit = " ".join(repr(v) for v in VALS)
     return ("0 trace\n12 vector{ %s } 1 2 3 2 reshape4 constant t\n" % lit +
-            't s" %s/raw.t4" bin save drop\n' % d +
-            't s" %s/txt.txt" save drop\n' % d +
-            '1 2 3 2 tensor zeros s" %s/raw.t4" load ." back " . \n' % d +
-            '12 vector zeros s" %s/raw.t4" load ." flat " . \n' % d +               # same element count, other shape: filled
-            '5 vector ones s" %s/raw.t4" load ." five " . \n' % d +                 # element count differs: refused, tensor untouched
-            '30 30 matrix ones 0.5 *= s" %s/big.txt" save drop\n' % d +
+            # `save` / `load` ask for host service: like the reference (HOLD, eforth.h:85-92) the VM drops the rest of an interpreted line after them
+            't s" %s/raw.t4" bin save\ndrop\n' % d +
+            't s" %s/txt.txt" save\ndrop\n' % d +
+            '1 2 3 2 tensor zeros s" %s/raw.t4" load\n." back " . \n' % d +
+            '12 vector zeros s" %s/raw.t4" load\n." flat " . \n' % d +             # same element count, other shape: filled
+            '5 vector ones s" %s/raw.t4" load\n." five " . \n' % d +               # element count differs: refused, tensor untouched
+            '30 30 matrix ones 0.5 *= s" %s/big.txt" save\ndrop\n' % d +
             "bye\n")
 
 

@@ -67,7 +67,8 @@ def event(step, value):
     return f_f64(1, T0) + f_i64(2, step) + f_len(5, f_len(1, value))
 
 
-def meta(plugin): return f_len(1, f_len(1, plugin.encode()))
+def meta(plugin, data_class=0):                            # SummaryMetadata { 1: PluginData { 1: plugin_name }, 4: data_class } (reference src/tb/schema.h:72-119)
+    return f_len(1, f_len(1, plugin.encode())) + (f_i64(4, data_class) if data_class else b"")
 
 
 def histo_value(tag, xs, nb):
@@ -144,14 +145,17 @@ def _byte_exact(binary, tmp_path):
     recs = records(blob)                                        # framing + both crcs of every record
     tile = np.array([0, 0.25, 0.5, 0.75, 1, 0.125, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5], np.float32).reshape(2, 2, 3, 1)
     WT, HT, px = tile_pixels(tile, 2)
-    img = f_i64(1, HT) + f_i64(2, WT) + f_i64(3, 3) + f_len(4, png_stored(WT, HT, px))
-    text_tensor = f_i64(1, 7) + f_len(2, f_len(2, f_i64(1, 1))) + f_len(8, b"epoch three")
+    # the reference's writer as of this tree (src/tb/writer.h:59-80, schema.h:37-68): text = scalar DT_STRING tensor + plugin "text" with DATA_CLASS_TENSOR;
+    # images = DT_STRING tensor of shape [3] { width, height, PNG } in front of plugin "images" with DATA_CLASS_BLOB_SEQUENCE.  tests/test_refhost_parity.py
+    # holds the same bytes as written by the reference's own code.
+    img_tensor = f_i64(1, 7) + f_len(2, f_len(2, f_i64(1, 3))) + f_len(8, str(WT).encode()) + f_len(8, str(HT).encode()) + f_len(8, png_stored(WT, HT, px))
+    text_tensor = f_i64(1, 7) + f_len(8, b"epoch three")
     want = [
         f_f64(1, T0) + f_i64(2, 0) + f_len(3, b"brain.Event:2"),
         event(3, f_len(1, b"train/loss") + f_f32(2, 0.5)),
         event(3, histo_value("nn/w", [-1, 0, 0.25, 0.5, 1, 2, 2, 3], 4)),
-        event(3, f_len(1, b"notes") + f_len(9, meta("text")) + f_len(8, text_tensor)),
-        event(7, f_len(1, b"imgs") + f_len(4, img)),
+        event(3, f_len(1, b"notes") + f_len(9, meta("text", 2)) + f_len(8, text_tensor)),
+        event(7, f_len(1, b"imgs") + f_len(8, img_tensor) + f_len(9, meta("images", 3))),
         event(7, f_len(1, b"train/loss") + f_f32(2, 1.5)),
     ]
     assert len(recs) == len(want)
@@ -217,4 +221,7 @@ def test_graph_event_and_projector_files_from_the_product_vm(tmp_path):
 def test_words_only_hint_without_a_log_directory(oracle_vm):
     env = {k: v for k, v in os.environ.items() if not k.startswith("T4_TB_")}
     r = subprocess.run([oracle_vm], input='0.5 s" x" .scalar\n3 .tbstep\nbye\n', capture_output=True, text=True, env=dict(env, T4_SEED="1"), timeout=60)
-    assert r.stdout.count("check TensorBoard param -tlogdir -rrun_id") == 2
+    # the reference's texts (System::_process_tb sys.cpp:234-253, confirmed on its own VM by tests/test_refhost_parity.py): tagged ops echo op / n / i / tag,
+    # the untagged ones (.tbstep, .graph) add the hint
+    assert "  sys#tbx(op=2, n=0.5, i=0, tag=x)\n" in r.stdout
+    assert "  sys#tbx(op=1, n=0, i=3), check TensorBoard param -tlogdir -rrun_id\n" in r.stdout

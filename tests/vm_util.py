@@ -186,4 +186,9 @@ def synth_mnist_dir(tmp_path_factory):
     # ... and ./data/CIFAR10/cifar-10-batches-bin with the synthetic CIFAR-10-shaped batches (seed 7 / 8)
     subprocess.run(["python3", os.path.join(ROOT, "tools", "make_synth_cifar.py"), os.path.join(str(d), "data", "CIFAR10", "cifar-10-batches-bin"), "256", "64"],
                    check=True, capture_output=True)
+    # model files the REFERENCE's saver wrote (tests/golden/refhost/, tools/regen_vm_goldens.py): tests/scripts/model_load_ref.4th loads one by relative name
+    import glob
+    import shutil
+    for f in glob.glob(os.path.join(ROOT, "tests", "golden", "refhost", "*.t4")):
+        shutil.copy(f, str(d))
     return str(d)

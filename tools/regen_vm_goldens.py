@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/vm/*.out (and tests/golden/refhost/*) FROM THE REFERENCE'S OWN HOST CODE.
+
+Build container only.  `make -C oracle refhost` compiles the reference's 17 host sources where they lie under /root/reference/src
+and links them with the reference-side binding (integration/t4k_bind*.cpp) over the CPU implementation of include/t4k.h
+(oracle/t4k_on_oracle.cpp): oracle/_ref/ten4_refhost is the reference's real VM, printer, layer factory, dataset loaders, model saver
+and TensorBoard writer running on the oracle's arithmetic.  Every tests/scripts/*.4th is replayed through it with T4_SEED=1 and its
+stdout, normalised as below, becomes the committed golden the product VM is compared with on the GPU (tests/test_vm_scripts.py) and the
+oracle VM on the CPU.  Normalisation: the start-up chatter up to the `\\ MMU.stat` line is replaced by the banner line, the `vm0>` trace
+lines the reference prints while `0 trace` itself executes are dropped, the tear-down lines become the product's trailer.
+
+Scripts in HAZARD are decided reference hazards (SURVEY.md 9 / DESIGN.md 7): their numbers come from the oracle VM (the product's
+host over the oracle) because the reference's code path does not compute anything meaningful there; tests/test_refhost_parity.py still
+requires every non-numeric token (layer tables, prompts, shapes) to equal the reference VM's.
+
+Also written: tests/golden/refhost/ref_model_roundtrip.t4 - a model file saved by the reference's aio_model.cpp (f-2 interop fixture:
+the product must load it and reproduce the forward output), and tests/golden/refhost/tb_events.tfevents - the tfevents file of the
+reference's src/tb writer for tests/scripts_tb/tb_words.4th under a pinned clock (f-4: byte equality)."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFHOST = os.path.join(ROOT, "oracle", "_ref", "ten4_refhost")
+FIXTIME = os.path.join(ROOT, "oracle", "_ref", "libfixedtime.so")
+ORACLE_VM = os.path.join(ROOT, "oracle", "ten4_oracle")
+HAZARD = {"dconv_gen", "hazards"}          # numbers from the oracle VM (see docstring)
+TB_TIME = "1700000000"
+
+
+def normalise_refhost(text):
+    i = text.index("\\ MMU.stat")
+    body = text[text.index("\n", i) + 1:]
+    keep = [l for l in body.splitlines() if not l.startswith("vm0> ")]
+    out = []
+    for l in keep:
+        if l.startswith("\\ VM[] freed"):
+            break
+        out.append(l)
+    return "tensorForth v4.0\n" + "\n".join(out) + "\n\ntensorForth done.\n"
+
+
+def normalise_oracle_vm(text):
+    lines = text.splitlines()
+    return "tensorForth v4.0\n" + "\n".join(lines[1:]) + "\n"
+
+
+def workdir():
+    d = tempfile.mkdtemp(prefix="t4gold")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_mnist.py"), os.path.join(d, "data", "MNIST", "raw"), "1024", "256"], check=True, capture_output=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_cifar.py"), os.path.join(d, "data", "CIFAR10", "cifar-10-batches-bin"), "256", "64"], check=True, capture_output=True)
+    for f in glob.glob(os.path.join(ROOT, "tests", "golden", "refhost", "*.t4")):
+        shutil.copy(f, d)
+    return d
+
+
+def run(binary, script, cwd, args=(), preload=False, seed=1):
+    env = dict(os.environ, T4_SEED=str(seed), T4_TB_FIXED_TIME=TB_TIME)
+    if preload:
+        env["LD_PRELOAD"] = FIXTIME
+    with open(script) as f:
+        r = subprocess.run([binary, *args], stdin=f, capture_output=True, text=True, env=env, cwd=cwd, timeout=1800)
+    assert r.returncode == 0, (binary, script, r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    return r.stdout
+
+
+def main():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all", "refhost"], check=True, capture_output=True)
+    os.makedirs(os.path.join(ROOT, "tests", "golden", "refhost"), exist_ok=True)
+    d = workdir()
+    # f-2 fixture first: model_save_load.4th saves model_roundtrip.t4 through the reference's AIO::nsave
+    run(REFHOST, os.path.join(ROOT, "tests", "scripts", "model_save_load.4th"), d)
+    shutil.copy(os.path.join(d, "model_roundtrip.t4"), os.path.join(ROOT, "tests", "golden", "refhost", "ref_model_roundtrip.t4"))
+    shutil.copy(os.path.join(d, "model_roundtrip.t4"), os.path.join(d, "ref_model_roundtrip.t4"))
+    for s in sorted(glob.glob(os.path.join(ROOT, "tests", "scripts", "*.4th"))):
+        name = os.path.basename(s)[:-4]
+        if name in HAZARD:
+            out = normalise_oracle_vm(run(ORACLE_VM, s, d))
+        else:
+            out = normalise_refhost(run(REFHOST, s, d))
+        with open(os.path.join(ROOT, "tests", "golden", "vm", name + ".out"), "w") as f:
+            f.write(out)
+        print("golden", name, "(oracle VM: decided hazard)" if name in HAZARD else "(reference VM)")
+    # f-4 fixture: the reference's TensorBoard writer under a pinned clock
+    tb = os.path.join(d, "tb")
+    os.makedirs(tb)
+    run(REFHOST, os.path.join(ROOT, "tests", "scripts_tb", "tb_words.4th"), d, args=["-t" + tb, "-rrun1"], preload=True)
+    ev = glob.glob(os.path.join(tb, "run1", "events.out.tfevents.*"))
+    assert len(ev) == 1, ev
+    shutil.copy(ev[0], os.path.join(ROOT, "tests", "golden", "refhost", "tb_events.tfevents"))
+    for extra in sorted(glob.glob(os.path.join(tb, "run1", "*"))):
+        if extra != ev[0]:
+            with open(extra) as f:
+                txt = f.read().replace(tb, "<logdir>")
+            with open(os.path.join(ROOT, "tests", "golden", "refhost", "tb_" + os.path.basename(extra)), "w") as f:
+                f.write(txt)
+    print("fixtures written under tests/golden/refhost/")
+    shutil.rmtree(d)
+
+
+if __name__ == "__main__":
+    main()
