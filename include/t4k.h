@@ -97,6 +97,8 @@ t4k_stream_t t4k_default_stream(void);
 int t4k_event_create(t4k_event_t *e);
 int t4k_event_record(t4k_event_t e, t4k_stream_t s);
 int t4k_event_sync(t4k_event_t e);
+/* the wait of a helper thread (host/dataset.cpp's reader): only the wait - no deferred work of the model's thread is run, the wait-error word is left alone */
+int t4k_event_wait(t4k_event_t e);
 int t4k_event_elapsed_ms(t4k_event_t start, t4k_event_t stop, float *ms);
 int t4k_event_destroy(t4k_event_t e);
 

@@ -1985,7 +1985,10 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             if (l32d && g.d_zero && N <= 1024 && E0 <= 1024 && (a1 > 128 || (N <= 512 && E0 <= 512))) {   // coalesced operand blocks through LDS-DMA; a wave walks at most four 32-deep blocks
                 q1.Z = q2.Z = g.d_zero;
                 static int xm = -1; if (xm < 0) { const char *e = getenv("T4K_GEMM_XMAP"); xm = e ? atoi(e) : 0; }   // measured: no effect on the GAN layers (the Infinity Cache serves all eight L2s), off
-                if (xm) { q1.xmap = a1 >= 16 ? (E1 >= E0 ? 2 : 1) : 0; q2.xmap = a2 >= 16 ? (E1 >= N ? 2 : 1) : 0; }
+                // The gated (in-place dX) launch may hold more workgroups than fit the chip at 1-2 per CU (64*W threads, W*16 KiB of LDS): progress then rests on the
+                // dispatcher handing out workgroups in id order - the dW blocks [0, a1 + ar) never wait, the dX writers behind them wait only for those - so the
+                // id -> tile map stays the identity whenever the gate is in use; a device that dispatches out of order ends in the bounded-spin error
+                if (xm && !alias32) { q1.xmap = a1 >= 16 ? (E1 >= E0 ? 2 : 1) : 0; q2.xmap = a2 >= 16 ? (E1 >= N ? 2 : 1) : 0; }
                 const dim3 gd((unsigned)(a1 + ar + a2));
 #define T4K_DL32(R_, W_) do { static bool attr_done = false; \
                     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_dual_l32<R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, W_ * 16384); attr_done = true; } \

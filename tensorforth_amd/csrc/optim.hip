@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(BLK) k_opt_chunked(int kind, const t4k_param_r
     const long j0 = ((long)blockIdx.x - r.pad) * 1024;
     typedef float v4 __attribute__((ext_vector_type(4)));
     const long jv = j0 + 4 * threadIdx.x;
-    const bool vec = ((((uintptr_t)r.G | (uintptr_t)r.DG | (uintptr_t)r.M | (uintptr_t)r.V) & 15) == 0) && jv + 3 < r.n;
+    const bool vec = ((((uintptr_t)r.G | (uintptr_t)r.DG | (uintptr_t)r.M | (uintptr_t)r.V | (r.G == keep_src ? (uintptr_t)keep_dst : 0)) & 15) == 0) && jv + 3 < r.n;   // the snapshot store is a 16-byte one too
     if (vec) {                                              // four consecutive elements per thread: 16-byte loads and stores, a quarter of the instructions
         v4 g = *reinterpret_cast<const v4 *>(r.G + jv), dg = *reinterpret_cast<const v4 *>(r.DG + jv);
         v4 m = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
@@ -164,8 +164,9 @@ __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec
         float v; int q, k;
         if (cs_fold16(fa, blockIdx.x, sm, v, q, k)) {
             float dg = fa.seg[q].dst[k] + v;
-            if (XCHG) { const long z = (long)(fa.seg[q].dst - slab) + k; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev); }
-            opt1(kind, fr.r[q], k, dg, lr, b1, b2, wd, mom, keep_src, keep_dst);
+            bool ok = true;
+            if (XCHG) { const long z = (long)(fa.seg[q].dst - slab) + k; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev, ok); }
+            if (ok) opt1(kind, fr.r[q], k, dg, lr, b1, b2, wd, mom, keep_src, keep_dst);
         }
         return;
     }
@@ -177,8 +178,9 @@ __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec
     const long j = ((long)b - r.pad) * 1024 + threadIdx.x;
     if (j < r.n) {
         float dg = r.DG[j];
-        if (XCHG) { const long z = (long)(r.DG - slab) + j; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev); }
-        opt1(kind, r, j, dg, lr, b1, b2, wd, mom, keep_src, keep_dst);
+        bool ok = true;
+        if (XCHG) { const long z = (long)(r.DG - slab) + j; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev, ok); }
+        if (ok) opt1(kind, r, j, dg, lr, b1, b2, wd, mom, keep_src, keep_dst);
     }
 }
 
@@ -292,6 +294,7 @@ static int opt_step_impl(int kind, const t4k_param_rec *tab_dev, const t4k_param
     bool slab_ok = dp && tab_dev && tab_host && n_tensors > 0 && n_tensors <= 64 && n_chunks > 0 && slab_n <= xchg().n && !g.capturing && kind >= 0 && kind <= 2;
     for (int i = 0; slab_ok && i < n_tensors; i++) if (tab_host[i].DG < slab || tab_host[i].DG + tab_host[i].n > slab + slab_n) slab_ok = false;
     if (dp && !slab_ok) {                                     // cannot ride in the update: sum the slab first (same transport, its own launches), then the plain step
+        if (g.capturing) return fail(T4K_ERR_UNSUPPORTED, "t4k_opt_step_dp: the one-shot exchange cannot be recorded into a graph (every call carries its own epoch)");
         if (g.pending) flush_pending();
         const int rc = xchg_allreduce(const_cast<float *>(slab), slab_n, S(s)); if (rc) return rc;
         return t4k_opt_chunked(kind, tab_dev, n_tensors, n_chunks, lr, b1, b2, wd, s);

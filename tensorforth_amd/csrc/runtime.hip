@@ -93,6 +93,8 @@ void t4k_shutdown(void) {
     if (g.ws) { (void)hipFree(g.ws); g.ws = nullptr; }
     if (g.own_stream && g.stream) { (void)hipStreamDestroy(g.stream); }
     g.stream = nullptr; g.own_stream = false;
+    g.pending = 0; g.pending_owner = 0;                 // deferred work dies with its workspace and stream (a later t4k_init must not flush into freed memory)
+    (void)t4k_xchg_destroy();
     g.ready = false;
 }
 
@@ -180,6 +182,9 @@ t4k_stream_t t4k_default_stream(void) { return (t4k_stream_t)st().stream; }
 int t4k_event_create(t4k_event_t *e) { T4K_REQUIRE_INIT(); hipEvent_t h; T4K_HIP(hipEventCreate(&h)); *e = (t4k_event_t)h; return T4K_OK; }
 int t4k_event_record(t4k_event_t e, t4k_stream_t s) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventRecord((hipEvent_t)e, S(s))); return T4K_OK; }
 int t4k_event_sync(t4k_event_t e) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventSynchronize((hipEvent_t)e)); return spin_check(); }
+// the wait of a HELPER thread (the dataset reader): nothing but the wait - it neither runs deferred work of the thread that drives the model nor
+// reads / clears the wait-error word, which stays for that thread's next synchronising call
+int t4k_event_wait(t4k_event_t e) { T4K_REQUIRE_INIT_NOFLUSH(); T4K_HIP(hipEventSynchronize((hipEvent_t)e)); return T4K_OK; }
 int t4k_event_elapsed_ms(t4k_event_t a, t4k_event_t b, float *ms) { T4K_REQUIRE_INIT(); T4K_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return T4K_OK; }
 int t4k_event_destroy(t4k_event_t e) { T4K_REQUIRE_INIT(); if (e) T4K_HIP(hipEventDestroy((hipEvent_t)e)); return T4K_OK; }
 

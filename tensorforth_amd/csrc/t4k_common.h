@@ -41,9 +41,12 @@ struct State {
     unsigned    slot_epoch[16] = {};  // per stream lane: launch count of the kernels that tag the arrival slots (next_slot_epoch)
     unsigned long long launches = 0;  // kernels launched by the library since t4k_init (t4k_launch_count)
     int         pending = 0;          // work a launch left for the NEXT entry point (pending.h): bit 0 = a conv stack's dF | dB partial fold
+    unsigned long pending_owner = 0;  // the thread that left it (thread_key()): only THAT thread flushes or consumes it - a helper thread of the host (the dataset
+                                      // reader waits on events through t4k_event_sync) must neither run the fold a second time nor clear the bit
     char        err[512] = {0};
 };
 State &st();
+inline unsigned long thread_key() { static thread_local char k; return (unsigned long)(uintptr_t)&k; }   // cheap per-thread identity
 // every kernel launch of the library goes through this macro and is counted: bench.py prints the MEASURED launches per step
 #define T4K_LAUNCH(kernel, ...) do { ++t4k::st().launches; hipLaunchKernelGGLInternal((kernel), __VA_ARGS__); } while (0)
 // what a drawing kernel receives: eager = (base, seed) by value and state == nullptr; inside a graph = the device copy
@@ -111,7 +114,7 @@ int  spin_check();                       // runtime.hip: T4K_OK, or T4K_ERR_HIP 
 // tensor, accumulate a second backward, all-reduce the slab - sees exactly what the undeferred path would have left.
 void flush_pending();                    // conv_stack.hip
 #define T4K_REQUIRE_INIT_NOFLUSH() do { if (!t4k::st().ready) return t4k::fail(T4K_ERR_NODEVICE, "t4k_init not called or no gfx950 device"); } while (0)
-#define T4K_REQUIRE_INIT() do { T4K_REQUIRE_INIT_NOFLUSH(); if (t4k::st().pending) t4k::flush_pending(); } while (0)
+#define T4K_REQUIRE_INIT() do { T4K_REQUIRE_INIT_NOFLUSH(); if (t4k::st().pending && t4k::st().pending_owner == t4k::thread_key()) t4k::flush_pending(); } while (0)
 #define T4K_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) return t4k::hip_fail(_e, #call); } while (0)
 #define T4K_LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return t4k::hip_fail(_e, "kernel launch"); } while (0)
 
@@ -306,13 +309,16 @@ __device__ __forceinline__ void xchg_push(const XchgDev &x, long j, float v) {
     for (int r = 0; r < T4K_XCHG_MAX; r++)
         if (r < x.world && r != x.rank) __hip_atomic_store(x.win[r] + (long)x.rank * x.per + j, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ float xchg_sum(const XchgDev &x, long j, float mine, int *err) {
+// ok = false when a peer's element never arrived within the patience: the caller must NOT use the sum (an optimizer step leaves W and dW of that element
+// untouched, so a rank whose peer died keeps its last consistent state instead of diverging on a stale slot - ADVICE r4 #2); the error word says why
+__device__ __forceinline__ float xchg_sum(const XchgDev &x, long j, float mine, int *err, bool &ok) {
     unsigned long long w[T4K_XCHG_MAX];
     const unsigned long long *my = x.win[x.rank] + j;
 #pragma unroll
     for (int r = 0; r < T4K_XCHG_MAX; r++)            // every slot's load in flight before the first tag is looked at
         w[r] = (r < x.world && r != x.rank) ? __hip_atomic_load(my + (long)r * x.per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
     float s = 0.f;
+    ok = true;
 #pragma unroll
     for (int r = 0; r < T4K_XCHG_MAX; r++) {          // rank order on every rank: the same numbers added in the same order
         if (r >= x.world) break;
@@ -323,7 +329,7 @@ __device__ __forceinline__ float xchg_sum(const XchgDev &x, long j, float mine, 
             if ((it & 63) == 63) {
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (!t0) t0 = now;
-                else if (now - t0 > x.patience) { if (err) __hip_atomic_store(err, 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                else if (now - t0 > x.patience) { if (err) __hip_atomic_store(err, 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = false; break; }
             }
             __builtin_amdgcn_s_sleep(2);
             w[r] = __hip_atomic_load(my + (long)r * x.per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

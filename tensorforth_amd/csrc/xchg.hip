@@ -45,7 +45,8 @@ __global__ void __launch_bounds__(256) k_xchg_allreduce(float *buf, long n, Xchg
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long)gridDim.x * 256) {
         const float v = buf[j];
         xchg_push(x, j, v);
-        buf[j] = xchg_sum(x, j, v, g_spin_err_dev);
+        bool ok; const float sum = xchg_sum(x, j, v, g_spin_err_dev, ok);
+        if (ok) buf[j] = sum;                                     // a peer that never arrived: the element keeps the local value, the call reports T4K_ERR_HIP
     }
 }
 
@@ -85,6 +86,7 @@ int t4k_xchg_connect(const void *handles) {
     T4K_REQUIRE_INIT();
     Xchg &x = xchg();
     if (!handles || !L.win || x.world < 1) return fail(T4K_ERR_ARG, "t4k_xchg_connect: t4k_xchg_create first");
+    if (x.connected) return fail(T4K_ERR_ARG, "t4k_xchg_connect: already connected - t4k_xchg_create again first (fresh windows: the epochs restart at 0, old tags must not survive)");
     int ndev = 0; (void)hipGetDeviceCount(&ndev);
     for (int d = 0; d < ndev; d++) if (d != st().device) { int can = 0; if (hipDeviceCanAccessPeer(&can, st().device, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0); }
     (void)hipGetLastError();                         // "already enabled" is not an error
@@ -110,6 +112,7 @@ int t4k_xchg_allreduce(float *buf, long n, t4k_stream_t s) {
     if (!xchg().connected) return fail(T4K_ERR_UNSUPPORTED, "t4k_xchg_allreduce: not connected (t4k_xchg_connect)");
     if (n <= 0) return T4K_OK;
     if (!buf) return fail(T4K_ERR_ARG, "t4k_xchg_allreduce: null");
+    if (st().capturing) return fail(T4K_ERR_UNSUPPORTED, "t4k_xchg_allreduce: cannot be recorded into a graph (every call carries its own epoch)");
     return xchg().world > 1 ? xchg_allreduce(buf, n, S(s)) : T4K_OK;
 }
 int t4k_xchg_world(void) { return xchg().connected ? xchg().world : 0; }

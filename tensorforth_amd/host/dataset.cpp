@@ -61,7 +61,7 @@ static void reader_main(Corpus *c, Reader *r) {
         r->busy = true;
         const bool wait_ev = c->pin_wait[slot]; c->pin_wait[slot] = false;
         lk.unlock();
-        if (wait_ev) t4k_event_sync(c->pin_ev[slot]);    // the staging launch of the batch this slot held
+        if (wait_ev) t4k_event_wait(c->pin_ev[slot]);    // the staging launch of the batch this slot held (reader thread: the plain wait, t4k.h)
         const int n = c->read_into(bid, slot);
         lk.lock();
         c->slot_n[slot] = n; r->queue[q] = -1; r->busy = false;
