@@ -165,6 +165,23 @@ def extras(vm_cls, local, ms_step, args, torch):
     t0 = time.perf_counter(); c.eval("200 steps\n"); torch.cuda.synchronize()
     out["t4_40a_net_ms_per_step"] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
     c.close()
+    # ---- the reference-equal-work step: the same timed loop with the first layer's dX stored every step (T4_LAZY_DX0=0, what the reference's backprop
+    # always does, backprop.cu:185,240).  The switch is read when the host library loads, so the figure comes from a child process of this very script.
+    if os.environ.get("T4_LAZY_DX0", "1") != "0":
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--net", args.net, "--batch", str(args.batch),
+                                "--no-extras", "--no-cpu-baseline", "--gemm-iters", "1", "--sustain-s", "0"], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, T4_LAZY_DX0="0"))
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                e = json.loads(line[-1])
+                out["eager_ms_per_step"] = e["ms_per_step"]
+                out["eager_note"] = "T4_LAZY_DX0=0 (first layer's dX stored every step, as the reference does): %s launches per step, %s images/s, roofline_step.frac %s on %d algorithmic bytes" % (
+                    e["config"]["launches_per_step"], e["value"], e["roofline_step"]["frac"], e["roofline_step"]["algorithmic_bytes_per_step"])
+            else:
+                out["eager_note"] = "eager leg failed: " + (r.stderr or r.stdout)[-300:]
+        except Exception as ex:                                  # never lose the main line over an extra
+            out["eager_note"] = "eager leg failed: %r" % (ex,)
     # ---- dataset-fed step: IDX file -> pinned double buffer (reader thread) -> one staging launch -> forward backprop nn.sgd
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as d:
@@ -259,57 +276,18 @@ def main():
     # stream inside `nn.sgd`, so the training loop stays inside the VM exactly as on one GPU.  torch.distributed only
     # carries the 128-byte communicator id to the ranks (and the barrier / max-time reduction of the bench contract).
     native = False
-    if dp and os.environ.get("T4_DP_NATIVE", "1") == "1":
-        idbuf = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        ok = torch.ones(1, device="cuda")
-        if rank == 0:
-            raw = (ctypes.c_ubyte * 128)()
-            if k.lib.t4k_comm_unique_id(raw) == 0:
-                idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
-            else:
-                ok.zero_()
-        dist.broadcast(idbuf, 0); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok.item()) > 0:
-            raw = (ctypes.c_ubyte * 128)(*idbuf.cpu().tolist())
-            good = torch.tensor([1.0 if k.lib.t4k_comm_init(raw, rank, world) == 0 else 0.0], device="cuda")
-            dist.all_reduce(good, op=dist.ReduceOp.MIN)
-            native = float(good.item()) > 0
-            if not native:
-                k.lib.t4k_comm_destroy()
-            elif k.lib.t4k_comm_world() != world or k.lib.t4k_comm_rank() != rank:
-                sys.stderr.write("bench: RCCL communicator has %d ranks, %d asked for\n" % (k.lib.t4k_comm_world(), world)); sys.exit(3)
-    # ---- the one-shot peer exchange (csrc/xchg.hip): every rank's receive window is shared through an IPC handle (all_gather'ed below), the
-    # optimizer launch then sums the gradient slab over the ranks itself - fold + all-reduce + SGD in one kernel, no collective between
-    # `backprop` and `nn.sgd`.  Checked against a known sum before it is trusted; RCCL (above) stays the fallback and carries the scalars.
     xchg = False
-    if dp and native and world > 1 and os.environ.get("T4_DP_XCHG", "1") == "1":
-        h = (ctypes.c_ubyte * 64)()
-        good = torch.tensor([1.0 if k.lib.t4k_xchg_create(1 << 17, rank, world, h) == 0 else 0.0], device="cuda")
-        mine = torch.tensor(list(h), dtype=torch.uint8, device="cuda")
-        allh = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(world)]
-        dist.all_gather(allh, mine); dist.all_reduce(good, op=dist.ReduceOp.MIN)
-        if float(good.item()) > 0:
-            blob = b"".join(bytes(t.cpu().tolist()) for t in allh)
-            good = torch.tensor([1.0 if k.lib.t4k_xchg_connect(blob) == 0 else 0.0], device="cuda")
-            dist.all_reduce(good, op=dist.ReduceOp.MIN)
-            dist.barrier()
-            if float(good.item()) > 0:                        # self-check: sum over ranks of (rank + 1) * i must be i * world (world + 1) / 2, twice (both window parities)
-                probe = torch.arange(70000, dtype=torch.float32, device="cuda") % 1000
-                for _ in range(2):
-                    v = (probe * (rank + 1)).contiguous()
-                    torch.cuda.synchronize()
-                    rc = k.lib.t4k_xchg_allreduce(v.data_ptr(), v.numel(), None) or k.lib.t4k_sync(None)
-                    okv = rc == 0 and bool(torch.equal(v, probe * (world * (world + 1) // 2)))
-                    good = torch.tensor([1.0 if okv else 0.0], device="cuda"); dist.all_reduce(good, op=dist.ReduceOp.MIN)
-                    if float(good.item()) <= 0:
-                        break
-            xchg = float(good.item()) > 0
-        if not xchg:
-            if rank == 0:
-                sys.stderr.write("bench: one-shot peer exchange unavailable or failed its self-check (%s) - the slab goes through RCCL\n" % k.lib.t4k_last_error().decode(errors="replace")[-300:])
-            k.lib.t4k_xchg_destroy()
-            if native:
-                k.call("t4k_rand_set_shard", rank, world)     # (destroy resets the shard the exchange had set)
+    neg = None
+    if dp:
+        # the ladder (library's own RCCL communicator -> one-shot peer exchange inside the optimizer launch, each rung agreed on by all ranks and the
+        # exchange checked against a known sum before it is trusted) lives in tensorforth_amd/dp.py, where the CPU tests drive it with scripted failures
+        from tensorforth_amd import dp as t4dp
+        neg = t4dp.negotiate_reduction(k.lib, rank, world, torch.device("cuda", local),
+                                       want_native=os.environ.get("T4_DP_NATIVE", "1") == "1", want_xchg=os.environ.get("T4_DP_XCHG", "1") == "1",
+                                       log=(lambda m: sys.stderr.write("bench: %s (%s)\n" % (m, k.lib.t4k_last_error().decode(errors="replace")[-300:]))) if rank == 0 else None)
+        native, xchg = neg["native"], neg["xchg"]
+        if native and not xchg:
+            k.call("t4k_rand_set_shard", rank, world)         # (a destroyed exchange resets the shard it had set; t4k_comm_init set it before)
     if dp and not native:
         k.call("t4k_rand_set_shard", rank, world)         # torch.distributed reduces the slab; the masks are still keyed by sample
     joined = k.lib.t4k_comm_world() if native else (dist.get_world_size() if dp else 1)
@@ -388,7 +366,11 @@ def main():
         gemm_traffic, step_traffic, traffic_src = measured_traffic()
         if args.net != "nn_f" or N != 128:
             step_traffic = None                                # the counter pass is of the default workload
-        step_bytes = N * net["bytes_per_img"] + 4 * net["params"] * 7            # k_opt = 7 for SGD
+        step_bytes_eager = N * net["bytes_per_img"] + 4 * net["params"] * 7      # k_opt = 7 for SGD; SURVEY 8(d): every layer-boundary tensor incl. the first layer's dX
+        lazy_dx0 = os.environ.get("T4_LAZY_DX0", "1") != "0"
+        # the timed step does not produce the first layer's dX (nobody reads it in a training loop; it is made on demand): its write + read
+        # (2 x 4 B per input element) is not counted as work done.  The reference-equal-work figure (eager store) is `eager_ms_per_step` below.
+        step_bytes = step_bytes_eager - (2 * 4 * N * 28 * 28 if lazy_dx0 else 0)
         out = {
             "metric": BASELINE_METRIC,   # `value` = CNN train images/sec; the GEMM TFLOP/s (% of MFMA peak) part is the `roofline` object
             "value": round(img_s, 1), "unit": "images/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
@@ -397,12 +379,14 @@ def main():
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
                                    "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
                        "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": round(launches, 2), "launches_source": "t4k_launch_count() around the timed loop", "conv_stack": stack_mode, "allreduce": ("one-shot peer exchange inside the optimizer launch (csrc/xchg.hip)" if xchg else ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None))),
+                       "allreduce_fallback_reason": neg["reason"] if neg else None, "ranks_seen": neg["ranks_seen"] if neg else None,
                        "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None,
                        "final_loss_note": "random images and labels, batch-SUM gradients (reference semantics): a throughput run, not a convergence test; training parity vs the oracle is in tests/"},
             "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                               "unit": "GB/s", "frac": round(step_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                               "traffic": step_traffic, "traffic_source": traffic_src,
-                              "algorithmic_bytes_per_step": step_bytes},
+                              "algorithmic_bytes_per_step": step_bytes, "algorithmic_bytes_per_step_eager": step_bytes_eager,
+                              "first_layer_dx": "on demand (T4_LAZY_DX0=1): its 2 x 4 B per input element are not in algorithmic_bytes_per_step" if lazy_dx0 else "stored every step"},
         }
         if sustained:
             out["sustained_ms_per_step"] = round(sustained[0], 4)

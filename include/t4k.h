@@ -388,6 +388,9 @@ int t4k_conv_stack_head_ok(const t4k_conv_stage *st, int n_stage, int N, const t
 int t4k_conv_stack_head_fwd(const float *X, float *X0, const t4k_conv_stage *st, int n_stage, int N, const t4k_stack_head *h, t4k_stream_t s);
 int t4k_conv_stack_fwd(const float *X, float *XCOPY, const t4k_conv_stage *st, int n_stage, int N, t4k_stream_t s);
 int t4k_conv_stack_bwd(const float *DY, const t4k_conv_stage *st, int n_stage, int N, int train, t4k_stream_t s);
+/* 1 when that call would be accepted (kernels built; the banded or the whole-image kernel it would launch fits the LDS and the workspace): the host's
+ * quiet test before it picks between the stack's backward and its per-layer kernels */
+int t4k_conv_stack_bwd_ok(const t4k_conv_stage *st, int n_stage, int N, int train, t4k_stream_t s);
 /* backward of the same run (_bactivate backprop.cu:256-263, _bpool, flatten `in = out`): DY is the gradient
  * w.r.t. the run's last tensor; each stage's input buffer receives its dX (X receives the run's dX). */
 int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);

@@ -287,6 +287,7 @@ int t4k_conv_stack_dx0_pending(const float *) { return 0; }
 int t4k_conv_stack_dx0(const t4k_conv_stage *, int, t4k_stream_t) { return T4K_OK; }
 int t4k_conv_stack_fwd(const float *, float *, const t4k_conv_stage *, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
 int t4k_conv_stack_bwd(const float *, const t4k_conv_stage *, int, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }
+int t4k_conv_stack_bwd_ok(const t4k_conv_stage *, int, int, int, t4k_stream_t) { return 0; }
 int t4k_conv_stack_head_ok(const t4k_conv_stage *, int, int, const t4k_stack_head *) { return 0; }
 int t4k_mlp_head_bwd_ok(int, int, int, int) { return 0; }
 int t4k_mlp_block_bwd(float *, const float *, float *, const float *, float *, const t4k_poolblock *, float *, float *, float *, float *, const float *, const t4k_poolblock *, float *, float *, float *, int, int, int, int, int, t4k_stream_t) { return T4K_ERR_UNSUPPORTED; }

@@ -87,3 +87,86 @@ class OverlappedSlabReducer:
         if self.side is not None and self.cut is not None:
             self.vs.wait_stream(self.side)
         self.cut = None
+
+
+def negotiate_reduction(lib, rank, world, device, want_native=True, want_xchg=True, log=None, xchg_allreduce=None, slab_floats=1 << 17):
+    """The fallback ladder of the gradient exchange, agreed on by ALL ranks (every decision is an all-reduce(MIN) of the ranks' verdicts, so
+    no rank is left on a transport its peers abandoned):
+
+      1. the library's own RCCL communicator (`t4k_comm_*`; torch.distributed only carries the 128-byte id) - else torch.distributed reduces the slab;
+      2. on top of it the one-shot peer exchange (`t4k_xchg_*`, csrc/xchg.hip): every rank's receive window is shared through an IPC handle, then
+         CHECKED against a known sum on both window parities before it is trusted - else the slab goes through RCCL (rung 1).
+
+    `lib` is the ctypes library (or, in the CPU tests, a stand-in with the same entry points whose failures are scripted: the ladder itself is
+    transport-agnostic and runs over gloo there).  Returns {"native", "xchg", "reason", "ranks_seen"}; the caller prints `reason` and
+    `ranks_seen` so that a driver can verify that N ranks really agreed (VERDICT r4 #9)."""
+    import ctypes
+    say = log or (lambda m: None)
+    res = {"native": False, "xchg": False, "reason": None, "ranks_seen": {}}
+
+    def all_min(flag):
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) > 0
+
+    def count_ranks():
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(round(float(t.item())))
+
+    res["ranks_seen"]["torch.distributed"] = count_ranks()
+    if want_native:
+        idbuf = torch.zeros(128, dtype=torch.uint8, device=device)
+        have_id = True
+        if rank == 0:
+            raw = (ctypes.c_ubyte * 128)()
+            if lib.t4k_comm_unique_id(raw) == 0:
+                idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+            else:
+                have_id = False
+        dist.broadcast(idbuf, 0)
+        if all_min(have_id):
+            raw = (ctypes.c_ubyte * 128)(*idbuf.cpu().tolist())
+            res["native"] = all_min(lib.t4k_comm_init(raw, rank, world) == 0)
+            if not res["native"]:
+                lib.t4k_comm_destroy()
+                res["reason"] = "a rank could not join the library's RCCL communicator: torch.distributed reduces the slab"
+            elif lib.t4k_comm_world() != world or lib.t4k_comm_rank() != rank:
+                raise SystemExit("RCCL communicator has %d ranks (this one is %d), %d asked for" % (lib.t4k_comm_world(), lib.t4k_comm_rank(), world))
+            else:
+                res["ranks_seen"]["rccl"] = lib.t4k_comm_world()
+        else:
+            res["reason"] = "rank 0 could not create an RCCL id (librccl missing?): torch.distributed reduces the slab"
+    if res["native"] and want_xchg and world > 1:
+        h = (ctypes.c_ubyte * 64)()
+        created = lib.t4k_xchg_create(slab_floats, rank, world, h) == 0
+        mine = torch.tensor(list(h), dtype=torch.uint8, device=device)
+        allh = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        good = all_min(created)
+        why = "a rank could not allocate / export its receive window"
+        if good:
+            blob = b"".join(bytes(t.cpu().tolist()) for t in allh)
+            good = all_min(lib.t4k_xchg_connect(blob) == 0)
+            why = "a rank could not map a peer's window (hipIpcOpenMemHandle; only SOME peers mappable counts as none: the exchange is all-or-nothing)"
+            dist.barrier()
+        if good:                                              # self-check: sum over ranks of (rank + 1) * i must be i * world (world + 1) / 2, on both window parities
+            probe = torch.arange(70000, dtype=torch.float32, device=device) % 1000
+            run = xchg_allreduce or (lambda v: lib.t4k_xchg_allreduce(v.data_ptr(), v.numel(), None) or lib.t4k_sync(None))
+            for _ in range(2):
+                v = (probe * (rank + 1)).contiguous()
+                if device is not None and str(device).startswith("cuda"):
+                    torch.cuda.synchronize()
+                rc = run(v)
+                good = all_min(rc == 0 and bool(torch.equal(v, probe * (world * (world + 1) // 2))))
+                why = "the exchange failed its known-sum self-check"
+                if not good:
+                    break
+        res["xchg"] = good
+        if good:
+            res["ranks_seen"]["xchg"] = lib.t4k_xchg_world()
+        else:
+            res["reason"] = "one-shot peer exchange not used (%s) - the slab goes through RCCL" % why
+            say(res["reason"])
+            lib.t4k_xchg_destroy()
+    return res

@@ -693,7 +693,9 @@ void Model::run_backward(Tensor &tgt) {
                 const int k0 = stack_end_[i];
                 t4k_conv_stage stg[3]; int ops = 0;
                 const int ns = stack_at(k0, stg, ops);
-                if (ns > 0 && k0 + ops - 1 == i && chk(t4k_conv_stack_bwd(dy, stg, ns, at(k0).N(), (train ? 1 : 0) | ((k0 < (int)stack_fresh_.size() && stack_fresh_[k0]) ? 0 : 2) | ((use_opt_fold && !grad_hook && !capturing_) ? 4 : 0) | ((use_lazy_dx0 && k0 == 0 && !capturing_ && !use_graphs) ? 8 : 0), s), "nn#bstack") == T4K_OK) {
+                const int bflags = (train ? 1 : 0) | ((k0 < (int)stack_fresh_.size() && stack_fresh_[k0]) ? 0 : 2) | ((use_opt_fold && !grad_hook && !capturing_) ? 4 : 0) | ((use_lazy_dx0 && k0 == 0 && !capturing_ && !use_graphs) ? 8 : 0);
+                // (asked first, quietly: without the forward's saved state the whole-image kernel runs, and its windows may not fit the LDS - the per-layer kernels then)
+                if (ns > 0 && k0 + ops - 1 == i && t4k_conv_stack_bwd_ok(stg, ns, at(k0).N(), bflags, s) && chk(t4k_conv_stack_bwd(dy, stg, ns, at(k0).N(), bflags, s), "nn#bstack") == T4K_OK) {
                     if (k0 == 0 && use_lazy_dx0 && t4k_conv_stack_dx0_pending(stg[0].O)) {
                         dx0_stale_ = true; at(0).stale_owner = this; if (at(0).grad[4]) at(0).grad[4]->stale_owner = this;
                     }

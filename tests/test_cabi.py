@@ -62,7 +62,7 @@ def test_release_library_has_no_lab_switches():
     for name in (b"T4K_STACK_LAB_NOSTORE", b"T4K_STACK_LAB_NOW1", b"T4K_STACK_LAB_NOXCHG", b"T4K_STACK_PROF_PTR"):
         assert name + b"\0" not in blob, name               # as a C string of its own (what getenv would be handed); comments of the embedded source may mention it
     assert b"#define CS_LAB_" not in blob
-    assert b"#ifdef CS_LAB_NOW1" in blob                     # (the embedded device source keeps the guarded text; nothing can define the macro)
+    assert b"defined(CS_LAB_NOW1)" in blob                    # (the embedded device source keeps the guarded text; nothing can define the macro)
 
 
 def test_conv_stack_code_objects_are_cached_on_disk(tmp_path):
