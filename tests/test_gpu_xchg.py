@@ -20,8 +20,17 @@ def _run(tmp, world, rows, steps, absent=None, timeout=240, patience_ms=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     if patience_ms:
         env["T4K_XCHG_TIMEOUT_MS"] = str(patience_ms)
+    # Ranks that share ONE device also share its workgroup slots: a rank whose optimizer launch (~220 workgroups that wait for their peers' elements)
+    # arrives late can find every slot held by the waiting workgroups of three early ranks - a dead lock that only the patience ends, and one that
+    # real ranks (a GPU each) cannot have.  With more than two ranks every process therefore gets its own quarter of the compute units (ROCr's
+    # HSA_CU_MASK), which is also the closer emulation of "one GPU per rank".
+    def rank_env(r):
+        if world <= 2:
+            return env
+        per = 256 // world
+        return dict(env, HSA_CU_MASK="0:%d-%d" % (r * per, (r + 1) * per - 1))
     procs = [subprocess.Popen([sys.executable, WORKER, str(tmp), str(r), str(world), str(rows), str(steps)] + (["absent"] if r == absent else []),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=rank_env(r), text=True) for r in range(world)]
     outs = []
     for p_ in procs:
         try:
