@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec
     const bool mom = !(fabsf(b1) < DU_EPS);
     if ((int)blockIdx.x < nfold) {
         float v; int q, k;
-        if (cs_fold16(fa, blockIdx.x, sm, v, q, k)) {
+        if (cs_fold16(fa, cs_fold_block(blockIdx.x, nfold), sm, v, q, k)) {
             float dg = fa.seg[q].dst[k] + v;
             bool ok = true;
             if (XCHG) { const long z = (long)(fa.seg[q].dst - slab) + k; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev, ok); }

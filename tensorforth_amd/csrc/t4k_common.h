@@ -271,6 +271,13 @@ __device__ __forceinline__ void rng_state_read(const uint64_t *state, uint64_t &
 struct CsFoldSeg { float *dst; int off, n, start; };                  // elements [off, off+n) of a partial row -> dst[0..n); start = first global element id
 struct CsFoldArgs { const float *part; long row; int nparts, nseg, total, pad_; CsFoldSeg seg[6]; };
 struct CsFoldSm { float a[64][17], b[4][17]; };
+// Workgroup id -> block of 16 elements.  Two neighbouring blocks share every 128-byte line of every partial row; workgroup ids go round the 8 XCDs, so
+// ids w and w + 8 sit behind the SAME L2: they get the two halves of a line (the second is an L2 hit instead of a second fetch over the fabric by
+// another XCD's L2 - k_opt_step read 6.8 MB for 2 MB of partial rows).  A permutation of who does what: no sum changes.
+__device__ __forceinline__ int cs_fold_block(int w, int nblocks) {
+    const int base = w & ~15;
+    return base + 16 <= nblocks ? base + ((w & 7) << 1) + ((w >> 3) & 1) : w;
+}
 // returns true for the ONE thread per element that holds the sum (`v`), with `q` the segment and `k` the element inside it
 __device__ __forceinline__ bool cs_fold16(const CsFoldArgs &a, int blk, CsFoldSm &sm, float &v, int &q, int &k) {
     const int el = threadIdx.x & 15, g = threadIdx.x >> 4, e = blk * 16 + el;
