@@ -65,6 +65,12 @@ enum { T4K_RED_SUM = 0, T4K_RED_NVAR, T4K_RED_MAX, T4K_RED_MIN };
 int         t4k_device_count(void);
 int         t4k_init(int device);                  /* select device, create default stream + workspace */
 void        t4k_shutdown(void);
+/* Kernels whose workgroups wait for each other (arrival gates of the one-launch dW || dX products, pair-mode tickets, the band exchange of the conv-stack
+ * head, column-stripe tickets) need every workgroup of the launch resident at once: true on an exclusively owned device, not on a partitioned or shared
+ * one.  t4k_gates_enable(0) makes every launcher pick its ungated path (more launches, same results); a wait that times out does it by itself, after
+ * reporting T4K_ERR_HIP once for the launch it spoiled (runtime.hip spin_check). */
+int t4k_gates_enable(int on);
+int t4k_gates_enabled(void);
 const char *t4k_last_error(void);
 const char *t4k_backend_name(void);                /* "hip-gfx950" for the product library */
 int         t4k_device_info(int *cu_count, int *clock_khz, size_t *hbm_bytes);

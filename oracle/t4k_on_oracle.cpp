@@ -45,6 +45,8 @@ int t4k_event_create(t4k_event_t *e) { *e = nullptr; return T4K_OK; }
 int t4k_event_record(t4k_event_t, t4k_stream_t) { return T4K_OK; }
 int t4k_event_sync(t4k_event_t) { return T4K_OK; }
 int t4k_event_wait(t4k_event_t) { return T4K_OK; }
+int t4k_gates_enable(int) { return T4K_OK; }
+int t4k_gates_enabled(void) { return 0; }
 int t4k_event_elapsed_ms(t4k_event_t, t4k_event_t, float *ms) { *ms = 0; return T4K_OK; }
 int t4k_event_destroy(t4k_event_t) { return T4K_OK; }
 int t4k_comm_unique_id(void *) { return T4K_ERR_UNSUPPORTED; }

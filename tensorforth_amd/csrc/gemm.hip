@@ -1934,9 +1934,9 @@ int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 
 
 struct ColSum { const float *X; float *out; int rows, E; bool done; };
 bool plain_any_big() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_PLAIN_ANY"); v = e ? atoi(e) : 2; } return v >= 2; }   // 0 off, 1 one-tile-per-CU shapes only, 2 (default) large ones too
-bool big_dma() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_BIG_DMA"); v = e ? atoi(e) : 1; } return v != 0; }
+bool big_dma() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_BIG_DMA"); v = e ? atoi(e) : 1; } return v != 0 && gates_ok(); }
 bool capturing(hipStream_t hs) { hipStreamCaptureStatus st_ = hipStreamCaptureStatusNone; return hipStreamIsCapturing(hs, &st_) == hipSuccess && st_ != hipStreamCaptureStatusNone; }   // a replayed graph would repeat the epoch argument
-bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0; }
+bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0 && gates_ok(); }
 // dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
 // shapes belong to the other kernels (deep K -> split-K, large -> 128x128 tiles).  Interior-tile shapes take it too since round 2
 // (T4K_GEMM_DUAL_FULL=0: the LDS-DMA kernels, 5 launches with their folds and the column sum: GAN round 0.356 instead of 0.318 ms of GPU time)
@@ -2121,7 +2121,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
         // 512 x 1024 x 1024: one launch instead of split-K slabs + a fold launch.  Tickets are per tile: default stream only.
         static int ppair = -1; if (ppair < 0) { const char *e = getenv("T4K_GEMM_PLAIN_PAIR"); ppair = e ? atoi(e) : 1; }
         const int var0 = gemm_variant();
-        if (ppair && !big && vec && C == 1 && (var0 & 4) && (var0 & 16) && (var0 & 32) && !(var0 & 64) && M % 64 == 0 && N % 64 == 0 && K % 256 == 0 && K >= 512 &&
+        if (ppair && gates_ok() && !big && vec && C == 1 && (var0 & 4) && (var0 & 16) && (var0 & 32) && !(var0 & 64) && M % 64 == 0 && N % 64 == 0 && K % 256 == 0 && K >= 512 &&
             tiles * 2 <= st().cu_count && tiles * 3 > st().cu_count && tiles <= 2048 && !defer && !(epi && epi->layer) && !rider && !cs &&
             st().d_sync && lane_of(S(s)) == 0 && (size_t)tiles * 4096 * sizeof(float) <= st().ws_bytes / 2 &&
             (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
@@ -2148,7 +2148,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     // pair mode (variant bit 3): an interior 64x64-tiled problem that gives each CU at most one workgroup is split in
     // two K halves combined in the epilogue => 2 workgroups (8 waves) per CU hide each other's LDS / barrier stalls
     p.pair = 0; p.sync = st().d_sync;
-    if (!big && vec && nsplit == 1 && C == 1 && (var & 4) && (var & 8) && p.sync && lane_of(S(s)) == 0 && tiles <= st().cu_count && tiles <= 2048 &&   // tickets are per tile, not per stream: default stream only
+    if (gates_ok() && !big && vec && nsplit == 1 && C == 1 && (var & 4) && (var & 8) && p.sync && lane_of(S(s)) == 0 && tiles <= st().cu_count && tiles <= 2048 &&   // tickets are per tile, not per stream: default stream only
         M % 64 == 0 && N % 64 == 0 && K % 128 == 0 && K >= 256 && (size_t)tiles * 4096 * sizeof(float) <= st().ws_bytes / 2) {
         p.pair = 1; nsplit = 2; kchunk = K / 2;
     }

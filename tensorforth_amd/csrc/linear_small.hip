@@ -605,7 +605,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
         const size_t ldsc = sizeof(float) * ((size_t)N * E0 + (size_t)E0 * LSC_CW + (size_t)N * LSC_CW + 256);
         int *gatec = TGT ? gate_for(hs, 0) : nullptr;            // the one shared counter (ints 0.. of the stream's gate block; zero between launches)
         const int nwg = (E1 + LSC_CW - 1) / LSC_CW;
-        if (cols_on && E0 * LSC_CW + E0 <= 256 && N >= 1 && N <= 512 && ldsc <= (size_t)LS_MAX_FLOATS * 4 && (DX || (train && DW)) && (!train || (DW && DB)) &&
+        if (cols_on && (gates_ok() || !TGT) && E0 * LSC_CW + E0 <= 256 && N >= 1 && N <= 512 && ldsc <= (size_t)LS_MAX_FLOATS * 4 && (DX || (train && DW)) && (!train || (DW && DB)) &&
             (!TGT || (gatec && st().d_sync && nwg <= st().cu_count)) && (cols_on >= 2 || N * E1 <= 32768)) {
             static bool attrc = false;
             if (!attrc) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linsmall_bwd_cols), hipFuncAttributeMaxDynamicSharedMemorySize, LS_MAX_FLOATS * 4); attrc = true; }
@@ -628,7 +628,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     State &g = st();
     static int gate_on = -1; if (gate_on < 0) { const char *e = getenv("T4K_LINSMALL_GATE"); gate_on = e ? atoi(e) : 1; }
     int *gate = gate_for(hs, 0);                                           // nullptr: a stream the library does not know -> no private counters
-    if (alias && (nA + nB > g.cu_count || !g.d_sync || !gate || !gate_on)) return false;   // the arrival counter needs every workgroup resident
+    if (alias && (nA + nB > g.cu_count || !g.d_sync || !gate || !gate_on || !gates_ok())) return false;   // the arrival counter needs every workgroup resident
     size_t lds = sizeof(float) * (size_t)(E0 * E1 + RA * E0);
     if (nB > 0 && sizeof(float) * (size_t)(N + 768) > lds) lds = sizeof(float) * (size_t)(N + 768);
     if (lds > (size_t)LS_MAX_FLOATS * 4) return false;

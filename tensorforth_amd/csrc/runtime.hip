@@ -41,8 +41,13 @@ int spin_check() {
                                   "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_GATE=0", "T4K_LINSMALL_COLS=0", "T4_STACK_HEAD=0 (or T4K_STACK_HEAD=0)", "T4_HEAD_BWD=0 (or T4K_HEAD_BWD=0)",
                                   "T4_DP_XCHG=0 (the slab then goes through RCCL); check that every rank reached the optimizer" };
     const int k = (code > 0 && code < 10) ? code : 0;
-    return fail(T4K_ERR_HIP, "an inter-workgroup wait timed out (code %d: %s): the launch's workgroups were not co-resident - results of that launch are invalid; "
-                             "on a shared or partitioned device set %s", code, what[k], off[k]);
+    // Degrade, do not keep failing: from here on the launchers pick only kernels whose workgroups never wait for each other
+    // (the per-layer / split paths: more launches, same results) - a partitioned or shared device then costs speed, not correctness.  The exchange of a
+    // data-parallel job (code 9) is another matter: a peer is missing, nothing local can replace it.
+    if (k != 9) g.gates_off = true;
+    return fail(T4K_ERR_HIP, "an inter-workgroup wait timed out (code %d: %s): the launch's workgroups were not co-resident - results of that launch are invalid%s; "
+                             "on a shared or partitioned device set %s (or call t4k_gates_enable(0) up front)", code, what[k],
+                             k != 9 ? "; the library now uses its ungated kernels (slower, correct) until t4k_gates_enable(1)" : "", off[k]);
 }
 }
 namespace { struct GraphRec { hipGraphExec_t exec; uint64_t rng_adv; }; }
@@ -98,6 +103,8 @@ void t4k_shutdown(void) {
     g.ready = false;
 }
 
+int t4k_gates_enable(int on) { st().gates_off = !on; return T4K_OK; }
+int t4k_gates_enabled(void) { return st().gates_off ? 0 : 1; }
 const char *t4k_last_error(void)  { return st().err; }
 unsigned long long t4k_launch_count(void) { return st().launches; }
 const char *t4k_backend_name(void) { return "hip-gfx950"; }

@@ -40,12 +40,14 @@ struct State {
     int         cu_count = 256;
     unsigned    slot_epoch[16] = {};  // per stream lane: launch count of the kernels that tag the arrival slots (next_slot_epoch)
     unsigned long long launches = 0;  // kernels launched by the library since t4k_init (t4k_launch_count)
+    bool        gates_off = false;    // no kernel that makes workgroups wait for each other is chosen any more (t4k_gates_enable(0), or set by spin_check() after a timed-out wait)
     int         pending = 0;          // work a launch left for the NEXT entry point (pending.h): bit 0 = a conv stack's dF | dB partial fold
     unsigned long pending_owner = 0;  // the thread that left it (thread_key()): only THAT thread flushes or consumes it - a helper thread of the host (the dataset
                                       // reader waits on events through t4k_event_sync) must neither run the fold a second time nor clear the bit
     char        err[512] = {0};
 };
 State &st();
+inline bool gates_ok() { return !st().gates_off; }
 inline unsigned long thread_key() { static thread_local char k; return (unsigned long)(uintptr_t)&k; }   // cheap per-thread identity
 // every kernel launch of the library goes through this macro and is counted: bench.py prints the MEASURED launches per step
 #define T4K_LAUNCH(kernel, ...) do { ++t4k::st().launches; hipLaunchKernelGGLInternal((kernel), __VA_ARGS__); } while (0)
@@ -106,6 +108,7 @@ inline float *ws_for(const void *s) {            // accepts a t4k_stream_t or an
         if (++_it > T4K_SPIN_MAX) { if (g_spin_err_dev) __hip_atomic_store(g_spin_err_dev, (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; } } } while (0)
 void gemm_set_spin_err(int *p);          // gemm.hip
 void linsmall_set_spin_err(int *p);      // linear_small.hip
+inline bool gates_ok();                  // may a launcher pick a kernel whose workgroups wait for each other (arrival gates, tickets, band exchange)?
 int  spin_check();                       // runtime.hip: T4K_OK, or T4K_ERR_HIP when a wait timed out since the last check (clears the word)
 
 // Deferred work.  t4k_conv_stack_bwd(train | 4) leaves its per-workgroup dF | dB partial rows UNFOLDED: t4k_opt_step, when it is the next

@@ -128,7 +128,11 @@ def _adam_check(name, got, want, lr, g_first=None, steps=1):
 # element below a hundredth of its tensor's largest has no 1e-4 accuracy of its own on either side.  Measured over three seeds, floor 1e-3:
 # 15 of 131 072 (D 3 dW), 3 of 256 (D 6 dW), 45 of 401 408 (G 4 dW) elements beyond the bar; floor 1e-2: 420 of 200 704 (0.2 %) of the frozen
 # discriminator's dX on the worst seed, a handful elsewhere.  The LeNet configs (#3, #5) hold 99.99 % (tests/lenet_parity.py); here the bar is 99 %.
-GAN_ELEM = dict(floor=1e-2, elem_min=0.99, min_outliers=2)
+# Round 5: the parameter gradients are held to the LeNet floor (1e-3) at 99.9 % - the counts above are 0.011 % of the large tensors and
+# 3 elements of the 256-element one (min_outliers covers a tensor too small for a percentage); only the frozen discriminator's dX (a difference of two
+# backprops through three layers, 0.2 % beyond the bar at floor 1e-2 on the worst seed) keeps the 1e-2 floor, at 99.7 %.
+GAN_ELEM = dict(floor=1e-3, elem_min=0.999, min_outliers=4)
+GAN_ELEM_DX = dict(floor=1e-2, elem_min=0.997, min_outliers=2)
 
 
 def _gan_two_rounds(seed):
@@ -188,7 +192,7 @@ def _gan_two_rounds(seed):
             if not flipped2:
                 # (floor 1e-2 from here on: these gradients have passed through the discriminator's three layers backwards and - for G's - the
                 # generator's as well; an element below a hundredth of the tensor's largest carries the rounding of a six-GEMM chain on both sides)
-                check_tensor("round %d dX of the frozen D" % rnd, _fetch(g, "D", "0 n@"), _fetch(o, "D", "0 n@"), TOL, **GAN_ELEM)
+                check_tensor("round %d dX of the frozen D" % rnd, _fetch(g, "D", "0 n@"), _fetch(o, "D", "0 n@"), TOL, **GAN_ELEM_DX)
             for e in GG:
                 b = _fetch(o, "G", e); og[("G", e.replace("nn.d", "nn."))] = b
                 if not flipped2:
