@@ -128,11 +128,13 @@ def _adam_check(name, got, want, lr, g_first=None, steps=1):
 # element below a hundredth of its tensor's largest has no 1e-4 accuracy of its own on either side.  Measured over three seeds, floor 1e-3:
 # 15 of 131 072 (D 3 dW), 3 of 256 (D 6 dW), 45 of 401 408 (G 4 dW) elements beyond the bar; floor 1e-2: 420 of 200 704 (0.2 %) of the frozen
 # discriminator's dX on the worst seed, a handful elsewhere.  The LeNet configs (#3, #5) hold 99.99 % (tests/lenet_parity.py); here the bar is 99 %.
-# Round 5: the parameter gradients are held to the LeNet floor (1e-3) at 99.9 % - the counts above are 0.011 % of the large tensors and
-# 3 elements of the 256-element one (min_outliers covers a tensor too small for a percentage); only the frozen discriminator's dX (a difference of two
-# backprops through three layers, 0.2 % beyond the bar at floor 1e-2 on the worst seed) keeps the 1e-2 floor, at 99.7 %.
-GAN_ELEM = dict(floor=1e-3, elem_min=0.999, min_outliers=4)
-GAN_ELEM_DX = dict(floor=1e-2, elem_min=0.997, min_outliers=2)
+# Round 5 ("tighten to floor 1e-3 / 99.9 % if the data allow"): they allow it for the DISCRIMINATOR's parameter gradients (0.011 % of the large
+# tensors, 3 elements of the 256-element one: min_outliers covers tensors too small for a percentage) - those are now held to the LeNet floor.  They do not for
+# the GENERATOR's (gradients that have passed backwards through all six products): at floor 1e-3 its first layer shows 38 to 386 of 32 768 (0.1 - 1.2 %) depending
+# on the seed, its last layer up to 1 202 of 401 408 (0.3 %), its 784 bias gradients 6 - nor for the frozen discriminator's dX; those keep round 4's bar.
+GAN_ELEM_D = dict(floor=1e-3, elem_min=0.999, min_outliers=4)
+GAN_ELEM = dict(floor=1e-2, elem_min=0.99, min_outliers=2)
+GAN_ELEM_DX = GAN_ELEM
 
 
 def _gan_two_rounds(seed):
@@ -183,7 +185,7 @@ def _gan_two_rounds(seed):
             for e in DG:
                 b = _fetch(o, "D", e); og[("D", e.replace("nn.d", "nn."))] = b
                 if not flipped:
-                    check_tensor("round %d D %s (two accumulated backprops)" % (rnd, e), _fetch(g, "D", e), b, TOL, **GAN_ELEM)
+                    check_tensor("round %d D %s (two accumulated backprops)" % (rnd, e), _fetch(g, "D", e), b, TOL, **GAN_ELEM_D)
             if flipped:
                 adopt("D", DG)
             for vm in (g, o):
