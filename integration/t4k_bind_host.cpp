@@ -189,14 +189,14 @@ void Dataset::normalize(DU mean, DU scale) {
 }
 int Dataset::fetch(char *ds_name, bool rewind, bool trace) {
     ld::Corpus *cp = ld::Loader::get(*this, ds_name);
-    if (!cp) { ERROR("  dataset#fetch => not found in Loader\n"); return -1; }
+    if (!cp) { ERROR("  } dataset#fetch => not found in Loader\n"); return -1; }
     if (ds_name) {                                        // first use: dimensions from the corpus
-        if (cp->init(N(), trace) == NULL) { ERROR("  dataset#fetch => corpus init failed!\n"); return -2; }
+        if (cp->init(N(), trace) == NULL) { ERROR("  } dataset#fetch => corpus init failed!\n"); return -2; }
         dataset_size = cp->corpus_sz;
         _reshape(cp->N, cp->H, cp->W, cp->C);
     }
     if (rewind) { cp->rewind(); batch_id = done = 0; }
-    if (!cp->fetch(batch_id, trace)) { ERROR("  dataset#fetch => corpus fetch failed\n"); return -3; }
+    if (!cp->fetch(batch_id, trace)) { ERROR("  } dataset#fetch => corpus fetch failed\n"); return -3; }
     batch_sz = cp->batch_sz; done = cp->eof;
     if (trace) INFO("  dataset#fetch => batch[%d] %d record(s)%s\n", batch_id, batch_sz, done ? ", completed" : "");
     _load(cp->data, cp->label, batch_sz);                 // t4k_bind.cpp: one H2D copy + u8 -> f32 on the GPU

@@ -53,12 +53,16 @@ int VM::find(const char *name) {
     return 0;
 }
 void VM::add(const char *name, std::function<void()> f, bool immd) {
+    // a built-in defined again (the tensor / nn vocabularies redefine `@ max min relu tanh sigmoid normalize flatten save load boot`) REPLACES the entry in
+    // place, as MMU::add_word does (mmu.h:68-93: "*** redefined"): dictionary indices - what `'` pushes, what mstat counts - stay the reference's.  The
+    // replaced body stays callable by the new one (shadow_).
+    if (const int w = find(name)) { shadow_[name] = std::move(dict_[w].xt); dict_[w].xt = std::move(f); dict_[w].immd = immd; return; }
     Word w; w.name = name; w.immd = immd; w.xt = std::move(f); dict_.push_back(std::move(w));
 }
 void VM::add_cell(uint32_t v) { if (here_ + 4 <= PMEM_SZ) { set_cell(here_, v); here_ += 4; } else pstr("pmem full\n"); }
 void VM::add_du(DU d) { uint32_t u; memcpy(&u, &d, 4); add_cell(u); }
 void VM::add_p(int op, uint32_t operand, bool udf, bool exit) {
-    add_cell(((uint32_t)op << 28) | (udf ? 1u << 27 : 0) | (exit ? 1u << 26 : 0) | (operand & 0xFFFFFFu));
+    add_cell(((uint32_t)op << 24) | (udf ? 1u << 28 : 0) | (exit ? 1u << 31 : 0) | (operand & 0xFFFFFFu));   // struct Param vm/param.h:15-26: ioff 24 | op 4 | udf 1 | 2 | exit 1 - `dump` shows the reference's bytes
 }
 void VM::add_lit(DU v, bool exit) { add_p(P_LIT, 0, false, exit); add_du(v); }
 void VM::add_w(int w) { Word &c = dict_[w]; add_p(P_WORD, c.udf ? c.pfa : (uint32_t)w, c.udf); }
@@ -75,6 +79,7 @@ bool VM::new_word() {
     if (find(name)) { pstr(name); pstr(" reDef? \n"); }
     Word w; w.name = name; w.udf = true;
     here_ = ALIGN4(here_);
+    add_str(w.name);                                     // the name lives in front of the parameter field (MMU::colon mmu.cu:148-159): `here`, `see` and `dump` show the reference's addresses
     w.pfa = here_;
     dict_.push_back(std::move(w));
     return true;
@@ -88,14 +93,14 @@ void VM::ds_next(uint32_t target) {                      // ForthVM::_ds_next ef
     if (d.type != T_DATASET) { pstr("RTOS is not a dataset?\n"); return; }
     Dataset &ds = (Dataset &)d;
     if (ds.done) { DU v = rs_pop(); DROP(v); ((Model &)m).tick(); }
-    else { ds.fetch(nullptr, false); ip_ = target; hold_ = true; }   // serviced inline (reference: OP_FETCH + HOLD)
+    else { hold_begin(); ds.fetch(nullptr, false); ip_ = target; hold_end(); }   // serviced inline (reference: OP_FETCH + HOLD)
 }
 void VM::nest() {
     query_ = false;
     while (ip_ && !stop_) {
         const uint32_t ix = cell(ip_);
-        const int op = ix >> 28; const uint32_t ioff = ix & 0xFFFFFFu;
-        const bool udf = (ix >> 27) & 1, exitf = (ix >> 26) & 1;
+        const int op = (ix >> 24) & 15; const uint32_t ioff = ix & 0xFFFFFFu;
+        const bool udf = (ix >> 28) & 1, exitf = (ix >> 31) & 1;
         ip_ += 4;
         switch (op) {
         case P_EXIT: ip_ = (uint32_t)rs_pop(); break;
@@ -125,14 +130,14 @@ void VM::nest() {
         case P_KEY:  PUSH((DU)getchar()); break;
         default:
             if (udf) { rs_.push_back((DU)ip_); ip_ = ioff; }
-            else dict_[ioff].xt();
+            else { dict_[ioff].xt(); if (hold_) msg_pos_ = out_.size(); }   // (a serviced word: later diagnostics follow what the service printed)
         }
     }
 }
 void VM::call(int w) {
     Word &c = dict_[w];
     if (c.udf) { rs_.push_back((DU)ip_); ip_ = c.pfa; nest(); }
-    else c.xt();
+    else { c.xt(); if (hold_) msg_pos_ = out_.size(); }
 }
 
 // ---------------------------------------------------------------- outer interpreter
@@ -157,7 +162,12 @@ int VM::process(const char *idiom) {                     // TensorVM::process te
         return 1;
     }
     bool ok; DU n = number(idiom, ok);
-    if (!ok) return 0;
+    if (!ok) {                                           // ForthVM::number eforth.cpp:470-473 (ERROR = printf: in front of the line's buffered text, as there)
+        const char *t = idiom; int b = base();
+        switch (*t) { case '%': b = 2; t++; break; case '&': case '#': b = 10; t++; break; case '$': b = 16; t++; break; }
+        hprintf(" number(%s) base=%d => error\n", t, b);
+        return 0;
+    }
     n = SCALAR(n);
     if (compile_) add_lit(n);
     else if (ten_lvl_ > 0) {                             // literal goes into the tensor on TOS
@@ -169,6 +179,7 @@ int VM::process(const char *idiom) {                     // TensorVM::process te
 bool VM::eval(const std::string &line) {
     SinkScope sink(this);
     line_ = line; pos_ = 0;
+    msg_pos_ = out_.size();                              // (the previous line's output has been flushed)
     const char *idiom;
     while (!stop_ && (idiom = fetch()) != nullptr) {
         std::string tk = idiom;
@@ -195,7 +206,7 @@ void VM::dot_obj(DU v) {
     if (o.type == T_MODEL) pstr(fmt_model((Model &)o)); else pstr(fmt_tensor((Tensor &)o));
 }
 void VM::dot(DU v) {
-    if (IS_OBJ(v)) { dot_obj(v); pstr(" "); st().mark_free(v); hold_ = true; return; }   // ForthVM::_print eforth.cpp:559-567
+    if (IS_OBJ(v)) { hold_begin(); dot_obj(v); pstr(" "); st().mark_free(v); hold_end(); return; }   // ForthVM::_print eforth.cpp:559-567
     char buf[48]; snprintf(buf, sizeof(buf), "%g", v);   // ostream << float, default precision 6
     std::string s = buf;
     if (fmt_w_ > (int)s.size()) s = std::string(fmt_w_ - s.size(), ' ') + s;
@@ -220,26 +231,42 @@ void VM::words() {
     }
     pstr("\n");
 }
-void VM::see(int w) {
+void VM::see(int w) {                                    // Debug::see / _see debug.cpp:136-166,206-249
     Word &c = dict_[w];
-    pstr(": "); pstr(c.name);
-    if (!c.udf) { pstr(" ( built-in ) ;\n"); return; }
-    static const char *pn[] = {";", "next", "loop", "lit", "var", "str", "dotq", "bran", "0bran", "for", "do", "key"};
-    uint32_t end = (w + 1 < (int)dict_.size() && dict_[w + 1].udf) ? dict_[w + 1].pfa : here_;
-    for (uint32_t a = c.pfa; a + 4 <= end;) {
-        uint32_t ix = cell(a); int op = ix >> 28; uint32_t ioff = ix & 0xFFFFFFu; a += 4;
-        char buf[96];
+    pstr(": "); pstr(c.name); pstr("\n");
+    if (!c.udf) { pstr(" ( built-ins ) ;\n"); return; }
+    static const char *pn[] = {";", "next ", "loop ", "lit", "var", "str", "dotq", "bran ", "0bran", "for  ", "do", "key"};
+    auto nfa = [&](int i) { return dict_[i].pfa - ALIGN4((uint32_t)dict_[i].name.size() + 1); };
+    for (uint32_t a = c.pfa; a + 4 <= (uint32_t)PMEM_SZ;) {
+        const uint32_t ix = cell(a); const int op = (ix >> 24) & 15; const uint32_t ioff = ix & 0xFFFFFFu; const bool udf = (ix >> 28) & 1, exitf = (ix >> 31) & 1;
+        int idx = op;
         if (op == P_WORD) {
-            const char *nm = "?";
-            if ((ix >> 27) & 1) { for (auto &d : dict_) if (d.udf && d.pfa == ioff) nm = d.name.c_str(); }
-            else if (ioff < dict_.size()) nm = dict_[ioff].name.c_str();
-            snprintf(buf, sizeof(buf), "\n  %04x: %s", a - 4, nm);
-        } else if (op == P_LIT) { snprintf(buf, sizeof(buf), "\n  %04x: lit %g", a - 4, mem_du(a)); a += 4; }
-        else if (op == P_STR || op == P_DOTQ) { snprintf(buf, sizeof(buf), "\n  %04x: %s \"%s\"", a - 4, pn[op], (const char *)&pmem_[a]); a += ioff; }
-        else if (op == P_VAR) { snprintf(buf, sizeof(buf), "\n  %04x: var %g", a - 4, mem_du(a)); a = end; }
-        else snprintf(buf, sizeof(buf), "\n  %04x: %s %04x", a - 4, op < 12 ? pn[op] : "?", ioff);
-        pstr(buf);
-        if (op == P_EXIT) break;
+            idx = -1;
+            if (udf) { for (int i = (int)dict_.size() - 1; i > 0; --i) if (dict_[i].udf && dict_[i].pfa == ioff) { idx = i; break; } }
+            else if (ioff < dict_.size()) idx = (int)ioff;
+            if (idx < 0) break;
+        }
+        char buf[64]; snprintf(buf, sizeof(buf), "  ( %04x[%3x] ) ", a, idx); pstr(buf);
+        a += 4;
+        bool done = false;
+        if (op == P_WORD) { pstr(dict_[idx].name); pstr("  "); }
+        else {
+            switch (op) {
+            case P_LIT:  pstr(fmt_scalar(mem_du(a), base())); break;
+            case P_STR:  pstr("s\" "); pstr((const char *)&pmem_[a]); pstr("\""); break;
+            case P_DOTQ: pstr(".\" "); pstr((const char *)&pmem_[a]); pstr("\""); break;
+            case P_VAR: {
+                const uint32_t end = ioff ? ioff : ((w + 1 < (int)dict_.size()) ? nfa(w + 1) : here_);
+                for (uint32_t v = a; v + 4 <= end; v += 4) { char t[32]; snprintf(t, sizeof(t), "%g ", mem_du(v)); pstr(t); }
+            }   /* falls through: the primitive's name follows the values */
+            default: pstr(op < 12 ? pn[op] : "?"); break;
+            }
+            if (op == P_NEXT || op == P_LOOP || op == P_BRAN || op == P_ZBRAN) { snprintf(buf, sizeof(buf), " \\ $%04x", ioff); pstr(buf); }
+            done = op == P_EXIT || (op == P_LIT && exitf) || (op == P_VAR && !ioff);
+        }
+        if (done) break;
+        pstr("\n");
+        switch (op) { case P_LIT: a += 4; break; case P_VAR: a = ioff; break; case P_STR: case P_DOTQ: a += ioff; break; default: break; }
     }
     pstr("\n");
 }
@@ -411,7 +438,7 @@ void VM::init_core() {
     CODE("create", [this] { if (!new_word()) return; add_p(P_VAR, 0, true); });
     CODE("does>",  [this] {
         uint32_t pfa = dict_.back().pfa;
-        while ((cell(pfa) >> 28) != P_VAR && pfa < here_) pfa += 4;
+        while (((cell(pfa) >> 24) & 15) != P_VAR && pfa < here_) pfa += 4;
         setjmp_at(pfa);
         add_p(P_BRAN, ip_); ip_ = (uint32_t)rs_pop();
     });
@@ -419,7 +446,7 @@ void VM::init_core() {
         int w = query_ ? find(fetch() ? tok_.c_str() : "") : POPi();
         if (!w) return;
         if (compile_) { add_lit((DU)w); add_w(find("to")); }
-        else { uint32_t pfa = dict_[w].pfa; if ((cell(pfa) >> 28) == P_LIT) set_du(pfa + 4, POP()); }
+        else { uint32_t pfa = dict_[w].pfa; if (((cell(pfa) >> 24) & 15) == P_LIT) set_du(pfa + 4, POP()); }
     });
     IMMD("is", [this] {
         int w = query_ ? find(fetch() ? tok_.c_str() : "") : POPi();
@@ -452,18 +479,25 @@ void VM::init_core() {
     CODE("dict",  [this] { words(); });
     CODE("dict_dump", [this] { words(); });
     CODE("see",   [this] { const char *n = fetch(); int w = n ? find(n) : 0; if (w) see(w); });
-    CODE("dump",  [this] {
+    CODE("dump",  [this] {                                  // Debug::mem_dump debug.cpp:110-132: 16 bytes per line, hex in groups of four, then the 7-bit characters
         int n = POPi(); uint32_t a = (uint32_t)POP();
-        for (uint32_t i = a & ~15u; i <= ((a + n + 15) & ~15u) && i + 16 <= PMEM_SZ; i += 16) {
+        auto al16 = [](uint32_t v) { return v + ((0u - v) & 0xFu); };
+        for (uint32_t i = al16(a); i <= al16(a + n) && i + 16 <= PMEM_SZ; i += 16) {
             char b[96]; int x = snprintf(b, sizeof(b), "%04x: ", i);
-            for (int j = 0; j < 16; j++) x += snprintf(b + x, sizeof(b) - x, "%02x%s", pmem_[i + j], (j % 4 == 3) ? "  " : " ");
-            pstr(b); pstr("\n");
+            char asc[17];
+            for (int j = 0; j < 16; j++) {
+                const uint8_t c = pmem_[i + j], c7 = c & 0x7f;
+                x += snprintf(b + x, sizeof(b) - x, "%02x %s", c, (j % 4 == 3) ? " " : "");
+                asc[j] = (c7 == 0x7f || c7 < 0x20) ? '.' : (char)c7;
+            }
+            asc[16] = 0;
+            pstr(b); pstr(asc); pstr("\n");
         }
     });
     CODE("forget", [this] {
         const char *n = fetch(); int w = n ? find(n) : 0; if (!w) return;
-        int b = find("boot") + 1; if (w < b) w = b;
-        if (dict_[w].udf) here_ = dict_[w].pfa;
+        int b = user0_ + 1; if (w < b) w = b;                 // (the reference clears from its eForth `boot` entry on, vocabularies and all: eforth.cpp:504-506)
+        if (dict_[w].udf) here_ = dict_[w].pfa - (uint32_t)dict_[w].name.size();   // MMU::clear mmu.h:95-98 (name length, unaligned)
         dict_.resize(w);
     });
     CODE("trace", [this] { trace_lvl = POPi(); });
@@ -474,7 +508,7 @@ void VM::init_core() {
         pstr(b);
     });
     CODE("ms",    [this] { std::this_thread::sleep_for(std::chrono::milliseconds(POPi())); });
-    CODE("flush", [this] { fflush(stdout); hold_ = true; });
+    CODE("flush", [this] { fflush(stdout); hold_end(); });
     CODE("sprintf", [this] {                             // ( n1 [n2 ..] addr u -- addr' u' )  eforth.cpp:576-611
         POPi(); std::string buf = (const char *)&pmem_[(uint32_t)POP()];
         auto t2s = [this](char c) {

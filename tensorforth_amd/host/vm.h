@@ -4,6 +4,7 @@
 // services dataset / print requests inline instead of the reference's HOLD + event-queue protocol.
 #pragma once
 #include "t4.h"
+#include <map>
 
 namespace t4 {
 
@@ -23,21 +24,29 @@ public:
     void init();
     // feed one line of Forth source; returns false after `bye`
     bool eval(const std::string &line);
-    std::string take_output() { std::string s; s.swap(out_); return s; }
+    std::string take_output() { std::string s; s.swap(out_); msg_pos_ = 0; return s; }
     bool done() const { return stop_; }
     Tensor *tos_tensor() { return TOS1T() ? &TTOS() : nullptr; }   // embedding API: the tensor on top of the data stack (ten4_fetch)
-    void host_msg(const char *t) { out_ += t; }   // host-layer diagnostics (hprintf) routed here by the sink
+    // Host-layer diagnostics (hprintf: the reference's INFO / ERROR, plain printf).  The reference's VM text is BUFFERED (events rendered by System::flush at the
+    // end of the line or at a HOLD, sys.cpp:110-120) while those printf calls write at once: on one input line every such message comes out IN FRONT of what the
+    // VM words of that line printed since the last flush.  msg_pos_ = where the unflushed part of this VM's output begins.
+    void host_msg(const char *t) { const size_t at = msg_pos_ <= out_.size() ? msg_pos_ : out_.size(); const size_t n = strlen(t); out_.insert(at, t); msg_pos_ = at + n; }
     int  trace_lvl = 1;                       // T4_VERBOSE default, `trace` word
 
 private:
     static constexpr int PMEM_SZ = 48 * 1024;
     std::vector<Word> dict_;
+    std::map<std::string, std::function<void()>> shadow_;   // bodies replaced by a redefinition of a built-in (VM::add)
+    int user0_ = 0;                           // index of the `User::` marker: user words start behind it
     std::vector<DU> ss_, rs_;
     DU tos_ = -1.0f;
     std::vector<uint8_t> pmem_;
     uint32_t here_ = 16;                      // user area: pmem[0] = base
     uint32_t ip_ = 0;
     bool compile_ = false, stop_ = false, query_ = true;
+    size_t msg_pos_ = 0;
+    void hold_begin() { msg_pos_ = out_.size(); }          // a host service starts: everything buffered so far is flushed first, the service's own messages follow it
+    void hold_end() { hold_ = true; msg_pos_ = out_.size(); }
     bool hold_ = false;                       // a word asked for host service (reference: state = HOLD, eforth.h:85-92): the outer interpreter
                                               // drops the rest of the input line (sys.cpp:101-108 clears the buffer after resume(), vm.cpp:59)
     std::string line_; size_t pos_ = 0;

@@ -210,7 +210,7 @@ void VM::init_tensor() {
         POPi(); uint32_t adr = (uint32_t)POPi();
         const char *fn = (const char *)&pmem_[adr];
         if (!TOS1T()) { pstr("tensor adr len [mode]?\n"); return; }
-        hold_ = true;                                    // syscall(OP_TSAVE / OP_TLOAD), tenvm.cpp:408
+        hold_begin(); hold_ = true;                      // syscall(OP_TSAVE / OP_TLOAD), tenvm.cpp:408 (serviced at the flush: its messages follow the buffered text)
         Tensor &t = TTOS();
         if (load) {
             FILE *f = fopen(fn, "rb"); if (!f) { pstr(" failed to open for input\n"); return; }
@@ -262,7 +262,7 @@ void VM::init_tensor() {
             char b[200]; snprintf(b, sizeof(b), "  sys#tbx(op=%d, n=%g, i=%d, tag=%s)\n", op, n, i, tag.c_str());
             pstr(b);
         }
-        if (IS_OBJ(n)) { st().mark_free(n); hold_ = true; }   // tenvm.cpp:418-420
+        if (IS_OBJ(n)) { st().mark_free(n); hold_end(); }   // tenvm.cpp:418-420
     };
     CODE(".tbinit", [tb] { tb("init", 0, true); });
     CODE(".tbstep", [this] { int i = POPi(); if (tb_active()) { tb_step(i); return; }
@@ -453,20 +453,22 @@ void VM::init_nn() {
         const char *dsn = fetch(); std::string name = dsn ? dsn : "";
         Dataset &ds = st().dataset((uint32_t)POPi());
         PUSH(ds);
+        hold_begin();
         ds.fetch(name.c_str(), false);                   // loads batch 0 immediately (sys.cpp:166-174)
-        hold_ = true;
+        hold_end();
     });
     CODE("normalize", [this] {                           // ( DS mean scale -- DS' ) on a dataset, else the tensor word
         if (SP() > 1 && is_d(SS(-2))) {
             DU scale = POP(); int mean = POPi();
             Dataset &ds = (Dataset &)st().du2obj(tos_);
+            hold_begin();
             char b[96]; snprintf(b, sizeof(b), "  OP_NORM(mean=%d, scale=%g)\n", mean, scale); pstr(b);
             ds.set_norm((DU)mean, scale); ds.fetch(nullptr, true);
-            hold_ = true;
+            hold_end();
         } else { DU std = POP(), avg = POP(); if (TOS1T()) TTOS().normalize(std, avg); }
     });
-    CODE("fetch",  [this] { if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, false); hold_ = true; });
-    CODE("rewind", [this] { if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, true); hold_ = true; });
+    CODE("fetch",  [this] { hold_begin(); if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, false); hold_end(); });
+    CODE("rewind", [this] { hold_begin(); if (is_d(tos_)) ((Dataset &)st().du2obj(tos_)).fetch(nullptr, true); hold_end(); });
     CODE("forward", [this] {                             // netvm.cpp:230-247
         if (is_m(SS(-1)) && TOS1D()) {
             DU x = POP();
@@ -512,13 +514,13 @@ void VM::init_nn() {
         POPi(); const uint32_t adr = (uint32_t)POPi();
         const char *fn = (const char *)&pmem_[adr];
         if (!is_m(tos_)) return;
-        hold_ = true;                                    // syscall(OP_NSAVE / OP_NLOAD), netvm.cpp:148-152
+        hold_begin(); hold_ = true;                      // syscall(OP_NSAVE / OP_NLOAD), netvm.cpp:148-152
         if (save) model_save(MTOS(), fn); else model_load(MTOS(), fn);
     };
-    CODE("save", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(true); else { int w = 0; for (int i = 1; i < (int)dict_.size(); i++) if (dict_[i].name == "save") { w = i; break; } if (w) dict_[w].xt(); } });
-    CODE("load", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(false); else { int w = 0; for (int i = 1; i < (int)dict_.size(); i++) if (dict_[i].name == "load") { w = i; break; } if (w) dict_[w].xt(); } });
+    CODE("save", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(true); else { auto it = shadow_.find("save"); if (it != shadow_.end()) it->second(); } });   // a tensor: the tensor vocabulary's word
+    CODE("load", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(false); else { auto it = shadow_.find("load"); if (it != shadow_.end()) it->second(); } });
     CODE("\nUser::", [] {});
-    const int user0 = (int)dict_.size();
+    const int user0 = (int)dict_.size() - 1; user0_ = user0;
     CODE("boot", [this, user0] { if ((int)dict_.size() > user0 + 1) { if (dict_[user0 + 1].udf) here_ = dict_[user0 + 1].pfa; dict_.resize(user0 + 1); } });
 }
 
