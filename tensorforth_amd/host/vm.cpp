@@ -505,7 +505,7 @@ void VM::init_core() {
         char b[240]; snprintf(b, sizeof(b), "\\ MMU.stat dict[%d/1024], pmem[%d]=%0.1f%%, obj#used[%d], HBM used=%zu KiB in %zu blocks (peak %zu KiB, %zu free block(s), %zu slab(s))\n",
                               (int)dict_.size(), here_, 100.0 * here_ / PMEM_SZ, st().live(), Arena::get().used() >> 10, Arena::get().live(),
                               Arena::get().peak() >> 10, Arena::get().free_blocks(), Arena::get().slabs());
-        pstr(b);
+        hprintf("%s", b);                                  // MMU::status is a plain printf (mmu.cu:124-128): in front of the line's buffered text
     });
     CODE("ms",    [this] { std::this_thread::sleep_for(std::chrono::milliseconds(POPi())); });
     CODE("flush", [this] { fflush(stdout); hold_end(); });

@@ -124,6 +124,33 @@ def test_committed_goldens_are_the_reference_vms_output(refhost, workdir, name):
         assert compare(ref, f.read(), rtol=0, atol=0) == [], "stale golden: run tools/regen_vm_goldens.py"
 
 
+# The reference's remaining examples, as far as a CPU replay can take them: the definitions, model / dataset set-up, `see` listings and layer tables of the
+# long trainers up to the line that starts the epochs (20 - 100 epochs of MNIST on the CPU oracle would take hours), t4_20a with its 1000-product benchmark
+# cut to one product, t4_30d with its trace level set to 0 (trace output is not compared).  Edits are made on the text read at test time, never stored.
+def _prefix(name, n_lines):
+    return "".join(open(os.path.join(REF, "examples", name + ".4th")).readlines()[:n_lines]) + "\nbye\n"
+
+
+PARTIAL = {
+    "t4_20a": lambda: open(os.path.join(REF, "examples", "t4_20a.4th")).read().replace("999 mx", "0 mx").replace("1 trace", "0 trace"),
+    "t4_30d": lambda: open(os.path.join(REF, "examples", "t4_30d.4th")).read().replace("2 trace", "0 trace"),
+    "t4_30e": lambda: _prefix("t4_30e", 86),              # everything in front of `### start training`
+    "t4_40a": lambda: _prefix("t4_40a", 73),              # ... of the epochs
+    "t4_40b": lambda: _prefix("t4_40b", 78),              # ... of `D ds0 99 gan`
+}
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(PARTIAL))
+def test_reference_examples_partial_replay_through_both_vms(refhost, workdir, name):
+    src = "0 trace\n" + PARTIAL[name]()
+    ref = _norm(_ref_text(_run(refhost, src, workdir)))
+    own = _norm(_run(TEN4_ORACLE, src, workdir))
+    ref, own = (re.sub(r"=> \S+\s+msec/cycle", "=> <t> msec/cycle", t) for t in (ref, own))   # (a timing; the product's `clock` also keeps fractions of a millisecond)
+    bad = compare(ref, own, rtol=0, atol=0)
+    assert bad == [], name + ": " + "\n".join(bad)
+
+
 @needs_ref
 def test_model_file_bytes_reference_saver_vs_product_saver(refhost, workdir, tmp_path):
     """f-2: src/io/aio_model.cpp:16-61,143-180 (run for real) and host/model.cpp write the same bytes; the fixture is that file"""
