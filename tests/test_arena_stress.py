@@ -18,34 +18,42 @@ SCRIPT = r'''0 trace
 : mixed ( n -- ) 0 do i 5 mod 1 + 100 * i 3 mod 1 + 10 * matrix i 7 mod 1 + 32 * vector drop drop loop ;
 mstat
 100000 churn
-." after_churn " mstat
+." after_churn " cr
+mstat
 30000 mixed
-." after_mixed " mstat
+." after_mixed " cr
+mstat
 \ long-lived tensors interleaved with garbage: 64 survivors of growing size
 : hold ( -- t1 .. t64 ) 64 0 do i 1 + 256 * vector 1000 vector drop loop ;
 hold
-." holding " mstat
+." holding " cr
+mstat
 \ fragmentation: survivors A with a freed block B between each pair (B is allocated between two A's, then dropped from under the top)
 : frag ( -- A0 .. A32 ) 256 vector 32 0 do i 1 + 300 * vector i 2 + 256 * vector swap drop loop ;
 frag
-." fragged " mstat
+." fragged " cr
+mstat
 \ holes of 300 .. 9600 floats are now scattered between live blocks: best fit must reuse them for same-size requests (no new slab)
 : refill ( -- B0 .. B31 ) 32 0 do i 1 + 300 * vector loop ;
 refill
-." refilled " mstat
+." refilled " cr
+mstat
 : dropall ( .. n -- ) 0 do drop loop ;
 129 dropall
-." dropped " mstat
+." dropped " cr
+mstat
 \ a tensor larger than a slab gets a slab of its own
 600000 vector drop
-." big " mstat
+." big " cr
+mstat
 bye
 '''
 
 
 def _stats(out):
     res = {}
-    for m in re.finditer(r"(\w+)\s+\\ MMU\.stat .*?obj#used\[(\d+)\], HBM used=(\d+) KiB in (\d+) blocks \(peak (\d+) KiB, (\d+) free block\(s\), (\d+) slab\(s\)\)", out):
+    # (label on its own line, `mstat` on the next: the reference's mstat is a plain printf, which on ONE line would come out in front of the buffered label)
+    for m in re.finditer(r"(\w+) \n[^\n]*-> ok\n\\ MMU\.stat .*?obj#used\[(\d+)\], HBM used=(\d+) KiB in (\d+) blocks \(peak (\d+) KiB, (\d+) free block\(s\), (\d+) slab\(s\)\)", out):
         res[m.group(1)] = dict(objs=int(m.group(2)), kib=int(m.group(3)), blocks=int(m.group(4)), peak=int(m.group(5)), free=int(m.group(6)), slabs=int(m.group(7)))
     return res
 
