@@ -164,6 +164,35 @@ def test_model_file_bytes_reference_saver_vs_product_saver(refhost, workdir, tmp
     assert blobs[0] == open(os.path.join(FIX, "ref_model_roundtrip.t4"), "rb").read(), "stale fixture: run tools/regen_vm_goldens.py"
 
 
+TSAVE = """0 trace
+2 3 matrix{ 1 2 3 4 5 6 } s" m.txt" save
+drop
+12 vector gradfill s" v.txt" save
+drop
+2 2 2 3 tensor rand s" t.txt" save
+drop
+30 30 matrix ones 0.5 *= s" big.txt" save
+drop
+2 3 matrix{ 0.5 0.25 0.125 0.75 0.999 0 } s" raw.t4" bin save
+drop
+bye
+"""
+
+
+@needs_ref
+def test_tensor_files_reference_writer_vs_product_writer(refhost, tmp_path):
+    """`save` of a tensor (tenvm.cpp:389-410 -> AIO::tsave aio_tensor.cpp:75-93, text form :230-238): the reference's own writer and the product's write the same
+    bytes - vector, matrix, rank-4 tensor with channels, and a matrix above the screen printer's elision threshold (saved text is not elided below 1 024 cells).
+    `bin save`: the reference opens the file read-only and writes nothing (decided hazard); the product writes the raw layout the reference defines."""
+    dirs = []
+    for i, binary in enumerate((refhost, TEN4_ORACLE)):
+        d = tmp_path / ("t%d" % i); d.mkdir(); dirs.append(d)
+        _run(binary, TSAVE, str(d))
+    for f in ("m.txt", "v.txt", "t.txt", "big.txt"):
+        assert (dirs[0] / f).read_bytes() == (dirs[1] / f).read_bytes(), f
+    assert not (dirs[0] / "raw.t4").exists() and (dirs[1] / "raw.t4").read_bytes()[:2] == b"T4"
+
+
 def _tb_files(binary, tmp, args, preload):
     tb = os.path.join(str(tmp), "tb"); os.makedirs(tb)
     _run(binary, open(TB_SCRIPT).read(), str(tmp), args=[a.replace("@", tb) for a in args], preload=preload)
