@@ -78,6 +78,10 @@ void Corpus::idle() {                                    // wait for outstanding
     if (worker) { Reader *r = (Reader *)worker; std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r] { return !r->busy && r->queue[0] < 0 && r->queue[1] < 0; }); }
     for (int s = 0; s < 2; s++) { if (pin_wait[s] && pin_ev[s]) t4k_event_sync(pin_ev[s]); pin_wait[s] = false; slot_bid[s] = -1; slot_n[s] = 0; }
 }
+void Corpus::settle() {                                  // as idle(), but the slots keep what they hold: a `rewind` at the end of an epoch finds batches 0 and 1 already read
+    if (worker) { Reader *r = (Reader *)worker; std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [r] { return !r->busy && r->queue[0] < 0 && r->queue[1] < 0; }); }
+    for (int s = 0; s < 2; s++) { if (pin_wait[s] && pin_ev[s]) t4k_event_sync(pin_ev[s]); pin_wait[s] = false; }
+}
 void Corpus::request(int bid) {                          // the staging launch of the batch the slot holds now must have been ISSUED
     if (bid < 0 || bid >= n_batches() || slot_bid[bid & 1] == bid) return;
     ensure_slots();
@@ -171,8 +175,8 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     }
     if (!cp) { hprintf("  } dataset#fetch => not found in Loader\n"); return -1; }
     die_if_no_backend();
-    if (rewind) {                                        // also after `normalize`: whatever was staged ahead is void
-        cp->idle();
+    if (rewind) {                                        // also after `normalize`: whatever was staged ahead on the DEVICE is void (the pinned raw bytes are not)
+        if (ds_name) cp->idle(); else cp->settle();
         for (int i = 0; i < RING; i++) { if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]); dev_bid[i] = -1; }
         mark_bid = -1;
         batch_id = done = 0;
@@ -223,6 +227,8 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
         }
         cp->request(b1);                                 // no-op when the slot holds (or is being filled with) that batch
         cp->request(b + 2);                              // slot b & 1: batch b's staging launch has been issued, the reader waits for its event
+    } else {                                             // last batch of the epoch: the training loops rewind next - the reader wraps around ahead of them (it waits for
+        cp->request(0); cp->request(1);                  // the staging launches of the batches the slots held), so the rewind costs no synchronous read
     }
     batch_id++;
     return 0;

@@ -197,7 +197,7 @@ struct Corpus {
     void ensure_slots();
     void request(int bid);                     // read batch bid into slot bid & 1, asynchronously
     int  wait_batch(int bid);                  // samples of batch bid once its slot is filled (reads inline when nobody was asked to)
-    void idle();                               // wait for the reader and forget what the slots hold
+    void idle(); void settle();                               // wait for the reader and forget what the slots hold
 };
 struct Dataset : Tensor {
     uint64_t dataset_size = 0;
