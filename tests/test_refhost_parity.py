@@ -219,6 +219,27 @@ def test_tensorboard_bytes_reference_writer_vs_product_sink(refhost, tmp_path):
     assert ref["events"] == open(os.path.join(FIX, "tb_events.tfevents"), "rb").read(), "stale fixture: run tools/regen_vm_goldens.py"
 
 
+TB_INIT = """0 trace
+0.25 s" a/x" .scalar
+s" second run" .tbinit
+5 .tbstep
+0.75 s" a/x" .scalar
+bye
+"""
+
+
+@needs_ref
+def test_tbinit_opens_the_same_second_run_in_both(refhost, tmp_path):
+    """`.tbinit` (Summary::init summary.cpp:18-28): a new run directory (name escaped) under the same logdir, a fresh events file with its own header record"""
+    got = []
+    for i, (binary, args, pre) in enumerate(((refhost, ["-t@", "-rrun1"], True), (TEN4_ORACLE, ["-t", "@", "-r", "run1"], False))):
+        tb = tmp_path / ("tb%d" % i); tb.mkdir()
+        _run(binary, TB_INIT, str(tmp_path), args=[a.replace("@", str(tb)) for a in args], preload=pre)
+        files = sorted(glob.glob(os.path.join(str(tb), "*", "events.out.tfevents.*")))
+        got.append({os.path.basename(os.path.dirname(f)): open(f, "rb").read() for f in files})
+    assert sorted(got[0]) == ["run1", "second_run"] and got[0] == got[1]
+
+
 def test_tensorboard_fixture_from_the_reference_writer_matches_the_product_sink(tmp_path):
     """runs everywhere (the fixture travels): the product's host over the oracle writes the committed bytes of the reference's writer"""
     if not os.path.exists(TEN4_ORACLE):
