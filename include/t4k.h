@@ -479,6 +479,7 @@ int t4k_opt_step(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *ta
  * linear layer (`in = dX`, backprop.cu:240, is read by no training loop) and needs the weights of that backward should a word ask for
  * it after the step.  G == NULL cancels a pending request. */
 int t4k_opt_snapshot(const float *G, float *G_PREV);
+int t4k_opt_snapshot_pending(void);              /* 1 while a request has not been consumed by an optimizer launch (a host checks it after ITS launch) */
 int t4k_opt_step_dp(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
                     float lr, float b1, float b2, float wd, float *slab, long slab_n, t4k_stream_t s);
 

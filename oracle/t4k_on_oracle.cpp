@@ -258,6 +258,7 @@ int t4k_conv2d_block_fwd(const float *I, float *IC, float *O, const float *F, co
 }
 static const float *g_keep_src = nullptr; static float *g_keep_dst = nullptr;
 int t4k_opt_snapshot(const float *G, float *G_PREV) { g_keep_src = G; g_keep_dst = G ? G_PREV : nullptr; return T4K_OK; }
+int t4k_opt_snapshot_pending(void) { return g_keep_src ? 1 : 0; }
 int t4k_opt_multi(int kind, const t4k_param_rec *tab, int nt, long, float lr, float b1, float b2, float wd, t4k_stream_t) {
     for (int i = 0; i < nt; i++) {
         const t4k_param_rec &r = tab[i];

@@ -274,6 +274,7 @@ int t4k_opt_snapshot(const float *G, float *G_PREV) {
     g_keep_src = G; g_keep_dst = G ? G_PREV : nullptr;
     return T4K_OK;
 }
+int t4k_opt_snapshot_pending(void) { return g_keep_src ? 1 : 0; }
 int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n_chunks,
                     float lr, float b1, float b2, float wd, t4k_stream_t s) {
     T4K_REQUIRE_INIT(); if (n_tensors <= 0 || n_chunks <= 0) return T4K_OK;

@@ -934,7 +934,11 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     if (dx0_stale_ && dx0_lin_ && !w0_saved_) {          // a deferred dX0 = dY W needs the weights of its backward: the update launch leaves them in w0_save_
         Tensor &w0 = *at(0).grad[0];
         if (!w0_save_) w0_save_ = &T4(w0.N(), w0.H(), w0.W(), w0.C());
-        t4k_opt_snapshot(w0.data, w0_save_->data); w0_saved_ = true;
+        // the snapshot rides in THIS model's next t4k_opt_step launch; an update served by a graph replay (arguments baked at capture) would never take it:
+        // there the copy is a launch of its own (the request is a process-global one-shot)
+        if (use_graphs || capturing_) chk(t4k_memcpy_d2d(w0_save_->data, w0.data, sizeof(float) * w0.numel, stream()), "nn#w0 copy");
+        else t4k_opt_snapshot(w0.data, w0_save_->data);
+        w0_saved_ = true;
     }
     if (!replay(g_opt_, tab_dev, (int)op, p)) {
         const bool cap = capturing_;
@@ -942,6 +946,10 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
         else chk(t4k_opt_step(kind, (const t4k_param_rec *)tab_dev, tab_host_.data(), tab_n, tab_chunks, lr, b1, b2, wd, stream()), nm);   // one workgroup per 1024 parameters (+ a conv stack's deferred partial fold)
         dp_in_opt_ = false;
         end_capture(g_opt_, cap);
+    }
+    if (t4k_opt_snapshot_pending()) {                    // must not happen (the launch above consumes it); never leave the request for another model's update
+        t4k_opt_snapshot(nullptr, nullptr); w0_saved_ = false;
+        hprintf("nn#%s: weight snapshot not taken - the first layer's deferred dX is no longer available\n", nm);
     }
     NLOG("} Model::%s\n", nm);
     return *this;
