@@ -1617,9 +1617,11 @@ void launch_plain_any(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s, 
 // 64-deep double-buffered stages (64 KiB each).  Interior tiles, K % 64 == 0, unsplit; layouts and epilogue as k_gemm_nn_plain.
 // RAGK: K >= 256 with a partial last stage (784 = 12 x 64 + 16), as k_gemm_nn_plain<RAGK>: one more DMA stage in which only the lanes inside the
 // tail move anything, its 8-deep chunks alternate between the k-groups, positions past the tail zeroed in registers (2048 x 2048 x 784: 58.5 -> measured below).
-template <bool AKC, bool BKC, bool EPI, bool RAGK = false>
-__global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
-    constexpr int BM = 128, BN = 128, BK = 64;
+// BK_ = 32 (round 5): 32-deep stages, 64 KiB of LDS, at most 128 registers - TWO workgroups per CU, each with its own stage barrier, so one's MFMAs fill the pipe
+// while the other's waves meet (grids of >= 2 tiles per CU; the 64-deep form keeps one workgroup per CU).
+template <bool AKC, bool BKC, bool EPI, bool RAGK = false, int BK_ = 64>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_ == 32 ? 4 : 2, BK_ == 32 ? 4 : 2))) k_gemm_plain128(PlainP p) {
+    constexpr int BM = 128, BN = 128, BK = BK_;
     constexpr int NC = BK / 8, CH = BK / 4, NCG = NC / 2;
     constexpr int STAGE = (BM + BN) * BK;
     constexpr int NJ = (BM * BK / 256) / 8;                // 1-KiB DMA instructions per operand per wave per stage (4)
@@ -1647,9 +1649,10 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int i = w * NJ + j;
-        if (AKC) { const int r = i * 4 + (lane >> 4), q = (lane & 15) ^ (r & (CH - 1)); voffA[j] = (unsigned)((m0 + r) * K + q * 4) * 4u; }
+        constexpr int RPI = 64 / CH;                       // rows of a K-contiguous operand one 1-KiB DMA instruction covers (CH quads of 16 bytes per row)
+        if (AKC) { const int r = i * RPI + lane / CH, q = (lane % CH) ^ (r & (CH - 1)); voffA[j] = (unsigned)((m0 + r) * K + q * 4) * 4u; }
         else     { const int kk = i * 2 + (lane >> 5);                                  voffA[j] = (unsigned)(kk * M + m0 + (lane & 31) * 4) * 4u; }
-        if (BKC) { const int r = i * 4 + (lane >> 4), q = (lane & 15) ^ (r & (CH - 1)); voffB[j] = (unsigned)((n0 + r) * K + q * 4) * 4u; }
+        if (BKC) { const int r = i * RPI + lane / CH, q = (lane % CH) ^ (r & (CH - 1)); voffB[j] = (unsigned)((n0 + r) * K + q * 4) * 4u; }
         else     { const int kk = i * 2 + (lane >> 5);                                  voffB[j] = (unsigned)(kk * N + n0 + (lane & 31) * 4) * 4u; }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
@@ -1668,7 +1671,7 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
         for (int j = 0; j < NJ; j++) {
             const int i = w * NJ + j;
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + i * 256) * 4));
-            const bool kin = ((((lane & 15) ^ ((i * 4 + (lane >> 4)) & (CH - 1)))) << 2) < tail, rin = i * 2 + (lane >> 5) < tail;
+            const bool kin = ((((lane % CH) ^ ((i * (64 / CH) + lane / CH) & (CH - 1)))) << 2) < tail, rin = i * 2 + (lane >> 5) < tail;
             if (AKC ? kin : rin) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
             if (BKC ? kin : rin) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
         }
@@ -1800,17 +1803,23 @@ __global__ void __launch_bounds__(512) k_gemm_plain128(PlainP p) {
             }
         }
 }
-template <bool AKC, bool BKC, bool EPI, bool RAGK = false>
+template <bool AKC, bool BKC, bool EPI, bool RAGK = false, int BK_ = 64>
 void launch_plain128_(const PlainP &q, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)2 * 256 * 64 * sizeof(float);
+    constexpr size_t lds_bytes = (size_t)2 * 256 * BK_ * sizeof(float);
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain128<AKC, BKC, EPI, RAGK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
-    T4K_LAUNCH((k_gemm_plain128<AKC, BKC, EPI, RAGK>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain128<AKC, BKC, EPI, RAGK, BK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
+    T4K_LAUNCH((k_gemm_plain128<AKC, BKC, EPI, RAGK, BK_>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
 }
 void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, nullptr, nullptr };
     const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias, ragk = p.K % 64 != 0;
-#define T4K_PL(A_, B_) do { if (ragk) { if (epi) launch_plain128_<A_, B_, true, true>(q, s); else launch_plain128_<A_, B_, false, true>(q, s); } \
+    // Two co-resident workgroups per CU on 32-deep stages once every CU gets at least two tiles (4096^2 x 1024: 261 -> 254 us, 8192 x 4096 x 512: 282 -> 264 us;
+    // with one tile per CU the doubled barrier count loses: 2048^3 129.5 -> 135.4 us).  K in whole 32s is unragged for this form.  T4K_GEMM_PLAIN128_BK32 = 0 / 1 / 2 (always).
+    static int bk32 = -1; if (bk32 < 0) { const char *e = getenv("T4K_GEMM_PLAIN128_BK32"); bk32 = e ? atoi(e) : 1; }
+    const long tiles = (long)(p.M / 128) * (p.N / 128);
+    const bool two = bk32 && p.K % 32 == 0 && (bk32 >= 2 || tiles >= 2L * st().cu_count);
+#define T4K_PL(A_, B_) do { if (two) { if (epi) launch_plain128_<A_, B_, true, false, 32>(q, s); else launch_plain128_<A_, B_, false, false, 32>(q, s); } \
+                            else if (ragk) { if (epi) launch_plain128_<A_, B_, true, true>(q, s); else launch_plain128_<A_, B_, false, true>(q, s); } \
                             else if (epi) launch_plain128_<A_, B_, true>(q, s); else launch_plain128_<A_, B_, false>(q, s); } while (0)
     if (!tA && !tB) T4K_PL(true, false); else if (!tA) T4K_PL(true, true); else if (!tB) T4K_PL(false, false); else T4K_PL(false, true);
 #undef T4K_PL

@@ -1202,7 +1202,10 @@ def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N,
                                          # 128x128 tiles on the lean pipeline (k_gemm_plain128): every layout, K in 64s, several tiles per CU, non-square tile grids
                                          (2048, 2048, 512, 0, 0), (2048, 2048, 320, 1, 1), (2176, 4096, 256, 1, 0), (4096, 2304, 448, 0, 1),
                                          # ... with a partial last K stage (k_gemm_plain128<RAGK>): tails of 16, 8 (one k-group idle), 44 (a partial chunk), 60
-                                         (2048, 2048, 784, 0, 1), (2048, 2048, 328, 1, 0), (2048, 2304, 300, 0, 0), (2304, 2048, 444, 1, 1), (2048, 2048, 784, 0, 0)])
+                                         (2048, 2048, 784, 0, 1), (2048, 2048, 328, 1, 0), (2048, 2304, 300, 0, 0), (2304, 2048, 444, 1, 1), (2048, 2048, 784, 0, 0),
+                                         # ... two workgroups per CU on 32-deep stages (k_gemm_plain128<.., 32>, grids of >= 512 tiles; the two shapes above with 544 / 576 tiles take it too):
+                                         # every layout, K in whole 32s that are not whole 64s (unragged for this form), a deep K
+                                         (2048, 4096, 288, 0, 0), (4096, 2048, 480, 1, 1), (4096, 2048, 512, 0, 1), (2048, 4096, 1056, 1, 0)])
 def test_gemm_large_transposed_products_exact_on_integer_operands(t4k, dev, M, N, K, tA, tB):
     """Large products with transposed operands and alpha / beta (the linear layers of an MLP) on the 8-wave LDS-DMA kernel, several 64x64
     tiles per CU, one shape with a ragged M: small-integer entries keep every fp32 sum exact, so the result equals the float64 product."""
@@ -1213,6 +1216,8 @@ def test_gemm_large_transposed_products_exact_on_integer_operands(t4k, dev, M, N
     dA = dev.up(np.ascontiguousarray(A.T) if tA else A); dB = dev.up(np.ascontiguousarray(B.T) if tB else B); dO = dev.up(O0)
     t4k.call("t4k_gemm", p(dA), p(dB), p(dO), 2.0, -1.0, tA, tB, M, N, K, 1, None)
     assert np.array_equal(dev.down(dO).astype(np.float64), 2.0 * want - O0)
+    t4k.call("t4k_gemm", p(dA), p(dB), p(dO), 1.0, 0.0, tA, tB, M, N, K, 1, None)         # and the kernels without an epilogue
+    assert np.array_equal(dev.down(dO).astype(np.float64), want)
 
 
 @pytest.mark.parametrize("N,E1,E0,stages,copy", [
