@@ -19,6 +19,13 @@ using namespace t4k;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor over [p, p + bytes): offsets are bytes, a lane offset >= bytes is out of range (loads return / the LDS-DMA stores zeros)
+__device__ __forceinline__ i32x4 buf_srd(const void *p, unsigned bytes) {
+    const unsigned long a = (unsigned long)p;
+    i32x4 r; r[0] = (int)(unsigned)a; r[1] = (int)((unsigned)(a >> 32) & 0xFFFFu); r[2] = (int)bytes; r[3] = 0x00020000;
+    return r;
+}
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32, CH = BK / 4, SW = 64 / BK, NC = BK / 8;
@@ -169,17 +176,17 @@ __global__ void __launch_bounds__(256) k_convbig(CbP p) {
 // image / past the tensor, columns past Cout, read a page of zeros (State::d_zero): no zero fill, no predicates in the MFMA loop.
 // Stride 1 only (gather and output grid are then the same); Cin % 64 == 0.
 struct Cb8 {
-    const float *X, *F, *B, *Z;        // gathered tensor (forward: input; dX: dO), filter [C1][K][K][C0], bias (forward), zero page
+    const float *X, *F, *B;            // gathered tensor (forward: input; dX: dO), filter [C1][K][K][C0], bias (forward)
     float *Y, *Y2;
     int N, H, W, Cin, Cout, C0f;
     int tiles_n;
 };
-template <int K, int P, bool BWD, int NTW>
-__global__ void __launch_bounds__(512) k_convbig8(Cb8 p) {
-    constexpr int BM = 128, BN = 64 * NTW, BK = 64, KK = K * K;
-    constexpr int NC = BK / 8, CH = BK / 4, NCG = NC / 2;
+template <int K, int P, bool BWD, int NTW, bool NT_ST, int BK_>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_ == 32 ? 4 : 2, BK_ == 32 ? 4 : 2))) k_convbig8(Cb8 p) {
+    constexpr int BM = 128, BN = 64 * NTW, BK = BK_, KK = K * K;
+    constexpr int NC = BK / 8, CH = BK / 4, NCG = NC / 2, RPI = 64 / CH;   // 8-deep chunks, 16-byte quads per row, chunks per k-group, rows per 1-KiB DMA instruction
     constexpr int STAGE = (BM + BN) * BK;
-    constexpr int NJA = 4, NJB = BN / 32;                  // 1-KiB DMA instructions per wave per stage
+    constexpr int NJA = BM * BK / 2048, NJB = BN * BK / 2048;              // 1-KiB DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,48 +203,67 @@ __global__ void __launch_bounds__(512) k_convbig8(Cb8 p) {
         tm = L / tiles_n; tn = L - tm * tiles_n;                                       // the N tiles of one pixel block side by side: they share the gathered rows
     }
     const long m0 = (long)tm * BM; const int n0 = tn * BN;
-    const int cpt = Cin / BK, nst = KK * cpt;               // stages per tap, stages
-    // this lane's four A rows (pixels) and its 16-byte quad of the stage's 64 channels (XOR-swizzled with the row: the DMA writes lane-linear)
-    int py[NJA], px[NJA]; const float *pb[NJA]; bool pok[NJA]; int qa[NJA];
+    const int nst = KK * (Cin / BK);                        // stages: BK channels of one tap each
+    // this lane's NJA rows (pixels) of the A stage and its 16-byte quad of the stage's channels (XOR-swizzled with the row: the DMA writes lane-linear).
+    // Sources are BUFFER addresses (buffer_load_dwordx4 ... offen lds): a lane keeps the byte offset of (pixel, quad) and one validity bit per tap; a tap
+    // outside the image is an offset past num_records, for which the DMA stores zeros (tools/experiments/buf_lds_probe.hip) - no zero page, no 64-bit
+    // selects.  The filter rows' lane offsets never change: a stage moves the scalar offset.  Rows of one lane are RPI pixels apart: one division.
+    unsigned offa[NJA], vma[NJA];
+    {
+        const int r0 = w * NJA * RPI + lane / CH;
+        const unsigned mf = (unsigned)(m0 + r0 < npix ? m0 + r0 : 0);                  // the launcher keeps npix Cin below 2^29: 32-bit pixel arithmetic
+        const unsigned t = mf / (unsigned)W;
+        int px = (int)(mf - t * (unsigned)W), py = (int)(t % (unsigned)H);
 #pragma unroll
-    for (int j = 0; j < NJA; j++) {
-        const int r = (w * NJA + j) * 4 + (lane >> 4);
-        qa[j] = ((lane & 15) ^ (r & (CH - 1))) * 4;
-        const long m = m0 + r; pok[j] = m < npix;
-        const long mc = pok[j] ? m : 0;
-        px[j] = (int)(mc % W); const long t = mc / W; py[j] = (int)(t % H);
-        pb[j] = p.X + ((t / H) * (long)H * W + (long)py[j] * W + px[j]) * Cin + qa[j];   // the pixel itself + the lane's quad: a stage adds its tap's shift
+        for (int j = 0; j < NJA; j++) {
+            const int r = r0 + j * RPI;
+            const int qa = ((lane % CH) ^ (r & (CH - 1))) * 4;
+            const long m = m0 + r; const bool pok = m < npix;
+            offa[j] = ((pok ? (unsigned)m : 0u) * (unsigned)Cin + (unsigned)qa) * 4u;
+            unsigned xm = 0, v = 0;                                                     // taps inside the image: (rows inside) x (columns inside)
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) if ((unsigned)(px + (BWD ? P - kx : kx - P)) < (unsigned)W) xm |= 1u << kx;
+#pragma unroll
+            for (int ky = 0; ky < K; ky++) if ((unsigned)(py + (BWD ? P - ky : ky - P)) < (unsigned)H) v |= xm << (ky * K);
+            vma[j] = pok ? v : 0u;
+            px += RPI; while (px >= W) { px -= W; py++; } while (py >= H) py -= H;
+        }
     }
     // B: forward F[ci][tap][co] - n-contiguous rows of BN floats, 1024 / (4 BN) k rows per instruction; dX F[c1][KK-1-tap][c0] - k-contiguous rows
-    const float *fb[NJB]; bool bok[NJB];
+    unsigned offb[NJB];
 #pragma unroll
     for (int j = 0; j < NJB; j++) {
         const int i = w * NJB + j;
-        if (!BWD) { constexpr int RPI = 256 / BN, LPR = BN / 4; const int kk = i * RPI + lane / LPR, col = (lane % LPR) * 4;
-                    bok[j] = n0 + col < Cout; fb[j] = p.F + (long)kk * KK * p.C0f + n0 + col; }
-        else      { const int r = i * 4 + (lane >> 4), q = ((lane & 15) ^ (r & (CH - 1))) * 4;
-                    bok[j] = n0 + r < Cout; fb[j] = p.F + ((long)(n0 + r) * KK + (KK - 1)) * p.C0f + q; }
+        if (!BWD) { constexpr int RPB = 256 / BN, LPR = BN / 4; const int kk = i * RPB + lane / LPR, col = (lane % LPR) * 4;
+                    offb[j] = n0 + col < Cout ? (unsigned)(((long)kk * KK * p.C0f + n0 + col) * 4) : 0x80000000u; }
+        else      { const int r = i * RPI + lane / CH, q = ((lane % CH) ^ (r & (CH - 1))) * 4;
+                    offb[j] = n0 + r < Cout ? (unsigned)(((long)(n0 + r) * KK * p.C0f + q) * 4) : 0x80000000u; }
     }
-    const float *zsrc = p.Z + (lane & 15) * 4;
+    const i32x4 srdX = buf_srd(p.X, (unsigned)(npix * Cin * 4)), srdF = buf_srd(p.F, (unsigned)((long)(BWD ? Cout : Cin) * KK * p.C0f * 4));
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        const int tap = kt / cpt, cb = (kt - tap * cpt) * BK;
-        const int ky = tap / K, kx = tap - ky * K;
+    // a stage's sources are worked out (prep) one stage before its DMA is fired: the arithmetic sits under the MFMAs, and what follows the stage barrier is
+    // as short as the dense GEMM's (s_mov m0 + one DMA instruction per KiB)
+    int itap = 0, icb = 0;                                  // the stage the next prep() works out: its tap, its first channel
+    unsigned vo[NJA], sb4 = 0;
+    auto prep = [&]() __attribute__((always_inline)) {
+        const int ky = itap / K, kx = itap - ky * K;
         const int dy = BWD ? P - ky : ky - P, dx = BWD ? P - kx : kx - P;
-        const long sh = ((long)dy * W + dx) * Cin + cb;
+        const unsigned sh4 = (unsigned)((((dy * W + dx) * Cin) + icb) * 4), bit = 1u << itap;
+#pragma unroll
+        for (int j = 0; j < NJA; j++) vo[j] = (vma[j] & bit) ? offa[j] + sh4 : 0x80000000u;
+        sb4 = (unsigned)((!BWD ? (icb * KK + itap) * p.C0f : (KK - 1 - itap) * p.C0f + icb) * 4);
+        icb += BK; if (icb == Cin) { icb = 0; itap++; }
+    };
+    auto fire = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NJA; j++) {
-            const int gi = py[j] + dy, gj = px[j] + dx;
-            const bool ok = pok[j] && (unsigned)gi < (unsigned)H && (unsigned)gj < (unsigned)W;
-            const float *sa = ok ? pb[j] + sh : zsrc;
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJA + j) * 256) * 4));
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sa), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vo[j]), "s"(srdX), "s"(la) : "memory");
         }
 #pragma unroll
         for (int j = 0; j < NJB; j++) {
-            const float *sb = bok[j] ? (!BWD ? fb[j] + ((long)cb * KK + tap) * p.C0f : fb[j] - (long)tap * p.C0f + cb) : zsrc;
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + BM * BK + (w * NJB + j) * 256) * 4));
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sb), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(offb[j]), "s"(srdF), "s"(la), "s"(sb4) : "memory");
         }
     };
     f32x16 acc[2][NTW];
@@ -275,13 +301,19 @@ __global__ void __launch_bounds__(512) k_convbig8(Cb8 p) {
                 for (int b = 0; b < NTW; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
     };
     float ca[2][4], cbv[NTW][4];
-    issue(0, 0);
+    prep(); fire(0); prep();
+    float bias[NTW];
+#pragma unroll
+    for (int b = 0; b < NTW; b++) { const int gn = n0 + wn * (32 * NTW) + b * 32 + l31; bias[b] = (!BWD && p.B && gn < Cout) ? p.B[gn] : 0.f; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < NTW; b++) asm volatile("" :: "v"(bias[b]));      // the bias has landed HERE as far as the compiler is concerned: no vmcnt(0) between the epilogue's stores
+    if (nst > 1) fire(1);                                   // stage kt + 2 is requested right behind stage kt's closing barrier: its buffer is free from there on
+    prep();
     rd(lds, lds + BM * BK, c0, ca, cbv);
     int buf = 0;
     for (int kt = 0; kt < nst; kt++) {
         const int b1 = buf ^ 1;
-        if (kt + 1 < nst) issue(kt + 1, b1);
         const float *a = lds + buf * STAGE, *b = a + BM * BK;
 #pragma unroll
         for (int ci = 0; ci + 1 < NCG; ci++) {
@@ -290,6 +322,7 @@ __global__ void __launch_bounds__(512) k_convbig8(Cb8 p) {
             __builtin_amdgcn_sched_barrier(0);
             mm(ca, cbv);
             __builtin_amdgcn_sched_barrier(0);
+
 #pragma unroll
             for (int j = 0; j < 4; j++) {
 #pragma unroll
@@ -299,10 +332,13 @@ __global__ void __launch_bounds__(512) k_convbig8(Cb8 p) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nst) fire(buf);
         float na[2][4], nbv[NTW][4];
         if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, c0, na, nbv);
         __builtin_amdgcn_sched_barrier(0);
         mm(ca, cbv);
+        __builtin_amdgcn_sched_barrier(0);
+        prep();                                             // stage kt + 3, under the MFMAs just issued
         if (kt + 1 < nst) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -314,7 +350,9 @@ __global__ void __launch_bounds__(512) k_convbig8(Cb8 p) {
         }
         buf = b1;
     }
-    // the two k-groups meet in LDS, group 0 stores (bias: forward)
+    // the two k-groups meet in LDS, group 0 stores (bias: forward; fetched before the main loop).  Streaming stores: the tile is not read again by this launch
+    // and a layer tensor of these sizes does not stay in the L2s for the next one (with plain stores the dirty lines of all tiles are written back at the END of
+    // the kernel: ~5 us of tail on a 16 MB output, tools/experiments/conv_stage_fit.py)
     __syncthreads();
     if (kg == 1) {
 #pragma unroll
@@ -326,19 +364,47 @@ __global__ void __launch_bounds__(512) k_convbig8(Cb8 p) {
     }
     __syncthreads();
     if (kg == 1) return;
+    // interior tiles (all of them when the pixel and channel counts are whole tiles): no predicates, 32-bit offsets from the tile's corner, the sixteen values of
+    // a block read from LDS together and stored back to back (a predicated store per element costs an LDS round trip and a branch each: ~4 us of tail)
+    const bool inner = m0 + BM <= npix && n0 + BN <= Cout;
+    if (inner) {
+        float *y0 = p.Y + (m0 * Cout + n0), *y2 = p.Y2 ? p.Y2 + (m0 * Cout + n0) : nullptr;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < NTW; b++) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = (acc[a][b][r] + lds[((w4 * 2 * NTW + a * NTW + b) * 16 + r) * 64 + lane]) + bias[b];
+                const int o0 = (wm * 64 + a * 32 + 4 * h) * Cout + wn * (32 * NTW) + b * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int o = o0 + ((r & 3) + 8 * (r >> 2)) * Cout;
+                    if (NT_ST) __builtin_nontemporal_store(v[r], &y0[o]); else y0[o] = v[r];
+                }
+                if (y2) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int o = o0 + ((r & 3) + 8 * (r >> 2)) * Cout;
+                        if (NT_ST) __builtin_nontemporal_store(v[r], &y2[o]); else y2[o] = v[r];
+                    }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < NTW; b++) {
             const int gn = n0 + wn * (32 * NTW) + b * 32 + l31;
             if (gn >= Cout) continue;
-            const float bias = (!BWD && p.B) ? p.B[gn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const long gm = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (gm < npix) {
-                    const float v = (acc[a][b][r] + lds[((w4 * 2 * NTW + a * NTW + b) * 16 + r) * 64 + lane]) + bias;
-                    p.Y[gm * Cout + gn] = v; if (p.Y2) p.Y2[gm * Cout + gn] = v;
+                    const float v = (acc[a][b][r] + lds[((w4 * 2 * NTW + a * NTW + b) * 16 + r) * 64 + lane]) + bias[b];
+                    p.Y[gm * Cout + gn] = v;
+                    if (p.Y2) p.Y2[gm * Cout + gn] = v;
                 }
             }
         }
@@ -617,26 +683,32 @@ template <bool BWD>
 void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
                      int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f) {
     const long npix = (long)N * Hy * Wy;
-    {   // stride 1, "same" padding, whole 64-channel stages: the 8-wave LDS-DMA kernel (k_convbig8)
-        // 1 (default): layers of at least 16 stages (K K Cin >= 1024) - measured on the CIFAR net (N = 256): the step 1.261 -> 1.220 ms with the 18- and
-        // 36-stage layers here (conv 128 -> 256 forward, the dX of both), while the 9-stage layers lose (64 -> 128 @ 16x16 forward 99.5 vs 96.0 us,
-        // 64 -> 64 @ 32x32 234 vs 218: one 8-wave workgroup per CU hides a short loop's barriers worse than three 4-wave ones); 2: every qualifying layer; 0: off
+    {   // stride 1, "same" padding, whole 64-channel stages: the 8-wave LDS-DMA kernel (k_convbig8), every such layer since round 5 (round 4 kept the 9-stage
+        // layers on k_convbig: with buffer-addressed DMA, the branch-free epilogue and two workgroups per CU on 32-channel stages they gain most -
+        // 64 -> 128 @ 16x16 forward 96.2 -> 83.9 us, 64 -> 64 @ 32x32 221 -> 194.5 us, dX 185 -> 168 us); T4K_CONVBIG8=0: off
         static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONVBIG8"); on = e ? atoi(e) : 1; }
         const bool shape = S == 1 && P == K / 2 && (K == 1 || K == 3 || K == 5) && Cin % 64 == 0 && Cout % 4 == 0 && Hx == Hy && Wx == Wy &&
-                           aligned16(X) && aligned16(F) && st().d_zero && npix >= 128;
-        if (on && shape && (on >= 2 || (long)K * K * Cin >= 1024)) {
+                           aligned16(X) && aligned16(F) && npix >= 128 && npix * Cin < (1L << 29) && (long)(Cin > Cout ? Cin : Cout) * K * K * C0f < (1L << 29);   // byte offsets of the buffer loads are 32-bit
+        if (on && shape) {
             const int tiles_m = (int)((npix + 127) / 128);
             // 128-wide tiles when they still give every CU a workgroup, 64-wide otherwise (CIFAR conv3 dX: 128 -> 256 workgroups) and for 64 output channels
             const bool wide = Cout > 64 && (long)tiles_m * ((Cout + 127) / 128) >= (long)st().cu_count;
             const int BN = wide ? 128 : 64;
-            Cb8 q = { X, F, B, st().d_zero, Y, Y2, N, Hy, Wy, Cin, Cout, C0f, (Cout + BN - 1) / BN };
+            Cb8 q = { X, F, B, Y, Y2, N, Hy, Wy, Cin, Cout, C0f, (Cout + BN - 1) / BN };
             const dim3 g8((unsigned)(tiles_m * q.tiles_n)), b8(512);
-            const size_t lds8 = sizeof(float) * 2 * (128 + BN) * 64;
-#define CB8(k, pd) do { if (wide) { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig8<k, pd, BWD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); a1 = true; } \
-                                    T4K_LAUNCH((k_convbig8<k, pd, BWD, 2>), g8, b8, lds8, hs, q); } \
-                        else      { static bool a2 = false; if (!a2) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig8<k, pd, BWD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); a2 = true; } \
-                                    T4K_LAUNCH((k_convbig8<k, pd, BWD, 1>), g8, b8, lds8, hs, q); } } while (0)
+            // grids of two or more tiles per CU: 32-channel stages, half the LDS, at most 128 registers - two workgroups share a CU and one's stage barrier
+            // (and prologue, and epilogue) runs under the other's MFMAs (as k_gemm_plain128<.., 32>)
+            static int bk32 = -1; if (bk32 < 0) { const char *e = getenv("T4K_CONVBIG8_BK32"); bk32 = e ? atoi(e) : 1; }
+            const bool two = bk32 && (bk32 >= 2 || (long)tiles_m * q.tiles_n >= 2L * st().cu_count);
+            const size_t lds8 = std::max(sizeof(float) * 2 * (128 + BN) * (two ? 32 : 64), sizeof(float) * 4 * 2 * (BN / 64) * 16 * 64);   // stages | the k-groups' meeting
+#define CB8_(k, pd, ntw, nt, bk) do { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig8<k, pd, BWD, ntw, nt, bk>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); a1 = true; } \
+                                      T4K_LAUNCH((k_convbig8<k, pd, BWD, ntw, nt, bk>), g8, b8, lds8, hs, q); } while (0)
+#define CB8n(k, pd, ntw) do { if (two) { if (nts) CB8_(k, pd, ntw, true, 32); else CB8_(k, pd, ntw, false, 32); } else { if (nts) CB8_(k, pd, ntw, true, 64); else CB8_(k, pd, ntw, false, 64); } } while (0)
+#define CB8(k, pd) do { if (wide) CB8n(k, pd, 2); else CB8n(k, pd, 1); } while (0)
+            static int nts = -1; if (nts < 0) { const char *e = getenv("T4K_CONVBIG8_NT"); nts = e ? atoi(e) : 0; }
             if (K == 1) CB8(1, 0); else if (K == 3) CB8(3, 1); else CB8(5, 2);
+#undef CB8n
+#undef CB8_
 #undef CB8
             return;
         }

@@ -94,11 +94,13 @@ def test_gated_kernels_while_another_stream_hogs_the_device(tmp_path):
     _run(tmp_path, {"HOG": "1"})
 
 
-def test_opt_in_conv_kernel_on_the_lean_pipeline_matches_the_oracle():
-    """k_convbig8 (csrc/conv_big.hip: forward / dX of many-channel layers on the dense GEMM's 8-wave LDS-DMA pipeline) takes layers of at least
-    16 stages by default; T4K_CONVBIG8=2 routes every qualifying layer of the conv parity tests through it, 0 none."""
-    for v in ("2", "0"):
-        _conv_tests(v)
+def test_conv_kernel_on_the_lean_pipeline_and_its_variants_match_the_oracle():
+    """k_convbig8 (csrc/conv_big.hip: forward / dX of many-channel stride-1 layers on the dense GEMM's 8-wave LDS-DMA pipeline) takes every qualifying layer of the
+    conv parity tests by default; T4K_CONVBIG8=0 none (k_convbig).  T4K_CONVBIG8_BK32: 32-channel stages with two workgroups per CU - 2 = on every grid,
+    0 = never (default: grids of two or more tiles per CU); T4K_CONVBIG8_NT=1: streaming stores in the epilogue."""
+    _conv_tests("0")
+    for env in ({"T4K_CONVBIG8_BK32": "2"}, {"T4K_CONVBIG8_BK32": "0"}, {"T4K_CONVBIG8_NT": "1"}):
+        _conv_tests(None, env)
 
 
 def test_conv_parity_without_the_thin_input_kernel_and_with_other_grids():
