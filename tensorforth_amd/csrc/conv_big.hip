@@ -672,6 +672,196 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     }
 }
 
+
+// ------------------------------------------------------------------ dF partials on a 128-row tile (round 5)
+// k_convbig_df8's 64 x 64 tile moves 32 KB per 2 x 64 x 64 x 64 flop stage - 16 bytes per clock for the two workgroups of a CU, which is what a CU's fetch
+// path delivers: the kernel sat at 66 % of the MFMA peak however its stages were scheduled.  Here a tile is 128 rows x (64 NTW) columns of dF: the rows are
+// 128 / CIW taps x CIW input channels (CIW = 128: one tap), the columns output channels; both operands are k-major with k = the slice's pixels
+// (A[k][m] = the input under the row's tap, B[k][n] = dO), the dense GEMM's TN layout, and a wave owns 64 x (32 NTW) of it (one A fragment feeds NTW MFMAs,
+// one B fragment two): half the bytes per flop.  Stride 1, same-size layers (the gather is then linear in the pixel index: a row's offset advances by a
+// constant per stage, only its validity needs (y, x)); sources are buffer offsets, rows outside the image / the slice and taps past K K are out-of-range
+// offsets (the DMA stores zeros), worked out one stage ahead of their DMA.  Slab layout and fold as k_convbig_df8.
+struct Cdw { const float *I, *DO; float *part; int H, W, C1, C0; int pix_per_slice, nslice, ci_tiles, ctiles, kks; long npix; };
+template <int K, int P, int CIW, int NTW, int BKP>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BKP == 32 ? 4 : 2, BKP == 32 ? 4 : 2))) k_convbig_dfw(Cdw p) {
+    constexpr int BM = 128, BN = 64 * NTW, KK = K * K, TPT = BM / CIW;
+    constexpr int NC = BKP / 8, NCG = NC / 2;
+    constexpr int STAGE = (BM + BN) * BKP;
+    constexpr int NJA = BKP / 16, NJB = BKP * BN / 2048;    // 1-KiB DMA instructions per wave per stage: A 2 pixels x 128 rows each, B 256 / BN pixels x BN columns
+    constexpr int LPR = BN / 4, RPB = 64 / LPR;             // B: lanes per pixel row, pixel rows per instruction
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = w >> 2, w4 = w & 3, wm = w4 >> 1, wn = w4 & 1, h = lane >> 5, l31 = lane & 31;
+    const int c0 = kg * NCG;
+    // one workgroup per tile, at most one (BKP 64) or two (BKP 32) per CU: XCD x (= workgroup id % 8) owns a contiguous run of the tile order
+    // (slice, co tile, ci tile, tap group), so the taps of one pixel slice - same dO rows, overlapping input rows - meet in one L2 and every XCD gets the
+    // same number of tiles (dealing whole 9-tap groups to the XCDs left four of them with 36 tiles for 32 CUs: a second round, 171 instead of 85 us)
+    const int T = p.nslice * p.ctiles * p.kks;
+    int L;
+    { const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
+      if (i >= q8 + (x < r8 ? 1 : 0)) return;
+      L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; }
+    const int slice = L / (p.ctiles * p.kks), rem = L - slice * (p.ctiles * p.kks), tl = rem / p.kks, ts = rem - tl * p.kks;
+    const int cit = tl % p.ci_tiles, cot = tl / p.ci_tiles;
+    const int n0 = cot * BN, H = p.H, W = p.W, C1 = p.C1, C0 = p.C0;
+    const long k_beg = (long)slice * p.pix_per_slice, k_end = min(p.npix, k_beg + p.pix_per_slice);
+    const int nst = k_end > k_beg ? (int)((k_end - k_beg + BKP - 1) / BKP) : 0;
+    // A: this lane's four rows m .. m + 3 of the tile = one tap, four adjacent input channels; its pixels (k rows) 2 i + lane / 32 of the stage
+    const int ma = (lane & 31) * 4, tap = ts * TPT + ma / CIW, cia = cit * CIW + ma % CIW;
+    const int ky = tap / K, kx = tap - ky * K, dy = ky - P, dx = kx - P;
+    const bool a_ok = tap < KK && cia < C1;
+    unsigned offa[NJA]; int cx[NJA], cy[NJA], left[NJA];
+#pragma unroll
+    for (int j = 0; j < NJA; j++) {
+        const long pix = k_beg + (w * NJA + j) * 2 + (lane >> 5);
+        left[j] = (int)min((long)(1 << 30), k_end - pix);            // > 0: the row lies inside the slice
+        const unsigned pu = (unsigned)pix, t = pu / (unsigned)W;
+        cx[j] = (int)(pu - t * (unsigned)W); cy[j] = (int)(t % (unsigned)H);
+        offa[j] = (unsigned)(((pix + dy * W + dx) * C1 + cia) * 4);
+    }
+    const int nb = (lane % LPR) * 4;
+    const bool b_ok = n0 + nb < C0;
+    unsigned offb[NJB]; int leftb[NJB];
+#pragma unroll
+    for (int j = 0; j < NJB; j++) {
+        const long pix = k_beg + (w * NJB + j) * RPB + lane / LPR;
+        leftb[j] = (int)min((long)(1 << 30), k_end - pix);
+        offb[j] = (unsigned)((pix * C0 + n0 + nb) * 4);
+    }
+    const int dxs = BKP % W, dyr = (BKP / W) % H;
+    const unsigned stepA = (unsigned)(BKP * C1 * 4), stepB = (unsigned)(BKP * C0 * 4);
+    const i32x4 srdI = buf_srd(p.I, (unsigned)(p.npix * C1 * 4)), srdO = buf_srd(p.DO, (unsigned)(p.npix * C0 * 4));
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    unsigned voa[NJA], vob[NJB];
+    auto prep = [&]() __attribute__((always_inline)) {      // the sources of the stage the row state stands at; the state moves on one stage
+#pragma unroll
+        for (int j = 0; j < NJA; j++) {
+            const bool ok = a_ok && left[j] > 0 && (unsigned)(cy[j] + dy) < (unsigned)H && (unsigned)(cx[j] + dx) < (unsigned)W;
+            voa[j] = ok ? offa[j] : 0x80000000u;
+            offa[j] += stepA; left[j] -= BKP;
+            cx[j] += dxs; const int c1 = cx[j] >= W ? 1 : 0; cx[j] -= c1 ? W : 0;
+            cy[j] += dyr + c1; cy[j] -= cy[j] >= H ? H : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < NJB; j++) { vob[j] = (b_ok && leftb[j] > 0) ? offb[j] : 0x80000000u; offb[j] += stepB; leftb[j] -= BKP; }
+    };
+    auto fire = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NJA; j++) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJA + j) * 256) * 4));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voa[j]), "s"(srdI), "s"(la) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < NJB; j++) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + BM * BKP + (w * NJB + j) * 256) * 4));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vob[j]), "s"(srdO), "s"(la) : "memory");
+        }
+    };
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < NTW; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    const int ra_ = wm * 64 + l31, rb_ = wn * (32 * NTW) + l31;
+    auto rd = [&](const float *a, const float *b, int ci, float (&av)[2][4], float (&bv)[NTW][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) av[t][j] = a[(ci * 8 + 4 * h + j) * BM + ra_ + t * 32];
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[t][j] = b[(ci * 8 + 4 * h + j) * BN + rb_ + t * 32];
+    };
+    auto mm = [&](float (&av)[2][4], float (&bv)[NTW][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < NTW; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+    };
+    float ca[2][4], cbv[NTW][4];
+    if (nst > 0) {
+        prep(); fire(0); prep();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (nst > 1) fire(1);
+        prep();
+        rd(lds, lds + BM * BKP, c0, ca, cbv);
+    }
+    int buf = 0;
+    for (int kt = 0; kt < nst; kt++) {
+        const int b1 = buf ^ 1;
+        const float *a = lds + buf * STAGE, *b = a + BM * BKP;
+#pragma unroll
+        for (int ci = 0; ci + 1 < NCG; ci++) {
+            float na[2][4], nbv[NTW][4];
+            rd(a, b, c0 + ci + 1, na, nbv);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ca, cbv);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) ca[t][j] = na[t][j];
+#pragma unroll
+                for (int t = 0; t < NTW; t++) cbv[t][j] = nbv[t][j];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nst) fire(buf);
+        float na[2][4], nbv[NTW][4];
+        if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BKP, c0, na, nbv);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ca, cbv);
+        __builtin_amdgcn_sched_barrier(0);
+        prep();                                             // stage kt + 3, under the MFMAs just issued
+        if (kt + 1 < nst) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) ca[t][j] = na[t][j];
+#pragma unroll
+                for (int t = 0; t < NTW; t++) cbv[t][j] = nbv[t][j];
+            }
+        }
+        buf = b1;
+    }
+    // the two k-groups meet in LDS (the stage buffers are free now), group 0 writes the slab rows [slice][(ci K + ky) K + kx][co]
+    __syncthreads();
+    if (kg == 1) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < NTW; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) lds[((w4 * 2 * NTW + a * NTW + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+    float *slab = p.part + (long)slice * C1 * KK * C0;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int mb = wm * 64 + a * 32;                    // a block of 32 rows: one tap (CIW >= 32)
+        const int tp = ts * TPT + mb / CIW, cib = cit * CIW + mb % CIW;
+        if (tp >= KK || cib >= C1) continue;
+#pragma unroll
+        for (int b = 0; b < NTW; b++) {
+            const int co = n0 + wn * (32 * NTW) + b * 32 + l31;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = acc[a][b][r] + lds[((w4 * 2 * NTW + a * NTW + b) * 16 + r) * 64 + lane];
+            if (co < C0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) slab[((cib + (r & 3) + 8 * (r >> 2) + 4 * h) * KK + tp) * C0 + co] = v[r];
+            }
+        }
+    }
+}
+
 } // namespace
 
 namespace t4k {
@@ -750,6 +940,41 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
     // L2 instead of crossing the fabric once per tap (a trailing slice may be empty: it writes a zero slab)
     static int x8 = -1; if (x8 < 0) { const char *e = getenv("T4K_DF_XCD"); x8 = e ? atoi(e) : 1; }
     if (x8 && nslice >= 8) { nslice = (nslice + 7) / 8 * 8; pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; }
+    {   // stride 1, same size, whole 128s of input channels, whole 64s of output channels: 128-row tiles (k_convbig_dfw; 128 -> 256 @ 8x8, N = 256: 92.0 -> 88.4 us).
+        // Two or four taps of 64 / 32 channels per tile work too (T4K_CONVBIG_DFW=3) but lose: 9 taps fill 10 / 12 tap slots and the fold reads 51 slices
+        // (64 -> 128 @ 16x16: 96.3 + 24 us of fold against 89 + 12)
+        static int dfw = -1; if (dfw < 0) { const char *e = getenv("T4K_CONVBIG_DFW"); dfw = e ? atoi(e) : 1; }
+        const bool shape = S == 1 && P == K / 2 && (K == 1 || K == 3 || K == 5) && H1 == H0 && W1 == W0 && (C1 % 128 == 0 || (dfw >= 3 && (C1 == 32 || C1 == 64))) && C0 % 64 == 0 &&
+                           npix * C1 < (1L << 29) && npix * C0 < (1L << 29) && aligned16(I) && aligned16(DO);
+        if (dfw && shape) {
+            const int ciw = C1 >= 128 ? 128 : C1, tpt = 128 / ciw, kks = (KK + tpt - 1) / tpt;
+            const int ntw = C0 % 128 == 0 ? 2 : 1, bn = 64 * ntw;
+            const int cit = (C1 + ciw - 1) / ciw, cot = C0 / bn, ctl = cit * cot, tilesw = kks * ctl;
+            // 1: 64-pixel stages, one workgroup per CU; 2: 32-pixel stages, two per CU (twice the slices, twice the slab bytes)
+            const int bkp = (dfw == 2 || dfw == 4) ? 32 : 64;
+            const long slots = (long)st().cu_count * (bkp == 32 ? 2 : 1);
+            long ns = slots / tilesw; if (ns < 1) ns = 1;
+            long pp = (npix + ns - 1) / ns; pp = (pp + bkp - 1) / bkp * bkp; if (pp < 4 * bkp) pp = 4 * bkp;
+            ns = (npix + pp - 1) / pp;
+            if ((size_t)ns * C1 * KK * C0 <= part_floats) {
+                Cdw q = { I, DO, part, H0, W0, C1, C0, (int)pp, (int)ns, cit, ctl, kks, npix };
+                const long T = ns * ctl * kks;
+                const dim3 gw((unsigned)(8 * ((T + 7) / 8))), bw(512);
+                const size_t ldsw = std::max(sizeof(float) * 2 * (128 + bn) * bkp, sizeof(float) * 4 * 2 * ntw * 16 * 64);
+#define DFW_(k, pd, cw, nt, bk) do { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig_dfw<k, pd, cw, nt, bk>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw); a1 = true; } \
+                                     T4K_LAUNCH((k_convbig_dfw<k, pd, cw, nt, bk>), gw, bw, ldsw, hs, q); } while (0)
+#define DFWb(k, pd, cw, nt) do { if (bkp == 32) DFW_(k, pd, cw, nt, 32); else DFW_(k, pd, cw, nt, 64); } while (0)
+#define DFWn(k, pd, cw) do { if (ntw == 2) DFWb(k, pd, cw, 2); else DFWb(k, pd, cw, 1); } while (0)
+#define DFW(k, pd) do { if (ciw == 128) DFWn(k, pd, 128); else if (ciw == 64) DFWn(k, pd, 64); else DFWn(k, pd, 32); } while (0)
+                if (K == 1) DFW(1, 0); else if (K == 3) DFW(3, 1); else DFW(5, 2);
+#undef DFW
+#undef DFWn
+#undef DFWb
+#undef DFW_
+                return (int)ns;
+            }
+        }
+    }
     static int df8 = -1; if (df8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8"); df8 = e ? atoi(e) : 64; }     // 0: the 4-wave register-staged kernel; 64 / 128: pixels per stage of the 8-wave LDS-DMA kernel
     if (df8 && npix * (C0 > C1 ? C0 : C1) / 4 + (long)4 * W1 * C1 < (1L << 31) && st().d_zero) {      // row offsets are ints in 16-byte units
         // 64-pixel stages: 64 KiB of LDS, two workgroups per CU (one's barrier under the other's MFMAs) -> up to 2 x CUs workgroups at once, all resident
