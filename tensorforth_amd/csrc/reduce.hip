@@ -210,6 +210,47 @@ __global__ void __launch_bounds__(BLK) k_bn_part(const float *__restrict__ X, co
         part[((long)blockIdx.x * 2 + 1) * C + e] = (sm[1][0][ex] + sm[1][1][ex]) + (sm[1][2][ex] + sm[1][3][ex]);
     }
 }
+// The same two column sums with 16-byte loads (C % 4 == 0, 16-byte aligned tensors): a lane owns four adjacent channels, 16 lanes cover one 256-byte row of the
+// 64-channel tile, a wave four rows per instruction, the workgroup sixteen - four times the bytes in flight per lane (k_bn_part on the CIFAR net's
+// 256 x 32 x 32 x 64 conv output: 22 us = 3 TB/s; this one: see profiles/LAB_NOTES.md).  Fixed order: a lane's rows, the wave's four row groups (xor 16, 32), the four waves.
+template <int MODE>
+__global__ void __launch_bounds__(BLK) k_bn_part4(const float *__restrict__ X, const float *__restrict__ Y, float *__restrict__ part,
+                                                  long rows, int C, int rows_per_chunk) {
+    __shared__ float sm[2][4][64];
+    const int lane = threadIdx.x & 63, ry = threadIdx.x >> 6, c4 = lane & 15, rs = lane >> 4, e = blockIdx.y * 64 + c4 * 4;
+    const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e < C) {
+#pragma unroll 4
+        for (long r = r0 + ry * 4 + rs; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4 *>(X + r * C + e);
+            const float vv[4] = { v.x, v.y, v.z, v.w };
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { a[q] += vv[q]; b[q] = fmaf(vv[q], vv[q], b[q]); }
+            } else {
+                const float4 y = *reinterpret_cast<const float4 *>(Y + r * C + e);
+                const float yy[4] = { y.x, y.y, y.z, y.w };
+#pragma unroll
+                for (int q = 0; q < 4; q++) { a[q] += vv[q]; b[q] = fmaf(vv[q], yy[q], b[q]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        a[q] += __shfl_xor(a[q], 16); a[q] += __shfl_xor(a[q], 32);
+        b[q] += __shfl_xor(b[q], 16); b[q] += __shfl_xor(b[q], 32);
+    }
+    if (rs == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { sm[0][ry][c4 * 4 + q] = a[q]; sm[1][ry][c4 * 4 + q] = b[q]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, ex = threadIdx.x & 63, ec = blockIdx.y * 64 + ex;
+        if (ec < C) part[((long)blockIdx.x * 2 + which) * C + ec] = (sm[which][0][ex] + sm[which][1][ex]) + (sm[which][2][ex] + sm[which][3][ex]);
+    }
+}
 template <int MODE>
 __global__ void __launch_bounds__(BLK) k_bn_fin(const float *__restrict__ part, float *stat, float *DW, float *DB,
                                                 long NHW, int C, int nchunk, int train) {
@@ -304,6 +345,14 @@ __global__ void __launch_bounds__(BLK) k_dbn_apply(const float *__restrict__ W, 
     }
 }
 
+// stage 1 of the chunked statistics: 16-byte loads where the tensors allow (T4K_BN_PART4=0: the scalar kernel)
+template <int MODE>
+static void launch_bn_part(const float *X, const float *Y, float *part, long NHW, int C, int rpc, long nch, hipStream_t hs) {
+    static int v4 = -1; if (v4 < 0) { const char *e = getenv("T4K_BN_PART4"); v4 = e ? atoi(e) : 1; }
+    const bool vec = v4 && (C % 4) == 0 && ((((uintptr_t)X) | ((uintptr_t)(Y ? Y : X))) & 15) == 0;
+    if (vec) T4K_LAUNCH(k_bn_part4<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, hs, X, Y, part, NHW, C, rpc);
+    else     T4K_LAUNCH(k_bn_part<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, hs, X, Y, part, NHW, C, rpc);
+}
 
 // synchronised statistics for data-parallel runs (a communicator exists): chunk partials -> sums -> all-reduce -> finalise
 template <int MODE>
@@ -312,7 +361,7 @@ static int bn_stats_sync(const float *X, const float *Y, float *stat, float *DW,
     const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
     float *part = ws_for(s), *sums = part + (size_t)nch * 2 * C;
     if (((size_t)nch * 2 + 4) * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
-    T4K_LAUNCH(k_bn_part<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), X, Y, part, NHW, C, rpc);
+    launch_bn_part<MODE>(X, Y, part, NHW, C, rpc, nch, S(s));
     T4K_LAUNCH(k_bn_sums, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, sums, C, (int)nch);
     int rc = t4k_allreduce_sum(sums, 2L * C, s); if (rc != T4K_OK) return rc;
     T4K_LAUNCH(k_bn_fin_sync<MODE>, dim3((C + BLK - 1) / BLK), dim3(BLK), 0, S(s), sums, stat, DW, DB,
@@ -396,7 +445,7 @@ int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const
         const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
         float *part = ws_for(s);
         if ((size_t)nch * 2 * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
-        T4K_LAUNCH(k_bn_part<0>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), I, (const float *)nullptr, part, NHW, C, rpc);
+        launch_bn_part<0>(I, nullptr, part, NHW, C, rpc, nch, S(s));
         T4K_LAUNCH(k_bn_fin<0>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, (float *)nullptr, (float *)nullptr, NHW, C, (int)nch, 0);
     } else T4K_LAUNCH(k_bn_stats, dim3(C), dim3(BLK), 0, S(s), I, stat, NHW, C);
     T4K_LAUNCH(k_bn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), I, O, XH, W, B, stat, total, C);
@@ -413,7 +462,7 @@ int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *D
         const int rpc = (int)((NHW + nch - 1) / nch); nch = (NHW + rpc - 1) / rpc;
         float *part = ws_for(s);
         if ((size_t)nch * 2 * C * sizeof(float) > st().ws_bytes / 2) return fail(T4K_ERR_NOMEM, "batchnorm workspace");
-        T4K_LAUNCH(k_bn_part<1>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, S(s), DY, XH, part, NHW, C, rpc);
+        launch_bn_part<1>(DY, XH, part, NHW, C, rpc, nch, S(s));
         T4K_LAUNCH(k_bn_fin<1>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, DW, DB, NHW, C, (int)nch, train);
     } else T4K_LAUNCH(k_dbn_stats, dim3(C), dim3(BLK), 0, S(s), DY, XH, stat, DW, DB, NHW, C, train);
     T4K_LAUNCH(k_dbn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), W, DY, XH, DX, stat, total, C);
