@@ -254,6 +254,12 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
 int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, const float *B,
                     int N, int H1, int W1, int C1, int H0, int W0, int C0,
                     int K, int S, int P, t4k_stream_t s);
+/* Model::_fconv followed by Model::_fbatchnorm (forward.cu:129-155, 263-309) - a conv layer with a batch-norm layer right behind it: Y = conv(I) (+ ICOPY as above),
+ * then O / XH / stat_dev exactly as t4k_batchnorm_fwd(Y, ...) writes them.  One call so that the per-channel sums of Y can leave the conv kernel's epilogue
+ * (where the layer's kernel carries them) instead of costing a separate pass over Y; otherwise it IS the two calls */
+int t4k_conv2d_bn_fwd(const float *I, float *ICOPY, float *Y, const float *F, const float *Bc,
+                      int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P,
+                      float *O, float *XH, const float *W, const float *B, float *stat_dev, t4k_stream_t s);
 /* k_dconv2d<TS,KS,S,P> nmath.tcu:211 (Model::_bconv backprop.cu:152-191):
  * DB[c0] += sum dO; DF += sum I*dO (both only if train);
  * DX (overwritten) scatter (i*S+ky-P, j*S+kx-P) += F[c1,K-1-ky,K-1-kx,c0]*dO  (flipped, quirk a-11).

@@ -125,6 +125,11 @@ int t4k_conv2d_fwd2(const float *I, float *IC, float *O, const float *F, const f
     if (IC) memcpy(IC, I, sizeof(float) * (size_t)N * H1 * W1 * C1);
     return t4k_conv2d_fwd(I, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, st);
 }
+int t4k_conv2d_bn_fwd(const float *I, float *IC, float *Y, const float *F, const float *Bc, int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P,
+                      float *O, float *XH, const float *W, const float *B, float *st, t4k_stream_t s) {      // the two layers, one after the other
+    int r = t4k_conv2d_fwd2(I, IC, Y, F, Bc, N, H1, W1, C1, H0, W0, C0, K, S, P, s); if (r) return r;
+    return t4k_batchnorm_fwd(Y, O, XH, W, B, st, N, H0 * W0, C0, s);
+}
 int t4k_conv2d_bwd(const float *I, const float *DO, float *DX, const float *F, float *DF, float *DB, int N, int H1, int W1, int C1, int H0, int W0, int C0,
                    int K, int S, int P, int tr, t4k_stream_t) {
     // product contract: DX == NULL -> dF|dB only, DF == NULL -> dX only (the oracle always computes both; use scratch for the skipped half)

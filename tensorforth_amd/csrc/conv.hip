@@ -18,7 +18,9 @@
 #include <float.h>
 
 namespace t4k { bool conv_thin_df(const float *I, const float *DO, float *part, size_t part_bytes, int N, int H, int W, int C1, int C0, int *nslice, hipStream_t hs); }
-namespace t4k { bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs); }
+namespace t4k { bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs,
+                                  float *bn_part = nullptr, size_t bn_part_floats = 0, int *bn_chunks = nullptr);
+                int bn_fwd_from_parts(const float *I, float *O, float *XH, const float *W, const float *B, float *stat, long NHW, int C, const float *part, int nchunk, hipStream_t hs); }
 namespace t4k { bool conv_img_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
                                         int N, int H, int W, int C1, int C0, hipStream_t hs); }
 using namespace t4k;
@@ -27,7 +29,7 @@ namespace t4k {                                   // conv_big.hip: LDS-staged MF
 bool conv_big_ok(int Cin, int Cout);
 template <bool BWD>
 void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
-                     int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f);
+                     int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, float *bn_part = nullptr, size_t bn_part_floats = 0, int *bn_chunks = nullptr);
 int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, const float *DO, float *part, size_t part_floats,
                        int N, int H1, int W1, int C1, int H0, int W0, int C0);
 int colsum_add(const float *X, float *OUT, long rows, int E, hipStream_t hs);
@@ -792,10 +794,12 @@ int t4k_conv2d_fwd(const float *I, float *O, const float *F, const float *B,
                    int K, int S, int P, t4k_stream_t s) {
     return t4k_conv2d_fwd2(I, nullptr, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, s);
 }
-int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, const float *B,
-                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
-                    int K, int S, int P, t4k_stream_t s) {
+// the forward of one layer; bn_part (may be NULL): where the layer's kernel may leave the per-channel sums of O as chunk partials (*bn_chunks > 0 says it did)
+static int conv2d_fwd_impl(const float *I, float *ICOPY, float *O, const float *F, const float *B,
+                           int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                           int K, int S, int P, float *bn_part, size_t bn_part_floats, int *bn_chunks, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
+    if (bn_chunks) *bn_chunks = 0;
     if (!conv_supported(K, S, P))
         return fail(T4K_ERR_UNSUPPORTED, "nn#fconv kernel_size=%d stride=%d padding=%d not supported", K, S, P);
     if (!I || !O || !F || !B || N <= 0 || C0 <= 0 || C1 <= 0 || H0 <= 0 || W0 <= 0) return fail(T4K_ERR_ARG, "t4k_conv2d_fwd: bad argument");
@@ -807,10 +811,10 @@ int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, cons
         return T4K_OK;
     }
     // image in, a full MFMA tile or two of channels out (3 -> 64): filter in registers, the layer-0 copy from the same launch (conv_img.hip)
-    if (K == 3 && S == 1 && P == 1 && H0 == H1 && W0 == W1 && ICOPY != O && conv_thin_fwd(I, ICOPY, O, F, B, N, H0, W0, C1, C0, t4k::S(s))) { T4K_LAUNCH_CHECK(); return T4K_OK; }
+    if (K == 3 && S == 1 && P == 1 && H0 == H1 && W0 == W1 && ICOPY != O && conv_thin_fwd(I, ICOPY, O, F, B, N, H0, W0, C1, C0, t4k::S(s), bn_part, bn_part_floats, bn_chunks)) { T4K_LAUNCH_CHECK(); return T4K_OK; }
     if (ICOPY) T4K_HIP(hipMemcpyAsync(ICOPY, I, sizeof(float) * (size_t)N * H1 * W1 * C1, hipMemcpyDeviceToDevice, t4k::S(s)));
     if (conv_big_on() && conv_big_ok(C1, C0) && aligned16(I) && aligned16(F)) {       // many channels: LDS-staged GEMM tiling
-        launch_conv_big<false>(K, S, P, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
+        launch_conv_big<false>(K, S, P, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0, bn_part, bn_part_floats, bn_chunks);
         T4K_LAUNCH_CHECK();
         return T4K_OK;
     }
@@ -819,6 +823,27 @@ int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, cons
     launch_conv_gemm<false>(K, S, P, g, t4k::S(s), I, O, nullptr, F, B, N, H1, W1, C1, H0, W0, C0, C0);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
+}
+int t4k_conv2d_fwd2(const float *I, float *ICOPY, float *O, const float *F, const float *B,
+                    int N, int H1, int W1, int C1, int H0, int W0, int C0,
+                    int K, int S, int P, t4k_stream_t s) {
+    return conv2d_fwd_impl(I, ICOPY, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, nullptr, 0, nullptr, s);
+}
+// conv forward + the batch-norm forward behind it: same tensors, same arithmetic per element as t4k_conv2d_fwd2 + t4k_batchnorm_fwd; where the layer's kernel
+// can carry them (k_convbig8, k_conv_thin_fwd) the per-channel sums leave its epilogue as chunk partials in the stream's workspace and the statistics pass over
+// the conv output (a full read of it) is not launched.  T4K_CONV_BN_RIDER=0: always the two calls.
+int t4k_conv2d_bn_fwd(const float *I, float *ICOPY, float *Y, const float *F, const float *Bc,
+                      int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P,
+                      float *O, float *XH, const float *W, const float *B, float *stat_dev, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!O || !XH || !W || !B || !stat_dev) return fail(T4K_ERR_ARG, "t4k_conv2d_bn_fwd: null batch-norm tensor");
+    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_BN_RIDER"); on = e ? atoi(e) : 1; }
+    const bool rider = on && !(st().bn_sync && t4k_comm_world() > 0);                // synchronised statistics go through the all-reduce path of t4k_batchnorm_fwd
+    int chunks = 0;
+    int rc = conv2d_fwd_impl(I, ICOPY, Y, F, Bc, N, H1, W1, C1, H0, W0, C0, K, S, P, rider ? ws_for(s) : nullptr, st().ws_bytes / 8, &chunks, s);
+    if (rc != T4K_OK) return rc;
+    if (chunks > 0) return bn_fwd_from_parts(Y, O, XH, W, B, stat_dev, (long)N * H0 * W0, C0, ws_for(s), chunks, t4k::S(s));
+    return t4k_batchnorm_fwd(Y, O, XH, W, B, stat_dev, N, H0 * W0, C0, s);
 }
 
 // conv forward + the element-wise run behind it (dropout/activation -> 2x2 pool -> activation -> flatten copy) in ONE launch

@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256) k_convbig(CbP p) {
 struct Cb8 {
     const float *X, *F, *B;            // gathered tensor (forward: input; dX: dO), filter [C1][K][K][C0], bias (forward)
     float *Y, *Y2;
+    float *part;                       // forward, every tile interior: per-channel sums of the output (sum y, sum y^2) per 64-row block, [2 tiles_m][2][Cout] - the statistics of a batch-norm layer behind this one
     int N, H, W, Cin, Cout, C0f;
     int tiles_n;
 };
@@ -369,6 +370,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_ ==
     const bool inner = m0 + BM <= npix && n0 + BN <= Cout;
     if (inner) {
         float *y0 = p.Y + (m0 * Cout + n0), *y2 = p.Y2 ? p.Y2 + (m0 * Cout + n0) : nullptr;
+        float cs[NTW], cq[NTW];
+#pragma unroll
+        for (int b = 0; b < NTW; b++) { cs[b] = 0.f; cq[b] = 0.f; }
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -389,7 +393,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_ ==
                         if (NT_ST) __builtin_nontemporal_store(v[r], &y2[o]); else y2[o] = v[r];
                     }
                 }
+                if (!BWD && p.part) {                       // the column sums ride along: a lane's 16 rows, then (below) the block's other 16 and the wave's second block
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { cs[b] += v[r]; cq[b] = fmaf(v[r], v[r], cq[b]); }
+                }
             }
+        if (!BWD && p.part) {
+#pragma unroll
+            for (int b = 0; b < NTW; b++) {
+                const float s1 = cs[b] + __shfl_xor(cs[b], 32), s2 = cq[b] + __shfl_xor(cq[b], 32);
+                if (h == 0) {
+                    float *pp = p.part + ((long)(tm * 2 + wm) * 2) * Cout + n0 + wn * (32 * NTW) + b * 32 + l31;
+                    pp[0] = s1; pp[Cout] = s2;
+                }
+            }
+        }
         return;
     }
 #pragma unroll
@@ -871,7 +889,8 @@ bool conv_big_ok(int Cin, int Cout) { return Cin >= 32 && (Cin % 32) == 0 && Cou
 // forward (BWD = false) or dX (BWD = true); X/Cin are the gathered tensor, Y/Cout the produced one
 template <bool BWD>
 void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float *Y, float *Y2, const float *F, const float *B,
-                     int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f) {
+                     int N, int Hx, int Wx, int Cin, int Hy, int Wy, int Cout, int C0f, float *bn_part, size_t bn_part_floats, int *bn_chunks) {
+    if (bn_chunks) *bn_chunks = 0;
     const long npix = (long)N * Hy * Wy;
     {   // stride 1, "same" padding, whole 64-channel stages: the 8-wave LDS-DMA kernel (k_convbig8), every such layer since round 5 (round 4 kept the 9-stage
         // layers on k_convbig: with buffer-addressed DMA, the branch-free epilogue and two workgroups per CU on 32-channel stages they gain most -
@@ -884,7 +903,9 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
             // 128-wide tiles when they still give every CU a workgroup, 64-wide otherwise (CIFAR conv3 dX: 128 -> 256 workgroups) and for 64 output channels
             const bool wide = Cout > 64 && (long)tiles_m * ((Cout + 127) / 128) >= (long)st().cu_count;
             const int BN = wide ? 128 : 64;
-            Cb8 q = { X, F, B, Y, Y2, N, Hy, Wy, Cin, Cout, C0f, (Cout + BN - 1) / BN };
+            float *rider = nullptr;                         // batch-norm statistics from the epilogue: forward, every tile interior, the slab fits
+            if (!BWD && bn_part && bn_chunks && npix % 128 == 0 && Cout % BN == 0 && (size_t)tiles_m * 2 * 2 * Cout <= bn_part_floats) { rider = bn_part; *bn_chunks = tiles_m * 2; }
+            Cb8 q = { X, F, B, Y, Y2, rider, N, Hy, Wy, Cin, Cout, C0f, (Cout + BN - 1) / BN };
             const dim3 g8((unsigned)(tiles_m * q.tiles_n)), b8(512);
             // grids of two or more tiles per CU: 32-channel stages, half the LDS, at most 128 registers - two workgroups share a CU and one's stage barrier
             // (and prologue, and epilogue) runs under the other's MFMAs (as k_gemm_plain128<.., 32>)
@@ -922,8 +943,8 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
     }
 #undef CB
 }
-template void launch_conv_big<false>(int, int, int, hipStream_t, const float *, float *, float *, const float *, const float *, int, int, int, int, int, int, int, int);
-template void launch_conv_big<true>(int, int, int, hipStream_t, const float *, float *, float *, const float *, const float *, int, int, int, int, int, int, int, int);
+template void launch_conv_big<false>(int, int, int, hipStream_t, const float *, float *, float *, const float *, const float *, int, int, int, int, int, int, int, int, float *, size_t, int *);
+template void launch_conv_big<true>(int, int, int, hipStream_t, const float *, float *, float *, const float *, const float *, int, int, int, int, int, int, int, int, float *, size_t, int *);
 
 // dF partial slabs; returns the number of slices written (0: workspace too small).  Layout [slice][C1*K*K][C0].
 int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, const float *DO, float *part, size_t part_floats,

@@ -167,9 +167,9 @@ bool launch_cout(const ImgBlk &p, int Cout, unsigned grid, hipStream_t hs) {
 // layer-0 copy of the batch (forward.cu:39) leaves from the registers that hold the centre tap.
 typedef float f32x16i __attribute__((ext_vector_type(16)));
 typedef float f32x4i __attribute__((ext_vector_type(4)));
-template <int CIN, int NT, bool COPY, bool NTS>
+template <int CIN, int NT, bool COPY, bool NTS, bool STAT>
 __global__ void __launch_bounds__(256) k_conv_thin_fwd(const float *__restrict__ X, float *__restrict__ Y, float *__restrict__ XC,
-                                                       const float *__restrict__ F, const float *__restrict__ B, int N, int H, int W, long ntile) {
+                                                       const float *__restrict__ F, const float *__restrict__ B, int N, int H, int W, long ntile, float *__restrict__ part) {
     constexpr int KK = 9 * CIN, NS = (KK + 1) / 2, COUT = NT * 32;
     __shared__ __attribute__((aligned(16))) float Os[4 * 32 * COUT];
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
@@ -203,6 +203,9 @@ __global__ void __launch_bounds__(256) k_conv_thin_fwd(const float *__restrict__
     // the ragged last tile on a path of its own) so that its waits are counted ones.  Measured at 256 x 32 x 32 x 3 -> 64 (67 MB of output, a
     // 10 us memset): 17 us without the layer-0 copy, 21 us with it, against 37 us + a 3.7 us copy on the generic gather kernel.
     float *os = Os + (threadIdx.x >> 6) * (32 * COUT);
+    float cs[NT], cq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { cs[t] = 0.f; cq[t] = 0.f; }
     constexpr int RPI = 256 / COUT, NST = 32 / RPI;          // tile rows per store instruction (64 lanes x 4 channels), store instructions per tile
     const int rr = lane / (COUT / 4), c4 = (lane % (COUT / 4)) * 4;
     auto store_piece = [&](long Tp, int i) __attribute__((always_inline)) {
@@ -216,7 +219,11 @@ __global__ void __launch_bounds__(256) k_conv_thin_fwd(const float *__restrict__
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) os[((r & 3) + 8 * (r >> 2) + 4 * h) * COUT + t * 32 + l31] = acc[t][r] + bias[t];   // D[row = pixel][col = channel]: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h
+            for (int r = 0; r < 16; r++) {
+                const float v = acc[t][r] + bias[t];
+                os[((r & 3) + 8 * (r >> 2) + 4 * h) * COUT + t * 32 + l31] = v;   // D[row = pixel][col = channel]: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h
+                if (STAT) { cs[t] += v; cq[t] = fmaf(v, v, cq[t]); }             // STAT: the per-channel sums of a batch-norm layer behind this one ride along (a wave's tiles; npix % 32 == 0)
+            }
         __builtin_amdgcn_wave_barrier();
     };
     constexpr int XL = 8 * CIN;                              // the tile's own 32 x CIN input floats = XL 16-byte pieces: the layer-0 copy (forward.cu:39);
@@ -289,6 +296,17 @@ __global__ void __launch_bounds__(256) k_conv_thin_fwd(const float *__restrict__
 #pragma unroll
         for (int i = 0; i < NST; i++) ps += pad[i];
         if (ps == 1.2345e-37f) os[lane] = ps;               // keeps the padding loads' registers pending through the loop (never true in effect: LDS only)
+    }
+    if (STAT) {                                             // one partial row pair per workgroup: [workgroup][sum y | sum y^2][COUT], folded by k_bn_fin in fixed order
+        __builtin_amdgcn_wave_barrier();                    // the wave's own LDS tile is free: its last stores have read it
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float s1 = cs[t] + __shfl_xor(cs[t], 32), s2 = cq[t] + __shfl_xor(cq[t], 32);
+            if (h == 0) { os[t * 32 + l31] = s1; os[COUT + t * 32 + l31] = s2; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * COUT)
+            part[(long)blockIdx.x * 2 * COUT + threadIdx.x] = (Os[threadIdx.x] + Os[32 * COUT + threadIdx.x]) + (Os[2 * 32 * COUT + threadIdx.x] + Os[3 * 32 * COUT + threadIdx.x]);
     }
     if (nfull < ntile && gw == nfull % GW) {                // the ragged last tile: guarded everything, stored straight from the accumulators
         float a[NS]; unsigned dd;
@@ -376,7 +394,9 @@ __global__ void __launch_bounds__(256) k_conv_thin_df(const float *__restrict__ 
 
 namespace t4k {
 // true when the layer was launched here (t4k_conv2d_fwd2 falls through to its other kernels otherwise); ICOPY may be null
-bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs) {
+bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs,
+                   float *bn_part, size_t bn_part_floats, int *bn_chunks) {
+    if (bn_chunks) *bn_chunks = 0;
     static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_THIN"); on = e ? atoi(e) : 1; }
     if (!on || C1 < 1 || C1 > 4 || (C0 != 32 && C0 != 64) || (long)N * H * W >= 0x7fffff00L) return false;
     if (!aligned16(I) || !aligned16(O) || (ICOPY && !aligned16(ICOPY))) return false;       // 16-byte pieces of the batch copy and of the output rows
@@ -385,8 +405,11 @@ bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const
     long wg = (ntile + 3) / 4; if (wg > cap) wg = cap;         // a wave walks ntile / (4 wg) tiles with its filter in registers
     const dim3 g((unsigned)wg), b(256);
     static int nts = -1; if (nts < 0) { const char *e = getenv("T4K_CONV_THIN_NT"); nts = e ? atoi(e) : 1; }
-#define T4K_THIN2(C_, T_, N_) do { if (ICOPY) T4K_LAUNCH((k_conv_thin_fwd<C_, T_, true, N_>), g, b, 0, hs, I, O, ICOPY, F, B, N, H, W, ntile); \
-                               else T4K_LAUNCH((k_conv_thin_fwd<C_, T_, false, N_>), g, b, 0, hs, I, O, ICOPY, F, B, N, H, W, ntile); } while (0)
+    const bool stat = bn_part && bn_chunks && ((long)N * H * W) % 32 == 0 && (size_t)wg * 2 * C0 <= bn_part_floats;    // batch-norm sums from the epilogue: whole tiles only
+    if (stat) *bn_chunks = (int)wg;
+#define T4K_THIN3(C_, T_, N_, S_) do { if (ICOPY) T4K_LAUNCH((k_conv_thin_fwd<C_, T_, true, N_, S_>), g, b, 0, hs, I, O, ICOPY, F, B, N, H, W, ntile, bn_part); \
+                                   else T4K_LAUNCH((k_conv_thin_fwd<C_, T_, false, N_, S_>), g, b, 0, hs, I, O, ICOPY, F, B, N, H, W, ntile, bn_part); } while (0)
+#define T4K_THIN2(C_, T_, N_) do { if (stat) T4K_THIN3(C_, T_, N_, true); else T4K_THIN3(C_, T_, N_, false); } while (0)
 #define T4K_THIN(C_, T_) do { if (nts) T4K_THIN2(C_, T_, true); else T4K_THIN2(C_, T_, false); } while (0)
     switch (C1 * 4 + C0 / 32) {
     case 5: T4K_THIN(1, 1); break; case 6: T4K_THIN(1, 2); break;
@@ -397,6 +420,7 @@ bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const
     }
 #undef T4K_THIN
 #undef T4K_THIN2
+#undef T4K_THIN3
     return true;
 }
 // dF | dB partial slabs of the same layer: true when launched here, *nslice = slab rows ((9 C1 + 1) x C0 floats each) for k_conv_df_fold

@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(BLK) k_bn_fin(const float *__restrict__ part, 
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     float a = 0.f, b = 0.f;
-    for (int k = lane; k < nchunk; k += 64) { a += part[((long)k * 2 + 0) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }
+#pragma unroll 8
+    for (int k = lane; k < nchunk; k += 64) { a += part[((long)k * 2 + 0) * C + c]; b += part[((long)k * 2 + 1) * C + c]; }   // (unrolled: the loads of eight trips in flight together, same order of additions)
     a = wave_sum_all(a); b = wave_sum_all(b);
     if (lane == 0) {
         if (MODE == 0) {
@@ -370,6 +371,15 @@ static int bn_stats_sync(const float *X, const float *Y, float *stat, float *DW,
 }
 
 } // namespace
+
+namespace t4k {
+// the batch-norm forward from chunk partials [nchunk][sum x | sum x^2][C] a producer left (t4k_conv2d_bn_fwd): finalise + apply
+int bn_fwd_from_parts(const float *I, float *O, float *XH, const float *W, const float *B, float *stat, long NHW, int C, const float *part, int nchunk, hipStream_t hs) {
+    T4K_LAUNCH(k_bn_fin<0>, dim3((C + 3) / 4), dim3(BLK), 0, hs, part, stat, (float *)nullptr, (float *)nullptr, NHW, C, nchunk, 0);
+    T4K_LAUNCH(k_bn_apply, dim3(grid_for(NHW * C)), dim3(BLK), 0, hs, I, O, XH, W, B, stat, NHW * C, C);
+    T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+}
 
 extern "C" {
 

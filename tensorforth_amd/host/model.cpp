@@ -430,6 +430,14 @@ void Model::run_forward(Tensor &input) {
             x = at(i + 1 + r.count).data; i += r.count;
             continue;
         }
+        if (fused && in.grad_fn == T4K_L_CONV && i + 2 < L && out.grad_fn == T4K_L_BATCHNM) {   // conv + batch-norm: the statistics ride in the conv's epilogue where its kernel carries them
+            Tensor &o2 = at(i + 2);
+            chk(t4k_conv2d_bn_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
+                                  out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2],
+                                  o2.data, out.grad[4]->data, out.grad[0]->data, out.grad[1]->data, out.mtum[4]->data, stream()), "nn#fconv+batchnorm");
+            x = o2.data; i += 1;
+            continue;
+        }
         if (i == 0 && copy_in_conv) {
             chk(t4k_conv2d_fwd2(x, n0.data, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
                                 out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2], stream()), "nn#fconv");

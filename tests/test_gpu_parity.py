@@ -329,6 +329,37 @@ def _batchnorm_case(t4k, dev, oracle, N, HW, C):
     assert rel(dev.down(dDX), DX) < 5e-4 and rel(dev.down(dDW), DW) < RTOL and rel(dev.down(dDB), DB) < RTOL
 
 
+@pytest.mark.parametrize("N,H,C1,C0", [(64, 16, 3, 64),      # image in, 64 channels out: k_conv_thin_fwd carries the sums (a partial pair per workgroup)
+                                       (8, 16, 64, 128),     # k_convbig8, 128-wide tiles (16 of them: two 64-row partial pairs each)
+                                       (16, 8, 64, 64),      # k_convbig8, 64-wide tiles
+                                       (5, 7, 64, 128),      # 245 pixels: a ragged tile -> no rider, the two layers one after the other
+                                       (16, 8, 10, 20)])     # a layer whose kernel carries no rider
+def test_conv_with_batchnorm_behind_it_matches_the_two_layers(t4k, dev, oracle, N, H, C1, C0):
+    """t4k_conv2d_bn_fwd (Model::_fconv + Model::_fbatchnorm): the conv output, x-hat, the batch-norm output and the statistics equal the oracle's conv followed by
+    its batch norm; where the conv kernel carries the per-channel sums in its epilogue the separate statistics pass is not launched - same tensors, the sums in
+    another (fixed) order.  T4K_CONV_BN_RIDER=0 (tests/test_gpu_switches.py) runs the two calls."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((N, H, H, C1)).astype(np.float32); f = (rng.standard_normal((C1, 3, 3, C0)) * 0.2).astype(np.float32); bc = rng.standard_normal(C0).astype(np.float32)
+    g = rng.standard_normal(C0).astype(np.float32); b = rng.standard_normal(C0).astype(np.float32)
+    y = np.zeros((N, H, H, C0), np.float32); out = np.zeros_like(y); xh = np.zeros_like(y); stat = np.zeros(3 * C0, np.float32)
+    o.t4o_conv2d_fwd(P(x), P(y), P(f), P(bc), N, H, H, C1, H, H, C0, 3, 1, 1)
+    o.t4o_batchnorm_fwd(P(y), P(out), P(xh), P(g), P(b), P(stat), N, H * H, C0)
+    dx, df, dbc, dg, db = dev.up(x), dev.up(f), dev.up(bc), dev.up(g), dev.up(b)
+    dic, dy, do, dxh, dst = dev.zeros(x.shape), dev.zeros(y.shape), dev.zeros(y.shape), dev.zeros(y.shape), dev.zeros(3 * C0)
+    t4k.call("t4k_conv2d_bn_fwd", p(dx), p(dic), p(dy), p(df), p(dbc), N, H, H, C1, H, H, C0, 3, 1, 1, p(do), p(dxh), p(dg), p(db), p(dst), None)
+    assert np.array_equal(dev.down(dic), x)
+    assert rel(dev.down(dy), y) < RTOL and rel(dev.down(dst)[:2 * C0], stat[:2 * C0]) < RTOL
+    assert rel(dev.down(dxh), xh) < 5e-4 and rel(dev.down(do), out) < 5e-4
+    # the same call twice gives the same bits (fixed fold order), and so do the two separate calls up to the order of the sums
+    do2, dxh2, dst2, dy2 = dev.zeros(y.shape), dev.zeros(y.shape), dev.zeros(3 * C0), dev.zeros(y.shape)
+    t4k.call("t4k_conv2d_bn_fwd", p(dx), None, p(dy2), p(df), p(dbc), N, H, H, C1, H, H, C0, 3, 1, 1, p(do2), p(dxh2), p(dg), p(db), p(dst2), None)
+    assert np.array_equal(dev.down(do2), dev.down(do)) and np.array_equal(dev.down(dst2)[:2 * C0], dev.down(dst)[:2 * C0])
+    t4k.call("t4k_conv2d_fwd", p(dx), p(dy2), p(df), p(dbc), N, H, H, C1, H, H, C0, 3, 1, 1, None)
+    t4k.call("t4k_batchnorm_fwd", p(dy2), p(do2), p(dxh2), p(dg), p(db), p(dst2), N, H * H, C0, None)
+    assert np.array_equal(dev.down(dy2), dev.down(dy)) and rel(dev.down(do2), dev.down(do)) < 1e-5
+
+
 def test_optimizers_and_multi_tensor_step(t4k, dev, oracle):
     o = oracle.lib(); P = oracle.P
     rng = np.random.default_rng(9)

@@ -99,7 +99,8 @@ def test_conv_kernel_on_the_lean_pipeline_and_its_variants_match_the_oracle():
     conv parity tests by default; T4K_CONVBIG8=0 none (k_convbig).  T4K_CONVBIG8_BK32: 32-channel stages with two workgroups per CU - 2 = on every grid,
     0 = never (default: grids of two or more tiles per CU); T4K_CONVBIG8_NT=1: streaming stores in the epilogue."""
     _conv_tests("0")
-    for env in ({"T4K_CONVBIG8_BK32": "2"}, {"T4K_CONVBIG8_BK32": "0"}, {"T4K_CONVBIG8_NT": "1"}):
+    for env in ({"T4K_CONVBIG8_BK32": "2"}, {"T4K_CONVBIG8_BK32": "0"}, {"T4K_CONVBIG8_NT": "1"}, {"T4K_CONVBIG_DFW": "0"}, {"T4K_CONVBIG_DFW": "3"}, {"T4K_CONVBIG_DFW": "4"},
+                {"T4K_CONV_BN_RIDER": "0"}, {"T4K_BN_PART4": "0"}):
         _conv_tests(None, env)
 
 
@@ -114,5 +115,5 @@ def test_conv_parity_without_the_thin_input_kernel_and_with_other_grids():
 def _conv_tests(v, extra=None):
     env = dict(os.environ, **({"T4K_CONVBIG8": v} if v is not None else {}), **(extra or {}))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
-                        "-k", "test_conv2d or many_channels or random_shapes or second_destination"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                        "-k", "test_conv2d or many_channels or random_shapes or second_destination or batchnorm"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
