@@ -335,6 +335,17 @@ typedef struct t4k_poolblock {
     float *copy_out;
 } t4k_poolblock;
 int t4k_poolblock_fwd(const float *X, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);
+/* the apply half of a batch-norm layer (statistics final in stat_dev, as t4k_batchnorm_fwd leaves them) + such a run right behind it, one pass over the
+ * layer's input Y: XH and O (the batch-norm layer's x-hat and output) and every tensor of the run are written exactly as t4k_batchnorm_fwd's apply +
+ * t4k_poolblock_fwd(O, ...) would */
+int t4k_bn_poolblock_fwd(const float *Y, float *O, float *XH, const float *W, const float *B, const float *stat_dev, const t4k_poolblock *blk,
+                         int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s);
+/* convolution + batch norm + such a run (conv -> batchnorm -> [dropout|activation] -> pool -> [activation]): t4k_conv2d_bn_fwd's statistics, then
+ * t4k_bn_poolblock_fwd; Hq x Wq = the pooled grid (H0 x W0 when the run has no pool layer) */
+int t4k_conv2d_bn_block_fwd(const float *I, float *ICOPY, float *Y, const float *F, const float *Bc,
+                            int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P,
+                            float *O, float *XH, const float *W, const float *B, float *stat_dev,
+                            const t4k_poolblock *blk, int Hq, int Wq, t4k_stream_t s);
 /* convolution forward with such a run right behind it (conv -> [dropout|activation] -> 2x2 pool -> [activation] -> [flatten]):
  * O and every tensor of the run are written exactly as t4k_conv2d_fwd2 + t4k_poolblock_fwd would; one launch when the
  * layer takes the gather-MFMA kernel (the pool window is four consecutive accumulator registers of a lane) */

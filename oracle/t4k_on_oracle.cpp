@@ -125,6 +125,17 @@ int t4k_conv2d_fwd2(const float *I, float *IC, float *O, const float *F, const f
     if (IC) memcpy(IC, I, sizeof(float) * (size_t)N * H1 * W1 * C1);
     return t4k_conv2d_fwd(I, O, F, B, N, H1, W1, C1, H0, W0, C0, K, S, P, st);
 }
+int t4k_bn_poolblock_fwd(const float *Y, float *O, float *XH, const float *W, const float *B, const float *st, const t4k_poolblock *blk, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s) {
+    const long NHW = (long)N * H1 * W1;                       // the apply half of t4o_batchnorm_fwd (oracle/t4_oracle.cpp), then the run as its own layers
+    for (long k = 0; k < NHW; k++) for (int c = 0; c < C; c++) { const long z = k * C + c; XH[z] = (Y[z] - st[C + c]) * st[c]; O[z] = XH[z] * W[c] + B[c]; }
+    return t4k_poolblock_fwd(O, blk, N, H1, W1, H0, W0, C, s);
+}
+int t4k_conv2d_bn_block_fwd(const float *I, float *IC, float *Y, const float *F, const float *Bc, int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P,
+                            float *O, float *XH, const float *W, const float *B, float *st, const t4k_poolblock *blk, int Hq, int Wq, t4k_stream_t s) {
+    int r = t4k_conv2d_fwd2(I, IC, Y, F, Bc, N, H1, W1, C1, H0, W0, C0, K, S, P, s); if (r) return r;
+    r = t4k_batchnorm_fwd(Y, O, XH, W, B, st, N, H0 * W0, C0, s); if (r) return r;
+    return t4k_poolblock_fwd(O, blk, N, H0, W0, Hq, Wq, C0, s);
+}
 int t4k_conv2d_bn_fwd(const float *I, float *IC, float *Y, const float *F, const float *Bc, int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P,
                       float *O, float *XH, const float *W, const float *B, float *st, t4k_stream_t s) {      // the two layers, one after the other
     int r = t4k_conv2d_fwd2(I, IC, Y, F, Bc, N, H1, W1, C1, H0, W0, C0, K, S, P, s); if (r) return r;

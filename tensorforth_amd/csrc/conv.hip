@@ -20,6 +20,7 @@
 namespace t4k { bool conv_thin_df(const float *I, const float *DO, float *part, size_t part_bytes, int N, int H, int W, int C1, int C0, int *nslice, hipStream_t hs); }
 namespace t4k { bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs,
                                   float *bn_part = nullptr, size_t bn_part_floats = 0, int *bn_chunks = nullptr);
+                int bn_stats_for(const float *I, float *stat, int N, int HW, int C, const float *part, int nchunk, t4k_stream_t s);
                 int bn_fwd_from_parts(const float *I, float *O, float *XH, const float *W, const float *B, float *stat, long NHW, int C, const float *part, int nchunk, hipStream_t hs); }
 namespace t4k { bool conv_img_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
                                         int N, int H, int W, int C1, int C0, hipStream_t hs); }
@@ -844,6 +845,24 @@ int t4k_conv2d_bn_fwd(const float *I, float *ICOPY, float *Y, const float *F, co
     if (rc != T4K_OK) return rc;
     if (chunks > 0) return bn_fwd_from_parts(Y, O, XH, W, B, stat_dev, (long)N * H0 * W0, C0, ws_for(s), chunks, t4k::S(s));
     return t4k_batchnorm_fwd(Y, O, XH, W, B, stat_dev, N, H0 * W0, C0, s);
+}
+
+// conv + batch-norm + the element-wise run behind them (the CIFAR-style block conv -> batchnorm -> relu -> maxpool -> dropout): the conv (its epilogue carrying the
+// per-channel sums where it can), the finalise of the statistics, then ONE pass that reads the conv output once and writes x-hat, the batch-norm output and
+// every tensor of the run (t4k_bn_poolblock_fwd) - the batch-norm output is not read back from memory.  Same tensors as the three calls.
+int t4k_conv2d_bn_block_fwd(const float *I, float *ICOPY, float *Y, const float *F, const float *Bc,
+                            int N, int H1, int W1, int C1, int H0, int W0, int C0, int K, int S, int P,
+                            float *O, float *XH, const float *W, const float *B, float *stat_dev,
+                            const t4k_poolblock *blk, int Hq, int Wq, t4k_stream_t s) {
+    T4K_REQUIRE_INIT();
+    if (!O || !XH || !W || !B || !stat_dev || !blk) return fail(T4K_ERR_ARG, "t4k_conv2d_bn_block_fwd: null tensor");
+    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_BN_RIDER"); on = e ? atoi(e) : 1; }
+    const bool rider = on && !(st().bn_sync && t4k_comm_world() > 0);
+    int chunks = 0;
+    int rc = conv2d_fwd_impl(I, ICOPY, Y, F, Bc, N, H1, W1, C1, H0, W0, C0, K, S, P, rider ? ws_for(s) : nullptr, st().ws_bytes / 8, &chunks, s);
+    if (rc != T4K_OK) return rc;
+    rc = bn_stats_for(Y, stat_dev, N, H0 * W0, C0, ws_for(s), chunks, s); if (rc != T4K_OK) return rc;
+    return t4k_bn_poolblock_fwd(Y, O, XH, W, B, stat_dev, blk, N, H0, W0, Hq, Wq, C0, s);
 }
 
 // conv forward + the element-wise run behind it (dropout/activation -> 2x2 pool -> activation -> flatten copy) in ONE launch

@@ -21,6 +21,7 @@ struct PB {                                   // device copy of t4k_poolblock + 
     int pre, pool, post; float a_pre, a_post;
     int N, H1, W1, H0, W0, C;
     RngArg rng, rng2;                        // Philox slices of a dropout pre-stage / post-stage (one run holds at most one dropout)
+    float *XH, *BO; const float *bnW, *bnB, *bnS;    // BN form (k_poolblock_fwd<.., true>): X is a conv output, the run starts with the batch-norm apply - x-hat, its output
 };
 
 // VW channels per thread (1, 2 or 4; C % VW == 0 and 4*VW-byte aligned tensors): vector loads / stores, and one
@@ -39,7 +40,9 @@ template <int VW> __device__ __forceinline__ void vstore(float *p, const Vec<VW>
     else              *p = r.v[0];
 }
 
-template <int KS, int VW>
+// BN: the run is preceded by the apply half of a batch-norm layer (statistics already finalised in bnS: [0, C) 1 / sigma, [C, 2C) mean): every element of X
+// is read ONCE, x-hat and the batch-norm output are written as k_bn_apply writes them (same expressions), and the run goes on from the value in registers.
+template <int KS, int VW, bool BN = false>
 __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
     const int CV = p.C / VW;
     const long total = (long)p.N * p.H0 * p.W0 * CV;
@@ -60,6 +63,12 @@ __global__ void __launch_bounds__(BLK) k_poolblock_fwd(PB p) {
                 if (gi >= p.H1 || gj >= p.W1) continue;
                 const long a = (((long)n * p.H1 + gi) * p.W1 + gj) * p.C + c;
                 Vec<VW> e = vload<VW>(p.X + a);
+                if (BN) {
+                    Vec<VW> xh;
+#pragma unroll
+                    for (int q = 0; q < VW; q++) { xh.v[q] = (e.v[q] - p.bnS[p.C + c + q]) * p.bnS[c + q]; e.v[q] = xh.v[q] * p.bnW[c + q] + p.bnB[c + q]; }
+                    vstore<VW>(p.XH + a, xh); vstore<VW>(p.BO + a, e);
+                }
                 if (p.pre) {
                     Vec<VW> o, f;
                     uint32_t r[4] = {0, 0, 0, 0};
@@ -201,7 +210,8 @@ int check_block(const t4k_poolblock *b, const char *who) {
 
 extern "C" {
 
-int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s) {
+static int poolblock_fwd_impl(const float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s,
+                             float *XH, float *BO, const float *bnW, const float *bnB, const float *bnS) {
     T4K_REQUIRE_INIT();
     int rc = check_block(b, "t4k_poolblock_fwd"); if (rc) return rc;
     if (!X) return fail(T4K_ERR_ARG, "t4k_poolblock_fwd: null input");
@@ -210,20 +220,33 @@ int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int
     p.X = X; p.P = b->pre_out; p.Q = b->pool_out; p.R = b->post_out; p.R2 = b->copy_out; p.Fpre = b->pre_mask; p.Fpost = b->post_mask;
     p.pre = b->pre_layer; p.pool = b->pool_layer; p.post = b->post_layer; p.a_pre = b->pre_alpha; p.a_post = b->post_alpha;
     p.N = N; p.H1 = H1; p.W1 = W1; p.H0 = H0; p.W0 = W0; p.C = C;
+    p.XH = XH; p.BO = BO; p.bnW = bnW; p.bnB = bnB; p.bnS = bnS;
     p.rng = RngArg{0, 0, nullptr};
     p.rng2 = RngArg{0, 0, nullptr};
     if (b->pre_layer == T4K_L_DROPOUT) p.rng = rng_draw(S(s), (uint64_t)(((long)N * H1 * W1 * C + 3) >> 2), true);
     if (b->post_layer == T4K_L_DROPOUT) p.rng2 = rng_draw(S(s), (uint64_t)((total + 3) >> 2), true);   // the slice t4k_dropout_mask would draw for the post tensor
-    const int VW = vec_width(C, X, b);
+    int VW = vec_width(C, X, b);
+    if (XH) { const uintptr_t m = (uintptr_t)(4 * VW - 1); if ((((uintptr_t)XH) | ((uintptr_t)BO)) & m) VW = 1; }
     const long nthr = total / VW;
     const int bs = (nthr < (long)BLK * 2 * st().cu_count) ? 64 : BLK;      // small runs: one-wave workgroups reach every CU
     const dim3 grid((unsigned)std::min<long>((nthr + bs - 1) / bs, 8192)), blk(bs);
-#define PBF(KS_) do { if (VW == 4) T4K_LAUNCH((k_poolblock_fwd<KS_, 4>), grid, blk, 0, S(s), p); \
-                      else if (VW == 2) T4K_LAUNCH((k_poolblock_fwd<KS_, 2>), grid, blk, 0, S(s), p); \
-                      else T4K_LAUNCH((k_poolblock_fwd<KS_, 1>), grid, blk, 0, S(s), p); } while (0)
+#define PBF_(KS_, BN_) do { if (VW == 4) T4K_LAUNCH((k_poolblock_fwd<KS_, 4, BN_>), grid, blk, 0, S(s), p); \
+                            else if (VW == 2) T4K_LAUNCH((k_poolblock_fwd<KS_, 2, BN_>), grid, blk, 0, S(s), p); \
+                            else T4K_LAUNCH((k_poolblock_fwd<KS_, 1, BN_>), grid, blk, 0, S(s), p); } while (0)
+#define PBF(KS_) do { if (XH) PBF_(KS_, true); else PBF_(KS_, false); } while (0)
     switch (b->KS) { case 1: PBF(1); break; case 2: PBF(2); break; default: PBF(3); break; }
 #undef PBF
+#undef PBF_
     T4K_LAUNCH_CHECK(); return T4K_OK;
+}
+int t4k_poolblock_fwd(const float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s) {
+    return poolblock_fwd_impl(X, b, N, H1, W1, H0, W0, C, s, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+// the apply half of a batch-norm layer + the run behind it in one pass over the conv output (the statistics are final in stat_dev)
+int t4k_bn_poolblock_fwd(const float *Y, float *O, float *XH, const float *W, const float *B, const float *stat_dev, const t4k_poolblock *b,
+                         int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s) {
+    if (!O || !XH || !W || !B || !stat_dev) return fail(T4K_ERR_ARG, "t4k_bn_poolblock_fwd: null batch-norm tensor");
+    return poolblock_fwd_impl(Y, b, N, H1, W1, H0, W0, C, s, XH, O, W, B, stat_dev);
 }
 
 int t4k_poolblock_bwd(const float *DY, float *X, const t4k_poolblock *b, int N, int H1, int W1, int H0, int W0, int C, t4k_stream_t s) {

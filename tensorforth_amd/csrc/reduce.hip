@@ -379,6 +379,8 @@ int bn_fwd_from_parts(const float *I, float *O, float *XH, const float *W, const
     T4K_LAUNCH(k_bn_apply, dim3(grid_for(NHW * C)), dim3(BLK), 0, hs, I, O, XH, W, B, stat, NHW * C, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
+// the statistics alone: from a producer's chunk partials (nchunk > 0, in the stream's workspace) or by the passes of t4k_batchnorm_fwd
+int bn_stats_for(const float *I, float *stat, int N, int HW, int C, const float *part, int nchunk, t4k_stream_t s);
 }
 
 extern "C" {
@@ -444,10 +446,9 @@ int t4k_dlinear_db(const float *DY, float *DB, int N, int E0, t4k_stream_t s) {
     T4K_LAUNCH(k_dlinear_db, dim3((E0 + 63) / 64), dim3(BLK), 0, S(s), DY, DB, N, E0);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
-int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B,
-                      float *stat, int N, int HW, int C, t4k_stream_t s) {
-    T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_fwd: shape");
-    const long NHW = (long)N * HW, total = NHW * C;
+// the statistics half of the batch-norm forward: stat_dev [0, C) = 1 / (sigma + eps), [C, 2C) = mean
+static int bn_fwd_stats(const float *I, float *stat, int N, int HW, int C, t4k_stream_t s) {
+    const long NHW = (long)N * HW;
     if (st().bn_sync && t4k_comm_world() > 0) {          // data parallel (opt-in, t4k_comm_sync_batchnorm): statistics over every rank's shard
         int rc = bn_stats_sync<0>(I, nullptr, stat, nullptr, nullptr, NHW, C, 0, s); if (rc != T4K_OK) return rc;
     } else if (NHW >= 2048) {                            // image-sized: chunked coalesced column sums + per-channel fold
@@ -458,6 +459,13 @@ int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const
         launch_bn_part<0>(I, nullptr, part, NHW, C, rpc, nch, S(s));
         T4K_LAUNCH(k_bn_fin<0>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, (float *)nullptr, (float *)nullptr, NHW, C, (int)nch, 0);
     } else T4K_LAUNCH(k_bn_stats, dim3(C), dim3(BLK), 0, S(s), I, stat, NHW, C);
+    return T4K_OK;
+}
+int t4k_batchnorm_fwd(const float *I, float *O, float *XH, const float *W, const float *B,
+                      float *stat, int N, int HW, int C, t4k_stream_t s) {
+    T4K_REQUIRE_INIT(); if (N <= 0 || HW <= 0 || C <= 0) return fail(T4K_ERR_ARG, "t4k_batchnorm_fwd: shape");
+    const long total = (long)N * HW * C;
+    int rc = bn_fwd_stats(I, stat, N, HW, C, s); if (rc != T4K_OK) return rc;
     T4K_LAUNCH(k_bn_apply, dim3(grid_for(total)), dim3(BLK), 0, S(s), I, O, XH, W, B, stat, total, C);
     T4K_LAUNCH_CHECK(); return T4K_OK;
 }
@@ -480,3 +488,10 @@ int t4k_batchnorm_bwd(const float *W, const float *DY, const float *XH, float *D
 }
 
 } // extern "C"
+
+namespace t4k {
+int bn_stats_for(const float *I, float *stat, int N, int HW, int C, const float *part, int nchunk, t4k_stream_t s) {
+    if (nchunk > 0) { T4K_LAUNCH(k_bn_fin<0>, dim3((C + 3) / 4), dim3(BLK), 0, S(s), part, stat, (float *)nullptr, (float *)nullptr, (long)N * HW, C, nchunk, 0); T4K_LAUNCH_CHECK(); return T4K_OK; }
+    return bn_fwd_stats(I, stat, N, HW, C, s);
+}
+}

@@ -430,6 +430,17 @@ void Model::run_forward(Tensor &input) {
             x = at(i + 1 + r.count).data; i += r.count;
             continue;
         }
+        if (fused && in.grad_fn == T4K_L_CONV && i + 3 < L && out.grad_fn == T4K_L_BATCHNM && run_of_[i + 2] >= 0) {   // conv + batch-norm + the element-wise run behind them: the conv
+            const int i2 = i + 2;                          // output is read once (statistics from the conv's epilogue, batch-norm apply inside the run's launch)
+            const Run &r = runs_[run_of_[i2]];
+            Tensor &o2 = at(i2), &pin = (r.blk.pool_layer ? at(i2 + (r.blk.pre_layer ? 1 : 0)) : o2);
+            const int Hq = r.blk.pool_layer ? at(i2 + (r.blk.pre_layer ? 2 : 1)).H() : pin.H(), Wq = r.blk.pool_layer ? at(i2 + (r.blk.pre_layer ? 2 : 1)).W() : pin.W();
+            chk(t4k_conv2d_bn_block_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),
+                                        out.H(), out.W(), out.C(), in.grad[0]->H(), in.stride[0], in.stride[2],
+                                        o2.data, out.grad[4]->data, out.grad[0]->data, out.grad[1]->data, out.mtum[4]->data, &r.blk, Hq, Wq, stream()), "nn#fconv+batchnorm+run");
+            x = at(i2 + r.count).data; i = i2 + r.count - 1;
+            continue;
+        }
         if (fused && in.grad_fn == T4K_L_CONV && i + 2 < L && out.grad_fn == T4K_L_BATCHNM) {   // conv + batch-norm: the statistics ride in the conv's epilogue where its kernel carries them
             Tensor &o2 = at(i + 2);
             chk(t4k_conv2d_bn_fwd(x, (i == 0 && copy_in_conv) ? n0.data : nullptr, out.data, in.grad[0]->data, in.grad[1]->data, out.N(), in.H(), in.W(), in.C(),

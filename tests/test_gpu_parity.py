@@ -669,6 +669,49 @@ def test_conv_block_forward_and_dual_store_backward(t4k, dev, oracle, N, H, C1, 
     assert rel(dev.down(dDF), DF) < RTOL and rel(dev.down(dDB), DB) < RTOL
 
 
+@pytest.mark.parametrize("N,H,C1,C0", [(16, 16, 3, 64), (8, 16, 64, 128), (4, 7, 64, 64), (8, 8, 10, 20)])
+def test_conv_batchnorm_and_the_run_behind_them_in_one_call(t4k, dev, oracle, N, H, C1, C0):
+    """t4k_conv2d_bn_block_fwd (the CIFAR-style block conv -> batchnorm -> relu -> maxpool -> dropout): conv output, x-hat, batch-norm output, relu mask / output, pool
+    output, dropout mask / output against the oracle's layers one after the other (dropout mask bit-exact, the Philox stream advanced identically), and bit-equal
+    to the library's own separate calls t4k_conv2d_bn_fwd + t4k_poolblock_fwd (the fused pass reads the conv output once; same expressions per element)."""
+    o = oracle.lib(); P = oracle.P
+    rng = np.random.default_rng(N + H + C0)
+    Hp = (H + 1) // 2
+    X = rng.standard_normal((N, H, H, C1)).astype(np.float32); F = (rng.standard_normal((C1, 3, 3, C0)) * 0.3).astype(np.float32); Bc = rng.standard_normal(C0).astype(np.float32)
+    g = rng.standard_normal(C0).astype(np.float32); b = rng.standard_normal(C0).astype(np.float32)
+    n1, n0 = N * H * H * C0, N * Hp * Hp * C0
+    seed, off = 77, 4096
+    o.t4o_rand_init(seed); o.t4o_rand_set_offset(off)
+    Y = np.zeros((N, H, H, C0), np.float32); o.t4o_conv2d_fwd(P(X), P(Y), P(F), P(Bc), N, H, H, C1, H, H, C0, 3, 1, 1)
+    BO = np.zeros_like(Y); XH = np.zeros_like(Y); stat = np.zeros(3 * C0, np.float32)
+    o.t4o_batchnorm_fwd(P(Y), P(BO), P(XH), P(g), P(b), P(stat), N, H * H, C0)
+    rm = np.zeros(n1, np.float32); ro = np.zeros_like(Y); o.t4o_activate(oracle.L_RELU, P(BO), P(ro), P(rm), 0.0, n1)
+    q = np.zeros((N, Hp, Hp, C0), np.float32); o.t4o_pool(oracle.L_MAXPOOL, P(ro), P(q), N, H, H, Hp, Hp, C0, 2)
+    dm = np.zeros(n0, np.float32); o.t4o_rand(P(dm), n0, 0, 0.0, 1.0); do_ = np.zeros_like(q); o.t4o_activate(oracle.L_DROPOUT, P(q), P(do_), P(dm), 0.25, n0)
+
+    def run(fused):
+        t4k.call("t4k_rand_init", seed); t4k.call("t4k_rand_set_offset", off)
+        d = {k: dev.zeros(v) for k, v in (("Y", Y.shape), ("BO", Y.shape), ("XH", Y.shape), ("st", (3 * C0,)), ("rm", Y.shape), ("ro", Y.shape), ("q", q.shape), ("dm", q.shape), ("do", q.shape))}
+        blk = PoolBlock(); blk.KS = 2; blk.pool_layer = oracle.L_MAXPOOL; blk.pool_out = p(d["q"])
+        blk.pre_layer, blk.pre_alpha = oracle.L_RELU, 0.0; blk.pre_mask = p(d["rm"]); blk.pre_out = p(d["ro"])
+        blk.post_layer, blk.post_alpha = oracle.L_DROPOUT, 0.25; blk.post_mask = p(d["dm"]); blk.post_out = p(d["do"])
+        dX, dF, dBc, dg, db = dev.up(X), dev.up(F), dev.up(Bc), dev.up(g), dev.up(b)
+        if fused:
+            t4k.call("t4k_conv2d_bn_block_fwd", p(dX), None, p(d["Y"]), p(dF), p(dBc), N, H, H, C1, H, H, C0, 3, 1, 1,
+                     p(d["BO"]), p(d["XH"]), p(dg), p(db), p(d["st"]), ctypes.byref(blk), Hp, Hp, None)
+        else:
+            t4k.call("t4k_conv2d_bn_fwd", p(dX), None, p(d["Y"]), p(dF), p(dBc), N, H, H, C1, H, H, C0, 3, 1, 1, p(d["BO"]), p(d["XH"]), p(dg), p(db), p(d["st"]), None)
+            t4k.call("t4k_poolblock_fwd", p(d["BO"]), ctypes.byref(blk), N, H, H, Hp, Hp, C0, None)
+        return {k: dev.down(v) for k, v in d.items()}, t4k.lib.t4k_rand_offset()
+    a, offa = run(True)
+    assert offa == o.t4o_rand_offset()
+    assert rel(a["Y"], Y) < RTOL and rel(a["st"][:2 * C0], stat[:2 * C0]) < RTOL and rel(a["XH"], XH) < 5e-4 and rel(a["BO"], BO) < 5e-4
+    assert np.array_equal(a["dm"].ravel(), dm) and rel(a["ro"], ro) < 5e-4 and rel(a["q"], q) < 5e-4 and rel(a["do"], do_) < 5e-4
+    c, offc = run(False)
+    assert offc == offa
+    for k in a: assert np.array_equal(a[k], c[k]), k
+
+
 @pytest.mark.parametrize("N,E0,E1", [(128, 10, 100), (7, 3, 17), (256, 1, 256), (64, 40, 200), (33, 48, 130)])
 def test_small_linear_head_is_bit_identical_to_oracle(t4k, dev, oracle, N, E0, E1):
     """Classifier-head path (linear_small.hip): fmaf chains in ascending k, the oracle's order => exact equality
