@@ -307,6 +307,9 @@ def test_batchnorm_synchronised_statistics_world_one(t4k, dev, oracle, N, HW, C)
         _batchnorm_case(t4k, dev, oracle, N, HW, C)          # a communicator alone changes nothing: synchronised statistics are opt-in
         assert lib.t4k_comm_sync_batchnorm(1) == 0
         _batchnorm_case(t4k, dev, oracle, N, HW, C)          # ... and this is the all-reduce path
+        # conv + batch-norm (+ run) in one call under synchronised statistics: no epilogue rider, the sums go through the all-reduce; same tensors
+        test_conv_with_batchnorm_behind_it_matches_the_two_layers(t4k, dev, oracle, 8, 16, 64, 128)
+        test_conv_batchnorm_and_the_run_behind_them_in_one_call(t4k, dev, oracle, 8, 16, 64, 128)
     finally:
         lib.t4k_comm_destroy()
 
