@@ -45,6 +45,9 @@ done <<'SHAPES'
 512 1024 1024 0 1
 2048 2048 784 0 1
 2048 2048 1024 0 1 bias
+2048 2048 2048 0 0
 4096 4096 1024 0 1 bias
+4096 4096 1024 0 0
+4096 4096 4096 0 0
 SHAPES
 cat "$OUT"

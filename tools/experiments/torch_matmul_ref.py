@@ -15,7 +15,7 @@ def timeit(fn, iters=200):
         best = min(best, e0.elapsed_time(e1) / iters * 1e3)
     return best
 print("torch", torch.__version__, torch.cuda.get_device_name(0), "preferred blas:", getattr(torch.backends.cuda, "preferred_blas_library", lambda: "?")())
-for M, N, K in [(1024, 1024, 1024), (1024, 1024, 784), (512, 1024, 1024), (2048, 2048, 2048), (2048, 2048, 784), (4096, 4096, 1024)]:
+for M, N, K in [(1024, 1024, 1024), (1024, 1024, 784), (512, 1024, 1024), (2048, 2048, 2048), (2048, 2048, 784), (4096, 4096, 1024), (4096, 4096, 4096), (16384, 256, 1152), (65536, 128, 576)]:
     A = torch.rand(M, K, device="cuda") - 0.5; B = torch.rand(K, N, device="cuda") - 0.5; W = torch.rand(N, K, device="cuda") - 0.5; b = torch.rand(N, device="cuda"); O = torch.empty(M, N, device="cuda")
     t_nn = timeit(lambda: torch.mm(A, B, out=O))
     t_nt = timeit(lambda: torch.mm(A, W.t(), out=O))
