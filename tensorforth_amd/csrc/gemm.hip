@@ -1810,9 +1810,149 @@ void launch_plain128_(const PlainP &q, hipStream_t s) {
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain128<AKC, BKC, EPI, RAGK, BK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
     T4K_LAUNCH((k_gemm_plain128<AKC, BKC, EPI, RAGK, BK_>), dim3((unsigned)((q.M / 128) * (q.N / 128))), dim3(512), lds_bytes, s, q);
 }
+
+// 256 x 256 tile, 16 waves (round 5): for outputs of at least one such tile per CU (4096^2 and up).  The 128 x 128 kernel pays its stage barrier once per 8 192 MFMA
+// cycles of a SIMD (two waves); here sixteen waves - a 4 x 4 grid of 64 x 64 blocks, no k-groups, no meeting in LDS at the end - put 16 384 cycles of MFMAs behind every
+// barrier on 32-deep stages of the same 64 KiB, and a stage moves half the bytes per flop (512 rows for 256 x 256 outputs).  126 registers: four waves per SIMD.
+// Interior tiles, K % 32 == 0; layouts and epilogue as k_gemm_plain128.
+template <bool AKC, bool BKC, bool EPI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_gemm_plain256(PlainP p) {
+    constexpr int BM = 256, BN = 256, BK = 32;
+    constexpr int NC = BK / 8, CH = BK / 4, RPI = 64 / CH;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int NJ = (BM * BK / 256) / 16;               // 1-KiB DMA instructions per operand per wave per stage (2)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3, h = lane >> 5, l31 = lane & 31;
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_m = M / BM, tiles_n = N / BN, T = tiles_m * tiles_n;
+    int tm, tn;
+    {
+        int L;
+        { const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
+          L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; }           // XCD x owns a contiguous run of the tile order
+        constexpr int GROUP_M = 4;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = L / per_group, first_m = grp * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        tm = first_m + (L % per_group) % gsz; tn = (L % per_group) / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN, nst = K / BK;
+    unsigned voffA[NJ], voffB[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int i = w * NJ + j;
+        if (AKC) { const int r = i * RPI + lane / CH, q = (lane % CH) ^ (r & (CH - 1)); voffA[j] = (unsigned)((m0 + r) * K + q * 4) * 4u; }
+        else     {                                                                      voffA[j] = (unsigned)(i * M + m0 + lane * 4) * 4u; }     // one k row of 256 floats per instruction
+        if (BKC) { const int r = i * RPI + lane / CH, q = (lane % CH) ^ (r & (CH - 1)); voffB[j] = (unsigned)((n0 + r) * K + q * 4) * 4u; }
+        else     {                                                                      voffB[j] = (unsigned)(i * N + n0 + lane * 4) * 4u; }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        const float *ba = p.A + (AKC ? (long)kt * BK : (long)kt * BK * M), *bb = p.B + (BKC ? (long)kt * BK : (long)kt * BK * N);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJ + j) * 256) * 4));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffA[j]), "s"(ba), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voffB[j]), "s"(bb), "s"(la + BM * BK * 4) : "memory");
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    const int ra_ = wm * 64 + l31, rb_ = wn * 64 + l31;
+    auto rd = [&](const float *a, const float *b, int ci, float (&av)[2][4], float (&bv)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int ra = ra_ + t * 32, rb = rb_ + t * 32;
+            if (AKC) { const v4f v = *reinterpret_cast<const v4f *>(a + ra * BK + (((ci * 2 + h) ^ (ra & (CH - 1))) << 2));
+                       av[t][0] = v[0]; av[t][1] = v[1]; av[t][2] = v[2]; av[t][3] = v[3]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) av[t][j] = a[(ci * 8 + 4 * h + j) * BM + ra];
+            }
+            if (BKC) { const v4f v = *reinterpret_cast<const v4f *>(b + rb * BK + (((ci * 2 + h) ^ (rb & (CH - 1))) << 2));
+                       bv[t][0] = v[0]; bv[t][1] = v[1]; bv[t][2] = v[2]; bv[t][3] = v[3]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) bv[t][j] = b[(ci * 8 + 4 * h + j) * BN + rb];
+            }
+        }
+    };
+    auto mm = [&](float (&av)[2][4], float (&bv)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j], bv[0][j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j], bv[1][j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j], bv[0][j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j], bv[1][j], acc[1][1], 0, 0, 0);
+        }
+    };
+    // four waves per SIMD: a wave reads a chunk's fragments and multiplies them - while it waits for LDS the other three keep the MFMA pipe busy, so no
+    // second fragment set is carried (with it the kernel spills, and a compiler-counted scratch reload waits for vmcnt(0), i.e. for the DMA of the NEXT stage)
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nst > 1) issue(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nst; kt++) {
+        const float *a = lds + buf * STAGE, *b = a + BM * BK;
+#pragma unroll
+        for (int ci = 0; ci < NC; ci++) {
+            float ca[2][4], cb[2][4];
+            rd(a, b, ci, ca, cb);
+            mm(ca, cb);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nst) issue(kt + 2, buf);
+        buf ^= 1;
+    }
+    const float alpha = EPI ? p.alpha : 1.f, beta = EPI ? p.beta : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int gn = n0 + wn * 64 + b * 32 + l31;
+            const float bsv = (EPI && p.bias) ? p.bias[gn] : 0.f;
+            float old[16];
+            if (EPI && beta != 0.f) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) old[r] = p.O[(long)(m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + gn];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int gm = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float o = acc[a][b][r];
+                if (EPI) { o *= alpha; if (beta != 0.f) o += old[r] * beta; o += bsv; }
+                __builtin_nontemporal_store(o, &p.O[(long)gm * N + gn]);
+            }
+        }
+}
+template <bool AKC, bool BKC, bool EPI>
+void launch_plain256_(const PlainP &q, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)2 * 512 * 32 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_plain256<AKC, BKC, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done = true; }
+    T4K_LAUNCH((k_gemm_plain256<AKC, BKC, EPI>), dim3((unsigned)((q.M / 256) * (q.N / 256))), dim3(1024), lds_bytes, s, q);
+}
 void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, nullptr, nullptr };
     const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias, ragk = p.K % 64 != 0;
+    {   // one 256 x 256 tile or more per CU: the 16-wave kernel (T4K_GEMM_PLAIN256: 0 off, 1 default, 2 any grid of whole 256-tiles)
+        static int p256 = -1; if (p256 < 0) { const char *e = getenv("T4K_GEMM_PLAIN256"); p256 = e ? atoi(e) : 1; }
+        const long t256 = (long)(p.M / 256) * (p.N / 256);
+        if (p256 && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 32 == 0 && p.K >= 64 && (p256 >= 2 || t256 >= (long)st().cu_count) &&
+            (long)p.M * p.K < (1L << 30) && (long)p.N * p.K < (1L << 30)) {
+#define T4K_P256(A_, B_) do { if (epi) launch_plain256_<A_, B_, true>(q, s); else launch_plain256_<A_, B_, false>(q, s); } while (0)
+            if (!tA && !tB) T4K_P256(true, false); else if (!tA) T4K_P256(true, true); else if (!tB) T4K_P256(false, false); else T4K_P256(false, true);
+#undef T4K_P256
+            return;
+        }
+    }
     // Two co-resident workgroups per CU on 32-deep stages once every CU gets at least two tiles (4096^2 x 1024: 261 -> 254 us, 8192 x 4096 x 512: 282 -> 264 us;
     // with one tile per CU the doubled barrier count loses: 2048^3 129.5 -> 135.4 us).  K in whole 32s is unragged for this form.  T4K_GEMM_PLAIN128_BK32 = 0 / 1 / 2 (always).
     static int bk32 = -1; if (bk32 < 0) { const char *e = getenv("T4K_GEMM_PLAIN128_BK32"); bk32 = e ? atoi(e) : 1; }

@@ -1282,7 +1282,9 @@ def test_gemm_ragged_edges_and_slivers_exact_on_integer_operands(t4k, dev, M, N,
                                          (2048, 2048, 784, 0, 1), (2048, 2048, 328, 1, 0), (2048, 2304, 300, 0, 0), (2304, 2048, 444, 1, 1), (2048, 2048, 784, 0, 0),
                                          # ... two workgroups per CU on 32-deep stages (k_gemm_plain128<.., 32>, grids of >= 512 tiles; the two shapes above with 544 / 576 tiles take it too):
                                          # every layout, K in whole 32s that are not whole 64s (unragged for this form), a deep K
-                                         (2048, 4096, 288, 0, 0), (4096, 2048, 480, 1, 1), (4096, 2048, 512, 0, 1), (2048, 4096, 1056, 1, 0)])
+                                         (2048, 4096, 288, 0, 0), (4096, 2048, 480, 1, 1), (4096, 2048, 512, 0, 1), (2048, 4096, 1056, 1, 0),
+                                         # ... 256 x 256 tiles on 16 waves (k_gemm_plain256: one such tile or more per CU), every layout, a second column of tiles past 4096
+                                         (4096, 4096, 160, 0, 0), (4096, 4096, 96, 1, 1), (4096, 4352, 224, 0, 1), (4352, 4096, 64, 1, 0)])
 def test_gemm_large_transposed_products_exact_on_integer_operands(t4k, dev, M, N, K, tA, tB):
     """Large products with transposed operands and alpha / beta (the linear layers of an MLP) on the 8-wave LDS-DMA kernel, several 64x64
     tiles per CU, one shape with a ragged M: small-integer entries keep every fp32 sum exact, so the result equals the float64 product."""

@@ -75,7 +75,7 @@ SWITCHES = [{}, {"T4K_GEMM_L32": "0"}, {"T4K_GEMM_DUAL_L32": "0"}, {"T4K_GEMM_L3
             {"T4K_GEMM_FULLK": "0"}, {"T4K_GEMM_FASTPRO": "0"}, {"T4K_GEMM_RAGGED_DMA": "0"}, {"T4K_GEMM_PLAIN_BIG": "0"}, {"T4K_GEMM_BIG_DMA": "0"},
             {"T4K_GEMM_BIG_FULLK": "0"}, {"T4K_GEMM_DUAL_FULL": "0"}, {"T4K_GEMM_DUAL_FULLK": "0"}, {"T4K_GEMM_SPLIT_DIV": "2"}, {"T4K_GEMM_S32_NW8": "0"},
             {"T4K_GEMM_S32_MAXK": "256"}, {"T4K_GEMM_DUAL_MAXK": "256"}, {"T4K_GEMM_DUAL32_MAXK": "128"}, {"T4K_HEAD_FOLD": "0"}, {"T4K_LINSMALL_GATE": "0"}, {"T4K_LINSMALL_COLS": "0"}, {"T4K_LINSMALL_COLS": "2"},
-            {"T4K_GEMM_PLAIN_PAIR": "0"}, {"T4K_GEMM_PLAIN128": "0"}, {"T4K_GEMM_PLAIN128": "2"}, {"T4K_GEMM_PLAIN128_RAGK": "0"}, {"T4K_GEMM_PLAIN128_BK32": "0"}, {"T4K_GEMM_PLAIN128_BK32": "2"}, {"T4K_GEMM_PLAIN_RAGK": "0"}, {"T4K_GEMM_PLAIN_RAGK": "1"}, {"T4K_GEMM_PLAIN_ANY": "0"}, {"T4K_GEMM_PLAIN_ANY": "1"}, {"T4K_GEMM_RAGGED_K": "0"}, {"T4K_GEMM_RAGGED_K": "2"}, {"T4K_GEMM_RAGGED_K": "2", "T4K_GEMM_S32": "0"}, {"T4K_GEMM_VARIANT": "21"}, {"T4K_GEMM_VARIANT": "37"}, {"T4K_GEMM_VARIANT": "61"}, {"T4K_GEMM_VARIANT": "5"}]
+            {"T4K_GEMM_PLAIN_PAIR": "0"}, {"T4K_GEMM_PLAIN128": "0"}, {"T4K_GEMM_PLAIN128": "2"}, {"T4K_GEMM_PLAIN128_RAGK": "0"}, {"T4K_GEMM_PLAIN128_BK32": "0"}, {"T4K_GEMM_PLAIN128_BK32": "2"}, {"T4K_GEMM_PLAIN256": "0"}, {"T4K_GEMM_PLAIN256": "2"}, {"T4K_GEMM_PLAIN_RAGK": "0"}, {"T4K_GEMM_PLAIN_RAGK": "1"}, {"T4K_GEMM_PLAIN_ANY": "0"}, {"T4K_GEMM_PLAIN_ANY": "1"}, {"T4K_GEMM_RAGGED_K": "0"}, {"T4K_GEMM_RAGGED_K": "2"}, {"T4K_GEMM_RAGGED_K": "2", "T4K_GEMM_S32": "0"}, {"T4K_GEMM_VARIANT": "21"}, {"T4K_GEMM_VARIANT": "37"}, {"T4K_GEMM_VARIANT": "61"}, {"T4K_GEMM_VARIANT": "5"}]
 
 
 def _run(tmp_path, env_extra):
