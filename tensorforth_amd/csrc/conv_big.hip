@@ -261,10 +261,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_ ==
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + (w * NJA + j) * 256) * 4));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vo[j]), "s"(srdX), "s"(la) : "memory");
         }
+        const unsigned sbu = __builtin_amdgcn_readfirstlane(sb4);       // wave-uniform by construction; the compiler cannot always prove it across the loop
 #pragma unroll
         for (int j = 0; j < NJB; j++) {
             const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * STAGE + BM * BK + (w * NJB + j) * 256) * 4));
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(offb[j]), "s"(srdF), "s"(la), "s"(sb4) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(offb[j]), "s"(srdF), "s"(la), "s"(sbu) : "memory");   // (s_nop 4: sbu may come fresh from a v_readfirstlane)
         }
     };
     f32x16 acc[2][NTW];
@@ -311,6 +312,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_ ==
     for (int b = 0; b < NTW; b++) asm volatile("" :: "v"(bias[b]));      // the bias has landed HERE as far as the compiler is concerned: no vmcnt(0) between the epilogue's stores
     if (nst > 1) fire(1);                                   // stage kt + 2 is requested right behind stage kt's closing barrier: its buffer is free from there on
     prep();
+    if constexpr (BK == 32) {
+        // two workgroups per CU = four waves per SIMD: a wave reads a chunk's fragments and multiplies them, the other three cover its LDS latency.  No second
+        // fragment set: with one the 128-wide forms spill, and a compiler-counted scratch reload inside this loop waits for vmcnt(0) - for the DMA of the next stage
+        int buf = 0;
+        for (int kt = 0; kt < nst; kt++) {
+            const float *a = lds + buf * STAGE, *b = a + BM * BK;
+#pragma unroll
+            for (int ci = 0; ci < NCG; ci++) {
+                rd(a, b, c0 + ci, ca, cbv);
+                mm(ca, cbv);
+                if (ci == 0 && kt > 0) { __builtin_amdgcn_sched_barrier(0); prep(); }  // the sources of stage kt + 2 (fired behind this stage's barrier), under the MFMAs just issued;
+            }                                                                          // stage 2's were worked out in front of the loop
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 2 < nst) fire(buf);
+            buf ^= 1;
+        }
+    } else {
     rd(lds, lds + BM * BK, c0, ca, cbv);
     int buf = 0;
     for (int kt = 0; kt < nst; kt++) {
@@ -350,6 +368,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_ ==
             }
         }
         buf = b1;
+    }
     }
     // the two k-groups meet in LDS, group 0 stores (bias: forward; fetched before the main loop).  Streaming stores: the tile is not read again by this launch
     // and a layer tensor of these sizes does not stay in the L2s for the next one (with plain stores the dirty lines of all tiles are written back at the END of
