@@ -822,6 +822,27 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BKP ==
                 for (int b = 0; b < NTW; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
     };
     float ca[2][4], cbv[NTW][4];
+    if constexpr (BKP == 32) {                              // two workgroups per CU = four waves per SIMD: read a chunk's fragments, multiply; no second fragment set (no scratch)
+        if (nst > 0) {
+            prep(); fire(0); prep();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (nst > 1) fire(1);
+            prep();
+        }
+        int buf = 0;
+        for (int kt = 0; kt < nst; kt++) {
+            const float *a = lds + buf * STAGE, *b = a + BM * BKP;
+#pragma unroll
+            for (int ci = 0; ci < NCG; ci++) {
+                rd(a, b, c0 + ci, ca, cbv);
+                mm(ca, cbv);
+                if (ci == 0 && kt > 0) { __builtin_amdgcn_sched_barrier(0); prep(); }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 2 < nst) fire(buf);
+            buf ^= 1;
+        }
+    } else {
     if (nst > 0) {
         prep(); fire(0); prep();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -866,6 +887,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BKP ==
             }
         }
         buf = b1;
+    }
     }
     // the two k-groups meet in LDS (the stage buffers are free now), group 0 writes the slab rows [slice][(ci K + ky) K + kx][co]
     __syncthreads();
