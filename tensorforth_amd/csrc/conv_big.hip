@@ -700,6 +700,19 @@ __global__ void __launch_bounds__(512) k_convbig_df8(Cd8 p) {
     // partial slab [slice][row = (ci*K+ky)*K+kx][co]  (the fold's layout, without a bias row)
     const int co = n0 + wn * 32 + l31;
     const long nrow = (long)p.C1 * KK;
+    // a wave's 32 rows are one tap (also with two taps per tile): whole blocks take a branch-free path - the 16 values read from LDS together, 32-bit offsets,
+    // stores back to back (a predicated block per element costs an LDS round trip, a branch and 64-bit address arithmetic each)
+    const int tpw = p.tp2 ? 2 * ts + wm : ts, ci0 = p.tp2 ? 0 : m0 + wm * 32;
+    if (tpw < KK && ci0 + 32 <= p.C1 && n0 + wn * 32 + 32 <= p.C0) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = (acc0[r] + acc1[r]) + lds[(w4 * 16 + r) * 64 + lane];
+        float *base = p.part + ((long)slice * nrow + ((long)ci0 * KK + tpw)) * p.C0 + co;
+        const int rs = KK * p.C0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) base[((r & 3) + 8 * (r >> 2) + 4 * h) * rs] = v[r];
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
