@@ -769,11 +769,21 @@ __global__ void __launch_bounds__(64 * NW) k_gemm_dual_l32(GemmP p1, GemmP p2, i
 
 // ---- classifier-head backward + the backward of the linear layer in front of it, ONE launch (t4k_mlp_head_bwd).
 // The head backward (loss preparation out -= target, dW2 | dB2, dX2 = dY2 W2 in place, mask multiply -> dY1) and the big layer's dW1 += dY1^T X1,
-// dX1 = dY1 W1 are dependent: the second needs dY1 [N][EA].  But dY1 is CHEAP to recompute - dY1[n, e] = mask[n, e] sum_j (P - T)[n, j] W2[j, e], EB = 10
-// terms - so every GEMM tile prepares the 32 rows of dY1 it multiplies with in LDS from P, T, W2 and the mask (all there before the launch) and the
-// two kernels stop depending on each other: the GEMM tiles (k_gemm_dual32's, A operand from LDS) and the column-sliced head workgroups
-// (linear_small.hip k_linsmall_bwd_cols, here as riders) run side by side.  The head riders still store dY1, dX2, dW2, dB2 - and dB1, the column sums of
-// the dY1 slice they have in hand.  The only shared write is `out -= target` over P: rider 0 stores it once EVERY workgroup has staged P and T (counter).
+// dX1 = dY1 W1 are dependent: the second needs dY1 [N][EA].  But dY1 is CHEAP to recompute - dY1[n, e] = mask[n, e] sum_j (P - T)[n, j] W2[j, e], EB <= 16
+// terms - so every GEMM tile prepares the 32 rows / columns of dY1 it multiplies with in LDS from P, T, W2 and the mask (all there before the launch) and
+// nothing waits for the head: GEMM tiles and the column-sliced head workgroups (k_linsmall_bwd_cols's body as riders) run side by side.  The riders store
+// dY1, dX2, dW2, dB2 and dB1 (the column sums of the dY1 slice they have in hand).  The only shared write is `out -= target` over P: a rider of its own
+// stores it once EVERY workgroup has its P and T values in registers (counter; off everybody's critical path).
+// Round 6 (k_head_bwd_l32): round 3's form of this launch (16.2 us) lost to two launches (7.0 + 6.0 us) because its tiles made three dependent memory round
+// trips in front of the GEMM and gathered the B operand row by row.  Here a tile workgroup
+//   1. issues the LDS-DMA of its B blocks (X1 or W1: 32 k x 32 columns per block, whole 128-byte runs, wave-private slots as gemm_s32_body<.., DMA>),
+//   2. requests P, T, W2 and the mask values it needs STRAIGHT INTO REGISTERS in MFMA operand layout - the same round trip as the DMA -
+//   3. multiplies (P - T) W2 on the matrix cores (ceil(EB / 2) v_mfma_f32_32x32x2_f32 per 32 x 32 block of dY1), applies the mask and leaves the block in LDS
+//      k-major with a pitch of 33 floats (conflict-free for the writes of either tile kind and for the fragment reads),
+//   4. one barrier, then the K loop proper: B fragments from the wave's DMA slots, A fragments from the dY1 tile, k-groups meet in LDS, epilogue as
+//      gemm_s32_body's (in-place dX1 behind the epoch-tagged arrival slots of the dW1 readers).
+// The tiles' dY1 comes from an MFMA sum, the riders' stored dY1 from the oracle's fmaf chain: the two differ by rounding only (1e-7 relative to the
+// largest term), far inside the 1e-4 bar of dW1 / dX1; every tensor the reference materialises is the riders' (bit-equal to the two-launch path).
 struct HeadBwd {
     const float *P, *T, *W2, *MASK;     // softmax output [N][EB], target, W2 [EB][EA], derivative mask of the layer between the linear layers [N][EA]
     float *X2, *DW2, *DB2, *Y1, *Y2;    // head input [N][EA] (receives dX2), gradients, dY1 tensor (= dX2 * mask), second copy of out - target
@@ -781,109 +791,286 @@ struct HeadBwd {
     int N, EA, EB, train, nwg; int *sync;
     const float *MSKB; float *Y1B;     // a second mask layer between the linear layers (`leakyrelu dropout`): dY1 = dX2 * MASK * MSKB, Y1 keeps the first product, Y1B the second
     MaskChain mc1;                      // mask multiplies behind the big layer's dX1 (the run in front of it), as linear_bwd_dual
+    const float *Z;                     // 4 KiB of zeros: source of DMA lanes past the K range / the matrix edge
 };
-template <int CB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_head_bwd_dual32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, HeadBwd hb) {
-    __shared__ float red[4 * 16 * 64];
-    extern __shared__ __attribute__((aligned(16))) float dyn[];       // tiles: d2 [N][EB] | w2 [EB][EA] | Ad (16-byte aligned offsets); riders: the cols layout
-    const int tid = threadIdx.x, N = hb.N, EA = hb.EA, EB = hb.EB, bx = blockIdx.x;
-    const int ntile = nb1 + t2;
-    if (bx < ntile) {
-        float *d2 = dyn, *w2 = d2 + ((N * EB + 3) & ~3), *Ad = w2 + ((EB * EA + 3) & ~3);
-        const bool first = bx < nb1;                                 // dW1 tile: rows e0..e0+31 of dY1^T, all n;  dX1 tile: rows n0..n0+31 of dY1, all e
-        const int tb = first ? bx : bx - nb1;
-        const int r0 = (first ? tb / p1.tiles_n : tb / p2.tiles_n) * 32;
-        auto pro = [&]() __attribute__((always_inline)) {
-        const int EAp = (EA + 3) & ~3, nel = first ? N * 32 : 32 * EAp;
-        constexpr int MQ = 16;                                       // mask values per thread fetched with the operands (N <= 128 rows or EAp <= 128 columns per pass; the rest in a second pass)
-        for (int i = tid; i < N * EB; i += 256) d2[i] = hb.P[i] - hb.T[i];
-        for (int i = tid; i < EB * EA; i += 256) w2[i] = hb.W2[i];
-        for (int base = 0; base < nel; base += MQ * 256) {
-            float mk[MQ];
+constexpr int HB_CW = 4;                // columns of the head's input per rider workgroup (k_linsmall_bwd_cols: LSC_CW)
+constexpr int HB_AP = 33;               // pitch of the dY1 tile in LDS
+// workgroups [0, a1): dW1 tiles (read X1, never wait) | [a1, a1 + nr): riders - the store rider, then the column riders | the rest: dX1 tiles (write X1 in place,
+// wait for the dW1 tiles of their column only).  slots == nullptr: a frozen layer (a1 == 0) - nothing to wait for.
+__global__ void __launch_bounds__(256) k_head_bwd_l32(GemmP p1, GemmP p2, int a1, int nr, unsigned *slots, unsigned *pslots, unsigned epoch, HeadBwd hb, int lab) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef __attribute__((address_space(3))) const float lds_f;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
+    const int N = hb.N, EA = hb.EA, EB = hb.EB, bx = blockIdx.x;
+#ifdef T4K_LAB
+#define HB_LAB(bit) (lab & (bit))
+#else
+#define HB_LAB(bit) 0
+#endif
+    if (bx < a1 || bx >= a1 + nr) {
+        // ---------------------------------------------------------------- GEMM tile
+        if (HB_LAB(2)) return;
+        const bool first = bx < a1;
+        const int tile = first ? bx : bx - a1 - nr, tiles_n = p1.tiles_n;        // both GEMMs have the same column tiling (E1)
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n, m0 = tm * 32, n0 = tn * 32;
+        const int M = first ? EA : N, Nn = p2.N, K = first ? N : EA;   // dW1: M = EA, K = N;  dX1: M = N, K = EA;  both: B = [K][Nn] rows (X1 / W1)
+        const float *pB = first ? p1.B : p2.B;
+        float *pO = first ? p1.O : p2.O;
+        const int nblk = (K + 31) >> 5;
+        const int b0 = w * nblk / 4, nb = (w + 1) * nblk / 4 - b0;   // this wave's k blocks (nblk <= 8: at most two, both requested up front)
+        float *Bs = lds + w * 2048, *Ad = lds + 8192;                // wave-private B slots (2 x 4 KiB; the wave's partial accumulators afterwards) | dY1 tile [nblk * 32][33]
+        {   // 1. B blocks by LDS-DMA
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)Bs;
+            const int i8 = lane >> 3, i7 = lane & 7;
+            const bool bcol = n0 + 4 * i7 < Nn;
+            const float *zsrc = hb.Z + 4 * i7;
 #pragma unroll
-            for (int q = 0; q < MQ; q++) {                           // the masks travel with P, T and W2: one memory round trip in front of the GEMM
-                const int i = base + tid + q * 256;
-                int n, e;
-                if (first) { n = i >> 5; e = min(r0 + (i & 31), EA - 1); } else { const int r = i / EAp; e = min(i - r * EAp, EA - 1); n = min(r0 + r, N - 1); }
-                const long zo = (long)min(n, N - 1) * EA + e;
-                mk[q] = i < nel ? (hb.MSKB ? hb.MASK[zo] * hb.MSKB[zo] : hb.MASK[zo]) : 0.f;
-            }
-            if (base == 0) {
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(hb.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // P and T are in LDS: `out -= target` may land as far as this workgroup is concerned
-            }
+            for (int s = 0; s < 2; s++) {
+                if (s < nb) {
+                    const int k0 = 32 * (b0 + s);
 #pragma unroll
-            for (int q = 0; q < MQ; q++) {
-                const int i = base + tid + q * 256;
-                if (i < nel) {
-                    int n, e; bool live = true;
-                    if (first) { n = i >> 5; e = min(r0 + (i & 31), EA - 1); }               // Ad[n][32]: k-major, as the [K][M] operand it replaces
-                    else { const int r = i / EAp; e = i - r * EAp; live = e < EA; e = min(e, EA - 1); n = min(r0 + r, N - 1); }   // Ad[32][EAp]: K-contiguous rows
-                    float a = 0.f;
-                    for (int j = 0; j < EB; j++) a = fmaf(d2[n * EB + j], w2[j * EA + e], a);
-                    Ad[i] = live ? a * mk[q] : 0.f;
+                    for (int j = 0; j < 4; j++) {
+                        const int r = 8 * j + i8;
+                        const float *sb = (k0 + r < K && bcol) ? pB + (long)(k0 + r) * Nn + n0 + 4 * i7 : zsrc;
+                        const unsigned la = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((s * 1024 + j * 256) * 4));
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sb), "s"(la) : "memory");
+                    }
                 }
             }
         }
-            __syncthreads();
-        };
-        if (first) gemm_s32_body<false, false, CB, 4, true>(p1, bx, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch, 0, nullptr, nullptr, Ad, 32, pro);
-        else       gemm_s32_body<true, false, CB, 4, true>(p2, bx - nb1, red, nullptr, slots ? 2 : 0, t1, t2, hb.mc1.d1 ? &hb.mc1 : nullptr, slots, epoch, 0, nullptr, nullptr, Ad, (EA + 3) & ~3, pro);
+        // epilogue operands, requested with everything else
+        const int gn = n0 + l31;
+        float oprev[4], mk1[4], mk2[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 4 * w + q, gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok = gm < M && gn < Nn;
+            const long z = (long)gm * Nn + gn;
+            oprev[q] = (first && ok) ? pO[z] : 0.f;
+            mk1[q] = (!first && hb.mc1.d1 && ok) ? hb.mc1.m1[z] : 0.f;
+            mk2[q] = (!first && hb.mc1.d2 && ok) ? hb.mc1.m2[z] : 0.f;
+        }
+        // 2. operands of the dY1 blocks this wave prepares (blocks w and w + 4 of the tile's k range), in MFMA layout
+        //    dW1 tile: block = 32 samples, the tile's 32 columns e of dY1;   dX1 tile: block = 32 columns e, the tile's 32 samples
+        float av[2][8], bv[2][8], mk[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int blk = w + 4 * t;
+            const int arow = first ? 32 * blk + l31 : m0 + l31;      // sample of this lane's A values (P - T)
+            const int bcl = first ? m0 + l31 : 32 * blk + l31;       // column e of this lane's B values (W2)
+            const bool on = blk < nblk, aok = on && arow < N, bok = on && bcl < EA;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int j = 2 * s + h;
+                const bool jk = j < EB;
+                if (t == 1 && !first)  av[t][s] = av[0][s];          // the same 32 samples for every column block
+                else av[t][s] = (aok && jk && !HB_LAB(8)) ? hb.P[(long)arow * EB + j] - hb.T[(long)arow * EB + j] : 0.f;
+                if (t == 1 && first)   bv[t][s] = bv[0][s];
+                else bv[t][s] = (bok && jk && !HB_LAB(8)) ? hb.W2[(long)j * EA + bcl] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ro = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n = first ? 32 * blk + ro : m0 + ro, e = first ? m0 + l31 : 32 * blk + l31;
+                const bool ok = on && n < N && e < EA;
+                const long zo = (long)n * EA + e;
+                mk[t][r] = (ok && !HB_LAB(64)) ? (hb.MSKB ? hb.MASK[zo] * hb.MSKB[zo] : hb.MASK[zo]) : 0.f;
+            }
+        }
+        // 3. dY1 blocks on the matrix cores -> LDS
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int blk = w + 4 * t;
+            if (blk < nblk) {
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; r++) d[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 8; s++) if (2 * s < EB) d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][s], bv[t][s], d, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int ro = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    Ad[first ? (32 * blk + ro) * HB_AP + l31 : (32 * blk + l31) * HB_AP + ro] = d[r] * mk[t][r];
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the wave's DMA blocks have landed (they were requested first)
+        const bool early = slots && a1 <= 128;                       // per-wave arrival slots: X1 is consumed as far as this wave is concerned
+        if (first && early && lane == 0) __hip_atomic_store(slots + 4 * tile + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0 && !HB_LAB(4)) __hip_atomic_store(pslots + bx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // P and T are in registers everywhere: `out -= target` may land as far as this workgroup is concerned
+        if (HB_LAB(16)) return;
+        // in-place dX1: the first look at the arrival slots of this column's dW1 tiles goes out here - its round trip passes under the K loop
+        const int gper = early ? 4 : 1, gslot = (a1 / tiles_n) * gper;
+        unsigned gbad = 0;
+        if (!first && slots && w == 0 && !HB_LAB(32)) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = lane + 64 * u;
+                if (i < gslot) { const int e0t = i / gper, ww = i - e0t * gper; gbad |= __hip_atomic_load(slots + gper * (e0t * tiles_n + tn) + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ epoch; }
+            }
+        }
+        if (first && slots && !early && tid == 0) __hip_atomic_store(slots + tile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // 4. K loop
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (s < nb) {
+                lds_f *b = (lds_f *)Bs + s * 1024, *a = (lds_f *)Ad + 32 * (b0 + s) * HB_AP;
+                float fa[4][4], fb[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { fa[c][j] = a[(8 * c + 4 * h + j) * HB_AP + l31]; fb[c][j] = b[(8 * c + 4 * h + j) * 32 + l31]; }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][2], fb[c][2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][3], fb[c][3], acc1, 0, 0, 0);
+                }
+            }
+        }
+        // the four k-groups meet in LDS (each wave's partial sums over its own, consumed, B slots)
+#pragma unroll
+        for (int r = 0; r < 16; r++) Bs[r * 64 + lane] = acc0[r] + acc1[r];
+        if (!first && slots && w == 0 && !HB_LAB(32) && !__all(gbad == 0)) {      // the dW1 tiles of this column have consumed X1 (see gemm_s32_body gate_mode 2); a1 <= 512 slots
+            for (int spin_it = 0;; spin_it++) {
+                if (spin_it > T4K_SPIN_MAX) { if (lane == 0 && g_spin_err_dev) __hip_atomic_store(g_spin_err_dev, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                unsigned bad = 0;
+#pragma unroll 4
+                for (int i = lane; i < gslot; i += 64) {
+                    const int e0t = i / gper, ww = i - e0t * gper;
+                    bad |= __hip_atomic_load(slots + gper * (e0t * tiles_n + tn) + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ epoch;
+                }
+                if (__all(bad == 0)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 4 * w + q, gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = lds[r * 64 + lane];
+#pragma unroll
+            for (int g = 1; g < 4; g++) v += lds[g * 2048 + r * 64 + lane];       // k-groups in order
+            if (gm < M && gn < Nn) {
+                const long z = (long)gm * Nn + gn;
+                if (first) pO[z] = v + oprev[q];                                  // dW1 accumulates (beta = 1)
+                else {
+                    pO[z] = v;
+                    if (hb.mc1.d1) { const float g1 = v * mk1[q]; hb.mc1.d1[z] = g1; if (hb.mc1.d2) hb.mc1.d2[z] = g1 * mk2[q]; }
+                }
+            }
+        }
         return;
     }
-    // ---- head riders: column slices of the head's input (see k_linsmall_bwd_cols)
-    constexpr int CW = 8;
-    const int cb = bx - ntile, c0 = cb * CW, cw = min(CW, EA - c0);
-    float *dys = dyn, *Ws = dys + N * EB, *Xs = Ws + EB * CW, *rd2 = Xs + N * CW;       // dY2 [N][EB], W2 slice [EB][CW], X2 slice [N][CW] (then dY1 slice), partial sums
-    for (int i = tid; i < N * EB; i += 256) dys[i] = hb.P[i] - hb.T[i];
-    for (int i = tid; i < EB * CW; i += 256) { const int j = i / CW, c = i - j * CW; Ws[i] = c < cw ? hb.W2[(long)j * EA + c0 + c] : 0.f; }
-    for (int i = tid; i < N * CW; i += 256) { const int n = i / CW, c = i - n * CW; Xs[i] = c < cw ? hb.X2[(long)n * EA + c0 + c] : 0.f; }
+    if (bx == a1) {
+        // ---------------------------------------------------------------- store rider: `out -= target` in place (+ its copy), once every other workgroup holds P and T
+        const int tot = N * EB;
+        for (int i = tid; i < tot; i += 256) lds[i] = hb.P[i] - hb.T[i];
+        if (w == 0 && !HB_LAB(4 | 1 | 2 | 16)) {         // (ablations that drop arrivals must drop the wait too)
+            // every other workgroup tags its slot once its P / T values sit in registers / LDS: plain stores to separate words (an arrival COUNTER serialised
+            // 270 agent-scope atomics on one address: +1.2 us on the launch), polled here with the 64 lanes' loads in flight together
+            for (int spin_it = 0;; spin_it++) {
+                if (spin_it > T4K_SPIN_MAX) { if (lane == 0 && g_spin_err_dev) __hip_atomic_store(g_spin_err_dev, 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                unsigned bad = 0;
+#pragma unroll 4
+                for (int i = lane; i < hb.nwg; i += 64) if (i != bx) bad |= __hip_atomic_load(pslots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ epoch;
+                if (__all(bad == 0)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        float *Pw = const_cast<float *>(hb.P);
+        for (int i = tid; i < tot; i += 256) { const float v = lds[i]; Pw[i] = v; if (hb.Y2) hb.Y2[i] = v; }
+        return;
+    }
+    // -------------------------------------------------------------------- column riders: k_linsmall_bwd_cols's slice of HB_CW columns of the head's input
+    if (HB_LAB(1)) return;
+    constexpr int CW = HB_CW, ZI = 8;
+    const int cb = bx - a1 - 1, c0 = cb * CW, cw = min(CW, EA - c0);
+    float *dys = lds, *Ws = dys + N * EB, *Xs = Ws + EB * CW, *red = Xs + N * CW;       // dY2 [N][EB], W2 slice [EB][CW], X2 slice [N][CW] (then the dY1 slice), partial sums [4][EB * CW] / [32][CW]
+    float mk[ZI], mkb[ZI];
+#pragma unroll
+    for (int k = 0; k < ZI; k++) {
+        const int z = tid + k * 256, n = z / CW, c = z - n * CW;
+        const bool ok = z < N * CW && c < cw;
+        const long o = (long)n * EA + c0 + c;
+        mk[k] = ok ? hb.MASK[o] : 0.f; mkb[k] = (ok && hb.MSKB) ? hb.MSKB[o] : 0.f;
+    }
+    {   // staging: every global load goes out before the first LDS store (one round trip)
+        constexpr int PRE = 6;
+        float pd[PRE], pt[PRE], px[PRE], pw = 0.f;
+#pragma unroll
+        for (int q = 0; q < PRE; q++) { const int i = tid + q * 256; const bool ok = i < N * EB; pd[q] = ok ? hb.P[i] : 0.f; pt[q] = ok ? hb.T[i] : 0.f; }
+        if (tid < EB * CW) { const int j = tid / CW, c = tid - j * CW; pw = c < cw ? hb.W2[(long)j * EA + c0 + c] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < PRE; q++) { const int i = tid + q * 256, n = i / CW, c = i - n * CW; px[q] = (hb.train && i < N * CW && c < cw) ? hb.X2[(long)n * EA + c0 + c] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < PRE; q++) { const int i = tid + q * 256; if (i < N * EB) dys[i] = pd[q] - pt[q]; }
+        if (tid < EB * CW) Ws[tid] = pw;
+        if (hb.train) {
+#pragma unroll
+            for (int q = 0; q < PRE; q++) { const int i = tid + q * 256; if (i < N * CW) Xs[i] = px[q]; }
+        }
+        for (int i = tid + PRE * 256; i < N * EB; i += 256) dys[i] = hb.P[i] - hb.T[i];
+        if (hb.train)
+            for (int i = tid + PRE * 256; i < N * CW; i += 256) { const int n = i / CW, c = i - n * CW; Xs[i] = c < cw ? hb.X2[(long)n * EA + c0 + c] : 0.f; }
+    }
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(hb.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int nout = EB * CW, G = min(4, 256 / nout);
+    if (tid == 0 && !HB_LAB(4)) __hip_atomic_store(pslots + bx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // P and the target are staged here
+    const int nout = EB * CW, G = min(4, 256 / nout);               // thread groups splitting the batch of one dW2 output (contiguous ranges, summed in order)
     float dwacc = 0.f;
-    if (hb.train && tid < nout * G) {                               // dW2[j, c0 + c]
+    if (hb.train && tid < nout * G) {
         const int g = tid / nout, t = tid - g * nout, j = t / CW, c = t - j * CW;
-        const int nb = (N + G - 1) / G, n0 = g * nb, n1 = min(N, n0 + nb);
+        const int nbt = (N + G - 1) / G, n0 = g * nbt, n1 = min(N, n0 + nbt);
 #pragma unroll 8
         for (int n = n0; n < n1; n++) dwacc = fmaf(dys[n * EB + j], Xs[n * CW + c], dwacc);
-        if (G > 1) rd2[g * nout + t] = dwacc;
+        if (G > 1) red[g * nout + t] = dwacc;
     }
-    __syncthreads();                                                 // X2 slice consumed: its place takes the dY1 slice
-    for (int z = tid; z < N * CW; z += 256) {                        // dX2[n, c0 + c] over X2 in place, dY1 = dX2 * mask
-        const int n = z / CW, c = z - n * CW;
-        float g1 = 0.f;
-        if (c < cw) {
+    __syncthreads();                                                 // the X2 slice is consumed: its place takes the dY1 slice
+    {
+        float g1v[ZI];
+#pragma unroll
+        for (int k = 0; k < ZI; k++) {                               // dX2[n, c0 + c] over X2 in place: fmaf chain ascending j (the oracle's order); dY1 = dX2 * mask
+            const int z = tid + k * 256, n = z / CW, c = z - n * CW;
+            g1v[k] = 0.f;
+            if (z >= N * CW || c >= cw) continue;
             float acc = 0.f;
             for (int j = 0; j < EB; j++) acc = fmaf(dys[n * EB + j], Ws[j * CW + c], acc);
             const long o = (long)n * EA + c0 + c;
             hb.X2[o] = acc;
-            g1 = acc * hb.MASK[o]; hb.Y1[o] = g1;
-            if (hb.MSKB) { g1 *= hb.MSKB[o]; hb.Y1B[o] = g1; }
+            float g1 = acc * mk[k]; hb.Y1[o] = g1;
+            if (hb.MSKB) { g1 *= mkb[k]; hb.Y1B[o] = g1; }
+            g1v[k] = g1;
         }
-        Xs[z] = g1;
+#pragma unroll
+        for (int k = 0; k < ZI; k++) { const int z = tid + k * 256; if (z < N * CW) Xs[z] = g1v[k]; }
     }
     __syncthreads();
     if (hb.train) {
         if (tid < nout) {
             const int j = tid / CW, c = tid - j * CW;
             float a = dwacc;
-            for (int g = 1; g < G; g++) a += rd2[g * nout + tid];
+            for (int g = 1; g < G; g++) a += red[g * nout + tid];
             if (c < cw) hb.DW2[(long)j * EA + c0 + c] += a;
         }
-        __syncthreads();                                             // rd2 is free again
-        {   // dB1[c0 + c] = sum_n dY1[n, c0 + c] (k_dlinear_db nmath.cu:274-280): 32 row groups per column, then the groups in order
-            const int c = tid & (CW - 1), g = tid >> 3;
+        __syncthreads();                                             // red is free again
+        {   // dB1[c0 + c] = sum_n dY1[n, c0 + c] (k_dlinear_db nmath.cu:274-280): 64 row groups per column, then the groups in order
+            const int c = tid & (CW - 1), g = tid >> 2;
             float b = 0.f;
 #pragma unroll 4
-            for (int n = g; n < N; n += 32) b += Xs[n * CW + c];
-            rd2[g * CW + c] = b;
+            for (int n = g; n < N; n += 64) b += Xs[n * CW + c];
+            red[g * CW + c] = b;
         }
         __syncthreads();
         if (tid < CW) {
             float b = 0.f;
-#pragma unroll
-            for (int g = 0; g < 32; g++) b += rd2[g * CW + tid];
+#pragma unroll 8
+            for (int g = 0; g < 64; g++) b += red[g * CW + tid];
             if (tid < cw) hb.DB1[c0 + tid] += b;
         }
         if (cb == 0) {                                               // dB2[j] = sum_n dY2[n, j]: 16 row groups per output
@@ -894,24 +1081,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
 #pragma unroll 4
                 for (int n = g; n < N; n += 16) b += dys[n * EB + j];
             }
-            rd2[g * 16 + j] = b;
+            red[g * 16 + j] = b;
             __syncthreads();
             if (tid < EB) {
                 float t = 0.f;
 #pragma unroll
-                for (int g2 = 0; g2 < 16; g2++) t += rd2[g2 * 16 + tid];
+                for (int g2 = 0; g2 < 16; g2++) t += red[g2 * 16 + tid];
                 hb.DB2[tid] += t;
             }
         }
-    }
-    if (cb == 0) {                                                   // `out -= target` in place (+ its copy), once every workgroup has read out / target
-        if (tid == 0) {
-            T4K_SPIN_WAIT(__hip_atomic_load(hb.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hb.nwg, 8);
-            __hip_atomic_store(hb.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        float *Pw = const_cast<float *>(hb.P);
-        for (int i = tid; i < N * EB; i += 256) { Pw[i] = dys[i]; if (hb.Y2) hb.Y2[i] = dys[i]; }
     }
 }
 
@@ -2129,7 +2307,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             const MaskChain mc32 = mcp ? *mcp : MaskChain{nullptr, nullptr, nullptr, nullptr};
             // arrival slots: ints [512, 1024) of the stream's gate block; the epoch is this stream's launch count (never 0, slots cleared when it wraps)
             unsigned *slots = reinterpret_cast<unsigned *>(gate_for(hs, 0)) + 512;
-            const unsigned epoch = next_slot_epoch(hs, slots);     // the lane's ONE counter, shared with k_head_bwd_dual32 (t4k_common.h)
+            const unsigned epoch = next_slot_epoch(hs, slots);     // the lane's ONE counter, shared with k_head_bwd_l32 (t4k_common.h)
             static int l32d = -1; if (l32d < 0) { const char *e = getenv("T4K_GEMM_DUAL_L32"); l32d = e ? atoi(e) : 1; }
             if (l32d && g.d_zero && N <= 1024 && E0 <= 1024 && (a1 > 128 || (N <= 512 && E0 <= 512))) {   // coalesced operand blocks through LDS-DMA; a wave walks at most four 32-deep blocks
                 q1.Z = q2.Z = g.d_zero;
@@ -2630,20 +2808,26 @@ int t4k_linear_block_bwd(const float *X, const float *W, float *DY, const float 
     return t4k_poolblock_bwd(DX, XRUN, blk, N, 1, 1, 1, 1, E1, s);
 }
 
-// Classifier-head backward AND the backward of the linear layer in front of it in ONE launch (k_head_bwd_dual32): what
+// Classifier-head backward AND the backward of the linear layer in front of it in ONE launch (k_head_bwd_l32): what
 // t4k_loss_linear_bwd(X2, W2, P, TGT, Y2, X2, MASK, Y1, DW2, DB2, N, EB, EA, 1) followed by t4k_linear_bwd(X1, W1, Y1, X1, DW1, DB1, N, EA, E1, 1)
 // compute (backprop.cu:103-121, 226-254; gradients accumulate), for a training pass with the in-place convention.  T4K_ERR_UNSUPPORTED when the shapes
 // do not qualify - the caller then makes the two calls.
+static size_t head_bwd_lds(int N, int EA, int EB) {                // dynamic LDS of k_head_bwd_l32: the larger of a tile's and a rider's
+    const size_t kd = (size_t)((std::max(N, EA) + 31) / 32) * 32;
+    const size_t lt = 8192 + kd * HB_AP, lr = (size_t)N * EB + (size_t)EB * HB_CW + (size_t)N * HB_CW + 256;
+    return sizeof(float) * std::max(std::max(lt, lr), (size_t)N * EB);
+}
 int t4k_mlp_head_bwd_ok(int N, int E1, int EA, int EB) {
     if (!st().ready) return 0;
     static int on = -1; if (on < 0) { const char *e = getenv("T4K_HEAD_BWD"); on = e ? atoi(e) : 1; }
-    if (!on || st().capturing || !st().d_sync || !dual_on()) return 0;
+    if (!on || st().capturing || !st().d_sync || !st().d_zero || !dual_on()) return 0;
     if (N < 1 || N > 256 || EA < 4 || EA > 256 || (EA & 3) || EB < 1 || EB > 16 || E1 < 4 || (E1 & 3)) return 0;
     auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
-    const long a1 = t32(EA, E1), a2 = t32(N, E1), nc = (EA + 7) / 8;
-    static int per_cu = -1;                                       // resident workgroups per CU at the largest LDS request (48 KiB dynamic + 16 KiB static)
-    if (per_cu < 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_head_bwd_dual32<8>, 256, 48 * 1024) != hipSuccess || nb < 1) nb = 1; per_cu = nb; }
-    return (a1 + a2 + nc <= (long)per_cu * st().cu_count - 32 && a1 <= 512) ? 1 : 0;      // every workgroup resident (the in-place gate and the target store spin)
+    const long a1 = t32(EA, E1), a2 = t32(N, E1), nr = 1 + (EA + HB_CW - 1) / HB_CW;
+    const size_t lds = head_bwd_lds(N, EA, EB);
+    int nb = 0;                                                   // resident workgroups per CU at this launch's LDS request
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_head_bwd_l32, 256, lds) != hipSuccess || nb < 1) return 0;
+    return (a1 + a2 + nr <= (long)nb * st().cu_count - 32 && a1 <= 512 && a1 + a2 + nr <= 768) ? 1 : 0;      // every workgroup resident (the in-place gate and the target store spin); 768 per-workgroup slots
 }
 static int head_bwd_launch(float *X2, const float *W2, float *P, const float *TGT, float *Y2, const MaskChain &mc2, float *DW2, float *DB2,
                            float *X1, const float *W1, const MaskChain &mc1, float *DW1, float *DB1, int N, int E1, int EA, int EB, bool train, hipStream_t hs, const char *who) {
@@ -2653,29 +2837,29 @@ static int head_bwd_launch(float *X2, const float *W2, float *P, const float *TG
         return fail(T4K_ERR_UNSUPPORTED, "%s: shapes do not qualify (t4k_mlp_head_bwd_ok)", who);
     State &g = st();
     auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
-    const long a1 = train ? t32(EA, E1) : 0, a2 = t32(N, E1), nc = (EA + 7) / 8;
+    const long a1 = train ? t32(EA, E1) : 0, a2 = t32(N, E1), nr = 1 + (EA + HB_CW - 1) / HB_CW;
     GemmP q1, q2;
     auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
         p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
         p.tiles_m = (M + 31) / 32; p.tiles_n = (Nn + 31) / 32; p.kchunk = K; p.nsplit = 1;
-        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0; p.xmap = 0; p.Z = nullptr;
+        p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0; p.xmap = 0; p.Z = g.d_zero;
     };
-    fill32(q1, DY1, X1, DW1, EA, E1, N, 1.0f);                    // dW1 += dY1^T X1   (A comes from LDS: the pointer is not read)
+    fill32(q1, DY1, X1, DW1, EA, E1, N, 1.0f);                    // dW1 += dY1^T X1   (A is prepared in LDS: the pointer is not read)
     fill32(q2, DY1, W1, X1, N, E1, EA, 0.0f);                     // dX1 = dY1 W1, over X1 (backprop.cu:240)
-    unsigned *slots = nullptr; unsigned epoch = 0;
-    if (train) {                                                  // arrival slots of the in-place dX (as linear_bwd_dual); a frozen layer has no dW readers to wait for
-        slots = reinterpret_cast<unsigned *>(gate) + 512;
-        epoch = next_slot_epoch(hs, slots);                       // the lane's ONE counter, shared with k_gemm_dual32
-    }
-    HeadBwd hb = { P, TGT, W2, mc2.m1, X2, DW2, DB2, mc2.d1, Y2, DB1, N, EA, EB, train ? 1 : 0, (int)(a1 + a2 + nc), gate, mc2.m2, mc2.d2, mc1 };
-    const int EAp = (EA + 3) & ~3;
-    const size_t lt = (size_t)((N * EB + 3) & ~3) + (size_t)((EB * EA + 3) & ~3) + (size_t)std::max(N * 32, 32 * EAp);
-    const size_t lr = (size_t)N * EB + (size_t)EB * 8 + (size_t)N * 8 + 256;
-    const size_t lds = sizeof(float) * std::max(lt, lr);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_dual32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); attr = true; }
-    if (lds > 48 * 1024) return fail(T4K_ERR_UNSUPPORTED, "%s: %zu bytes of LDS", who, lds);
-    T4K_LAUNCH(k_head_bwd_dual32<8>, dim3((unsigned)(a1 + a2 + nc)), dim3(256), lds, hs, q1, q2, (int)a1, (int)a1, (int)a2, slots, epoch, hb);
+    // arrival slots, all tagged with the lane's ONE epoch counter (shared with k_gemm_dual32): ints [512, 1024) of the lane's gate block for the in-place dX
+    // (as linear_bwd_dual; a frozen layer has no dW readers to wait for), ints [1280, 2048) one per workgroup for the `out -= target` store
+    unsigned *slots = reinterpret_cast<unsigned *>(gate) + 512, *pslots = reinterpret_cast<unsigned *>(gate) + 1280;
+    const unsigned epoch = next_slot_epoch(hs, slots);
+    if (!train) slots = nullptr;
+    HeadBwd hb = { P, TGT, W2, mc2.m1, X2, DW2, DB2, mc2.d1, Y2, DB1, N, EA, EB, train ? 1 : 0, (int)(a1 + a2 + nr), gate, mc2.m2, mc2.d2, mc1, g.d_zero };
+    const size_t lds = head_bwd_lds(N, EA, EB);
+    static size_t attr = 0;
+    if (lds > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_head_bwd_l32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+    int lab = 0;
+#ifdef T4K_LAB
+    { const char *e = getenv("T4K_HB_LAB"); lab = e ? atoi(e) : 0; }       // timing ablations (wrong results): see the kernel's HB_LAB bits
+#endif
+    T4K_LAUNCH(k_head_bwd_l32, dim3((unsigned)(a1 + a2 + nr)), dim3(256), lds, hs, q1, q2, (int)a1, (int)nr, slots, pslots, epoch, hb, lab);
     T4K_LAUNCH_CHECK();
     return T4K_OK;
 }

@@ -35,7 +35,7 @@ struct State {
     struct Lane { hipStream_t s; void *ws; } lane[8] = {};   // per-stream workspaces for t4k_stream_create()d streams
     int         n_lane  = 0;
     float      *d_zero  = nullptr;     // 4 KiB of zeros, never written: the source of LDS-DMA lanes whose operand row lies outside the tensor (conv_big.hip)
-    int        *d_sync  = nullptr;     // 32768 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags, [8192,32768) per-stream arrival gates (gate_for / flags_for; ints [512,1024) of a stream's block are the epoch slots of k_gemm_dual32)
+    int        *d_sync  = nullptr;     // 32768 zeroed, self re-arming ints: [0,4096) pair-mode GEMM tickets/flags, [8192,32768) per-stream arrival gates (gate_for / flags_for; ints [512,1024) of a stream's block are the epoch slots of k_gemm_dual32, [1280,2048) the per-workgroup slots of k_head_bwd_l32)
     int        *spin_err = nullptr;   // pinned, device-visible error word of the inter-workgroup waits (spin_check)
     int         cu_count = 256;
     unsigned    slot_epoch[16] = {};  // per stream lane: launch count of the kernels that tag the arrival slots (next_slot_epoch)
@@ -87,7 +87,7 @@ inline int *flags_for(const void *s) { int *g0 = gate_for(s, 0); return g0 ? g0 
 inline unsigned next_slot_epoch(hipStream_t hs, unsigned *slots) {
     const int li = lane_of(hs);
     unsigned &e = st().slot_epoch[(li >= 0 && li < 15) ? li : 15];
-    if (++e == 0) { (void)hipMemsetAsync(slots, 0, 512 * sizeof(unsigned), hs); e = 1; }
+    if (++e == 0) { (void)hipMemsetAsync(slots, 0, 1536 * sizeof(unsigned), hs); e = 1; }   // ints [512, 2048) of the block: the dual launches' slots, the broadcast flags (zero between launches anyway), k_head_bwd_l32's per-workgroup slots
     return e;
 }
 inline float *ws_for(const void *s) {            // accepts a t4k_stream_t or an already resolved hipStream_t

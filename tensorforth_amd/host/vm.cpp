@@ -56,7 +56,7 @@ void VM::add(const char *name, std::function<void()> f, bool immd) {
     // a built-in defined again (the tensor / nn vocabularies redefine `@ max min relu tanh sigmoid normalize flatten save load boot`) REPLACES the entry in
     // place, as MMU::add_word does (mmu.h:68-93: "*** redefined"): dictionary indices - what `'` pushes, what mstat counts - stay the reference's.  The
     // replaced body stays callable by the new one (shadow_).
-    if (const int w = find(name)) { shadow_[name] = std::move(dict_[w].xt); dict_[w].xt = std::move(f); dict_[w].immd = immd; return; }
+    if (const int w = find(name)) { shadow_[name].push_back(std::move(dict_[w].xt)); dict_[w].xt = std::move(f); dict_[w].immd = immd; return; }
     Word w; w.name = name; w.immd = immd; w.xt = std::move(f); dict_.push_back(std::move(w));
 }
 void VM::add_cell(uint32_t v) { if (here_ + 4 <= PMEM_SZ) { set_cell(here_, v); here_ += 4; } else pstr("pmem full\n"); }
@@ -496,7 +496,8 @@ void VM::init_core() {
     });
     CODE("forget", [this] {
         const char *n = fetch(); int w = n ? find(n) : 0; if (!w) return;
-        int b = user0_ + 1; if (w < b) w = b;                 // (the reference clears from its eForth `boot` entry on, vocabularies and all: eforth.cpp:504-506)
+        int b = user0_ + 1; if (w < b) w = b;
+        if (w >= (int)dict_.size()) return;                   // a built-in with no user word defined yet: nothing to clear                 // (the reference clears from its eForth `boot` entry on, vocabularies and all: eforth.cpp:504-506)
         if (dict_[w].udf) here_ = dict_[w].pfa - (uint32_t)dict_[w].name.size();   // MMU::clear mmu.h:95-98 (name length, unaligned)
         dict_.resize(w);
     });

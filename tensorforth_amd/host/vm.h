@@ -36,7 +36,7 @@ public:
 private:
     static constexpr int PMEM_SZ = 48 * 1024;
     std::vector<Word> dict_;
-    std::map<std::string, std::function<void()>> shadow_;   // bodies replaced by a redefinition of a built-in (VM::add)
+    std::map<std::string, std::vector<std::function<void()>>> shadow_;   // bodies replaced by redefinitions of a built-in (VM::add), oldest first: a redefining body calls the one it replaced by its INDEX (a look-up of "the latest" would find itself after a third definition)
     int user0_ = 0;                           // index of the `User::` marker: user words start behind it
     std::vector<DU> ss_, rs_;
     DU tos_ = -1.0f;

@@ -517,11 +517,12 @@ void VM::init_nn() {
         hold_begin(); hold_ = true;                      // syscall(OP_NSAVE / OP_NLOAD), netvm.cpp:148-152
         if (save) model_save(MTOS(), fn); else model_load(MTOS(), fn);
     };
-    CODE("save", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(true); else { auto it = shadow_.find("save"); if (it != shadow_.end()) it->second(); } });   // a tensor: the tensor vocabulary's word
-    CODE("load", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(false); else { auto it = shadow_.find("load"); if (it != shadow_.end()) it->second(); } });
+    CODE("save", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(true); else { auto it = shadow_.find("save"); if (it != shadow_.end() && !it->second.empty()) it->second[0](); } });   // a tensor: the tensor vocabulary's word (the FIRST body this name had)
+    CODE("load", [this, pickle] { if (is_m(SS(-2)) || (SP() > 2 && is_m(SS(-3)))) pickle(false); else { auto it = shadow_.find("load"); if (it != shadow_.end() && !it->second.empty()) it->second[0](); } });
     CODE("\nUser::", [] {});
     const int user0 = (int)dict_.size() - 1; user0_ = user0;
-    CODE("boot", [this, user0] { if ((int)dict_.size() > user0 + 1) { if (dict_[user0 + 1].udf) here_ = dict_[user0 + 1].pfa; dict_.resize(user0 + 1); } });
+    CODE("boot", [this, user0] {   // mmu.clear(FIND("boot") + 1), eforth.cpp:420: the same pfa - strlen(name) as forget (mmu.h:95-98)
+         if ((int)dict_.size() > user0 + 1) { if (dict_[user0 + 1].udf) here_ = dict_[user0 + 1].pfa - (uint32_t)dict_[user0 + 1].name.size(); dict_.resize(user0 + 1); } });
 }
 
 } // namespace t4
