@@ -337,7 +337,9 @@ def main():
     k.lib.t4k_conv_stack_stats.restype = None
     k.lib.t4k_conv_stack_stats(ctypes.byref(cj), ctypes.byref(cd), ctypes.byref(cf))
     stack_mode = "off" if (cj.value + cd.value == 0) else ("jit" if cj.value else "prebuilt")
-    want = {"nn_f": 5, "nn_c": 6}[args.net] + (1 if (dp and native and not xchg) else 0)    # nn_f: cs_fwd(+head), head backward, linear backward (dW || dX), cs_bwd_b, optimizer (+ fold [+ exchange]); with RCCL between them the fold keeps its launch.  nn_c (one conv stage, relu head): single-stage stack forward with the head, head backward (2 launches), linear backward, cs_bwd_b, optimizer
+    want = {"nn_f": 4, "nn_c": 6}[args.net] + (1 if (dp and native and not xchg) else 0)    # nn_f: cs_fwd(+head), head backward with the linear backward in front of it (k_head_bwd_l32: riders + dW || dX tiles), cs_bwd_b, optimizer (+ fold [+ exchange]); with RCCL between them the fold keeps its launch.  nn_c (one conv stage, relu head): single-stage stack forward with the head, head backward (2 launches), linear backward, cs_bwd_b, optimizer
+    if N > 256:
+        want += 1                                              # the one-launch head backward takes batches up to 256 per GPU; larger ones the column-stripe head + the dual GEMM
     if N > 512:
         want += 3                                              # the column-stripe head backward holds the batch in LDS (N <= 512): larger batches take the gated head kernels (3 more launches)
     if not args.allow_fallback and os.environ.get("T4_STACK", "1") != "0" and (stack_mode == "off" or cf.value or launches > want + 0.01):

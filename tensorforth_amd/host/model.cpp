@@ -101,7 +101,7 @@ void (*Model::grad_hook)(int, long, long, void *) = nullptr;
 void *Model::grad_hook_user = nullptr;
 bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
 bool Model::use_stack  = getenv("T4_STACK") ? atoi(getenv("T4_STACK")) != 0 : true;
-bool Model::use_head_bwd = getenv("T4_HEAD_BWD") ? atoi(getenv("T4_HEAD_BWD")) != 0 : false;    // T4_HEAD_BWD=1: classifier-head backward and the linear layer in front of it in ONE launch (round 3's k_head_bwd_dual32, 16.2 us; round 4's separate launches - head on column stripes + dual GEMM on LDS-DMA blocks - take 9.4 + 5.6 us)
+bool Model::use_head_bwd = getenv("T4_HEAD_BWD") ? atoi(getenv("T4_HEAD_BWD")) != 0 : true;    // classifier-head backward and the linear layer in front of it in ONE launch (round 6: k_head_bwd_l32, 9.7 us; T4_HEAD_BWD=0: head on column stripes + dual GEMM, 6.9 + 5.6 us)
 bool Model::use_stack_head = getenv("T4_STACK_HEAD") ? atoi(getenv("T4_STACK_HEAD")) != 0 : true;   // T4_STACK_HEAD=0: the classifier head behind a conv stack keeps its own launches
 bool Model::use_lazy_dx0 = getenv("T4_LAZY_DX0") ? atoi(getenv("T4_LAZY_DX0")) != 0 : true;
 bool Model::use_opt_fold = getenv("T4_OPT_FOLD") ? atoi(getenv("T4_OPT_FOLD")) != 0 : true;   // T4_OPT_FOLD=0: the conv stack's partial fold keeps its own launch behind the backward

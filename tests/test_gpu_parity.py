@@ -775,7 +775,7 @@ def test_loss_prep_folded_into_linear_backward(t4k, dev, oracle, N, E0, E1, mask
         if train: assert rel(dev.down(dDW), DWr) < RTOL and rel(dev.down(dDB), DBr) < RTOL
 
 
-@pytest.mark.parametrize("N,E1,EA,EB", [(128, 980, 100, 10), (64, 512, 64, 16), (37, 260, 52, 3), (256, 1024, 128, 10)])
+@pytest.mark.parametrize("N,E1,EA,EB", [(128, 980, 100, 10), (64, 512, 64, 16), (37, 260, 52, 3), (256, 1024, 128, 10), (160, 256, 64, 10), (96, 132, 200, 7)])
 def test_head_backward_and_the_linear_layer_in_front_in_one_launch(t4k, dev, oracle, N, E1, EA, EB):
     """t4k_mlp_head_bwd == t4k_loss_linear_bwd (head: out -= target, dW2 | dB2, dX2 in place, mask multiply -> dY1) followed by t4k_linear_bwd
     (dW1 | dB1, dX1 in place) of the oracle: the GEMM tiles recompute their rows of dY1 instead of waiting for the head, so every tensor both
