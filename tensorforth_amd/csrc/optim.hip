@@ -161,12 +161,31 @@ __global__ void __launch_bounds__(1024) k_opt_step(int kind, const t4k_param_rec
     __shared__ CsFoldSm sm;
     const bool mom = !(fabsf(b1) < DU_EPS);
     if ((int)blockIdx.x < nfold) {
+        // the parameter, its gradient and moments are requested BEFORE the partial rows are summed: behind the fold they were a second, dependent memory
+        // round trip on the launch's longest path (round 6)
+        const int blk = cs_fold_block(blockIdx.x, nfold), e = blk * 16 + (threadIdx.x & 15);
+        int q0 = 0, k0 = 0; bool has = false;
+#pragma unroll
+        for (int t = 0; t < 6; t++) if (t < fa.nseg && e >= fa.seg[t].start && e < fa.seg[t].start + fa.seg[t].n) { k0 = e - fa.seg[t].start; q0 = t; has = true; }
+        float g0 = 0.f, d0 = 0.f, m0 = 0.f, v0 = 0.f;
+        if (has && threadIdx.x < 16) {
+            const t4k_param_rec &r = fr.r[q0];
+            g0 = r.G[k0]; d0 = fa.seg[q0].dst[k0];
+            if (kind != 0 || mom) m0 = r.M[k0];
+            if (kind != 0) v0 = r.V[k0];
+        }
         float v; int q, k;
-        if (cs_fold16(fa, cs_fold_block(blockIdx.x, nfold), sm, v, q, k)) {
-            float dg = fa.seg[q].dst[k] + v;
+        if (cs_fold16(fa, blk, sm, v, q, k)) {
+            float dg = d0 + v;
             bool ok = true;
             if (XCHG) { const long z = (long)(fa.seg[q].dst - slab) + k; xchg_push(xd, z, dg); dg = xchg_sum(xd, z, dg, g_spin_err_dev, ok); }
-            if (ok) opt1(kind, fr.r[q], k, dg, lr, b1, b2, wd, mom, keep_src, keep_dst);
+            if (ok) {
+                const t4k_param_rec &r = fr.r[q];
+                if (keep_src && r.G == keep_src) keep_dst[k] = g0;
+                if (kind == 0) { sgd1(g0, dg, m0, r.Nw, lr, b1, mom); if (mom) r.M[k] = m0; }
+                else { if (kind == 1) adam1(g0, dg, m0, v0, lr, b1, b2); else adamw1(g0, dg, m0, v0, lr, b1, b2, wd); r.M[k] = m0; r.V[k] = v0; }
+                r.G[k] = g0; r.DG[k] = 0.f;
+            }
         }
         return;
     }
