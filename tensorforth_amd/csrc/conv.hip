@@ -714,10 +714,10 @@ template <int CO>
 void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, float *DX, float *DX2, const float *F,
                         int N, int H0, int W0, int C0, int H1, int W1, FoldArgs fa) {
     const long npix = (long)N * H1 * W1;
-    static int wide = -1; if (wide < 0) { const char *e = getenv("T4K_DX_WIDE"); wide = e ? atoi(e) : 1; }
+    static const int wide = T4K_LAB_ENV("T4K_DX_WIDE", 1);
     if (wide && K == 3 && S == 1 && P == 1 && (C0 == 32 || C0 == 64 || C0 == 128) && aligned16(DO) && aligned16(F)) {
         const int ppb = 4 * (64 / (C0 / 4));
-        static int wpc = -1; if (wpc < 0) { const char *e = getenv("T4K_DX_WIDE_WPC"); wpc = e ? atoi(e) : 8; }
+        static const int wpc = T4K_LAB_ENV("T4K_DX_WIDE_WPC", 8);
         long gw = (npix + ppb - 1) / ppb; if (gw > (long)st().cu_count * wpc) gw = (long)st().cu_count * wpc;   // the weights are loaded once per workgroup
         const dim3 gg((unsigned)gw + fa.nfold), bb(256);
         if (C0 == 32)      T4K_LAUNCH((k_conv_dx_wide<CO, 8>),  gg, bb, 0, hs, DO, DX, DX2, F, N, H0, W0, H1, W1, fa);
@@ -735,12 +735,12 @@ void launch_conv_dx_few(int K, int S, int P, hipStream_t hs, const float *DO, fl
     }
 }
 
-bool conv_block_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_BLOCK"); v = e ? atoi(e) : 1; } return v != 0; }
-bool conv_big_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_BIG"); v = e ? atoi(e) : 1; } return v != 0; }
-bool conv_few_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_CONV_FEW"); v = e ? atoi(e) : 1; } return v != 0; }
+bool conv_block_on() { static const int v = T4K_LAB_ENV("T4K_CONV_BLOCK", 1); return v != 0; }
+bool conv_big_on() { static const int v = T4K_LAB_ENV("T4K_CONV_BIG", 1); return v != 0; }
+bool conv_few_on() { static const int v = T4K_LAB_ENV("T4K_CONV_FEW", 1); return v != 0; }
 // two waves per tile when the layer is small enough to leave SIMDs empty and has enough k-work to split
 int conv_gemm_ksplit(long npix, int Cout, int Cin, int K) {
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_KSPLIT"); on = e ? atoi(e) : 1; }
+    static const int on = T4K_LAB_ENV("T4K_CONV_KSPLIT", 1);
     const long waves = ((npix + 31) / 32) * ((Cout + 31) / 32);
     return (on && waves < 1536 && ((Cin + 1) / 2) * K * K >= 18) ? 2 : 1;
 }
@@ -838,7 +838,7 @@ int t4k_conv2d_bn_fwd(const float *I, float *ICOPY, float *Y, const float *F, co
                       float *O, float *XH, const float *W, const float *B, float *stat_dev, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!O || !XH || !W || !B || !stat_dev) return fail(T4K_ERR_ARG, "t4k_conv2d_bn_fwd: null batch-norm tensor");
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_BN_RIDER"); on = e ? atoi(e) : 1; }
+    static const int on = T4K_LAB_ENV("T4K_CONV_BN_RIDER", 1);
     const bool rider = on && !(st().bn_sync && t4k_comm_world() > 0);                // synchronised statistics go through the all-reduce path of t4k_batchnorm_fwd
     int chunks = 0;
     int rc = conv2d_fwd_impl(I, ICOPY, Y, F, Bc, N, H1, W1, C1, H0, W0, C0, K, S, P, rider ? ws_for(s) : nullptr, st().ws_bytes / 8, &chunks, s);
@@ -856,7 +856,7 @@ int t4k_conv2d_bn_block_fwd(const float *I, float *ICOPY, float *Y, const float 
                             const t4k_poolblock *blk, int Hq, int Wq, t4k_stream_t s) {
     T4K_REQUIRE_INIT();
     if (!O || !XH || !W || !B || !stat_dev || !blk) return fail(T4K_ERR_ARG, "t4k_conv2d_bn_block_fwd: null tensor");
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_BN_RIDER"); on = e ? atoi(e) : 1; }
+    static const int on = T4K_LAB_ENV("T4K_CONV_BN_RIDER", 1);
     const bool rider = on && !(st().bn_sync && t4k_comm_world() > 0);
     int chunks = 0;
     int rc = conv2d_fwd_impl(I, ICOPY, Y, F, Bc, N, H1, W1, C1, H0, W0, C0, K, S, P, rider ? ws_for(s) : nullptr, st().ws_bytes / 8, &chunks, s);
@@ -943,7 +943,7 @@ int t4k_conv2d_bwd2(const float *I, const float *DO, float *DX, float *DX2, cons
         // enough slices that ~2000 waves are in flight (each wave then issues only a few batches of loads) without
         // inflating the partial slab the fold has to read: 512 workgroups in total across the (tap, c0) tiles
         const int tiles = ((nrow1 + 31) / 32) * ((C0 + 31) / 32);
-        static int dfwg = -1; if (dfwg < 0) { const char *e = getenv("T4K_CONV_DF_WG"); dfwg = e ? atoi(e) : 512; if (dfwg < 1) dfwg = 1; }
+        static const int dfwg = std::max(1, T4K_LAB_ENV("T4K_CONV_DF_WG", 512));
         int nslice = (dfwg + tiles - 1) / tiles; if (nslice > (rows + 3) / 4) nslice = (rows + 3) / 4; if (nslice < 1) nslice = 1;
         while (nslice > 1 && (size_t)nslice * nrow1 * C0 * sizeof(float) > st().ws_bytes / 8) nslice >>= 1;
         const int rpw = (rows + nslice * 4 - 1) / (nslice * 4);

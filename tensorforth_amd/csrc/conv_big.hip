@@ -949,7 +949,7 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
     {   // stride 1, "same" padding, whole 64-channel stages: the 8-wave LDS-DMA kernel (k_convbig8), every such layer since round 5 (round 4 kept the 9-stage
         // layers on k_convbig: with buffer-addressed DMA, the branch-free epilogue and two workgroups per CU on 32-channel stages they gain most -
         // 64 -> 128 @ 16x16 forward 96.2 -> 83.9 us, 64 -> 64 @ 32x32 221 -> 194.5 us, dX 185 -> 168 us); T4K_CONVBIG8=0: off
-        static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONVBIG8"); on = e ? atoi(e) : 1; }
+        static const int on = T4K_LAB_ENV("T4K_CONVBIG8", 1);
         const bool shape = S == 1 && P == K / 2 && (K == 1 || K == 3 || K == 5) && Cin % 64 == 0 && Cout % 4 == 0 && Hx == Hy && Wx == Wy &&
                            aligned16(X) && aligned16(F) && npix >= 128 && npix * Cin < (1L << 29) && (long)(Cin > Cout ? Cin : Cout) * K * K * C0f < (1L << 29);   // byte offsets of the buffer loads are 32-bit
         if (on && shape) {
@@ -963,14 +963,14 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
             const dim3 g8((unsigned)(tiles_m * q.tiles_n)), b8(512);
             // grids of two or more tiles per CU: 32-channel stages, half the LDS, at most 128 registers - two workgroups share a CU and one's stage barrier
             // (and prologue, and epilogue) runs under the other's MFMAs (as k_gemm_plain128<.., 32>)
-            static int bk32 = -1; if (bk32 < 0) { const char *e = getenv("T4K_CONVBIG8_BK32"); bk32 = e ? atoi(e) : 1; }
+            static const int bk32 = T4K_LAB_ENV("T4K_CONVBIG8_BK32", 1);
             const bool two = bk32 && (bk32 >= 2 || (long)tiles_m * q.tiles_n >= 2L * st().cu_count);
             const size_t lds8 = std::max(sizeof(float) * 2 * (128 + BN) * (two ? 32 : 64), sizeof(float) * 4 * 2 * (BN / 64) * 16 * 64);   // stages | the k-groups' meeting
 #define CB8_(k, pd, ntw, nt, bk) do { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_convbig8<k, pd, BWD, ntw, nt, bk>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); a1 = true; } \
                                       T4K_LAUNCH((k_convbig8<k, pd, BWD, ntw, nt, bk>), g8, b8, lds8, hs, q); } while (0)
 #define CB8n(k, pd, ntw) do { if (two) { if (nts) CB8_(k, pd, ntw, true, 32); else CB8_(k, pd, ntw, false, 32); } else { if (nts) CB8_(k, pd, ntw, true, 64); else CB8_(k, pd, ntw, false, 64); } } while (0)
 #define CB8(k, pd) do { if (wide) CB8n(k, pd, 2); else CB8n(k, pd, 1); } while (0)
-            static int nts = -1; if (nts < 0) { const char *e = getenv("T4K_CONVBIG8_NT"); nts = e ? atoi(e) : 0; }
+            static const int nts = T4K_LAB_ENV("T4K_CONVBIG8_NT", 0);
             if (K == 1) CB8(1, 0); else if (K == 3) CB8(3, 1); else CB8(5, 2);
 #undef CB8n
 #undef CB8_
@@ -980,7 +980,7 @@ void launch_conv_big(int K, int S, int P, hipStream_t hs, const float *X, float 
     }
     CbP p = { X, F, B, Y, Y2, N, Hx, Wx, Cin, Hy, Wy, Cout, C0f, 0 };
     const int tiles_m = (int)((npix + 127) / 128);
-    static int wmul = -1; if (wmul < 0) { const char *e = getenv("T4K_CONVBIG_WIDE_MUL"); wmul = e ? atoi(e) : 1; }
+    static const int wmul = T4K_LAB_ENV("T4K_CONVBIG_WIDE_MUL", 1);
     const bool wide = Cout > 64 && (long)tiles_m * ((Cout + 127) / 128) >= (long)st().cu_count * wmul;   // 128-wide tiles only when they still give every CU a workgroup (CIFAR conv3 dX: 128 -> 256 workgroups)
     const int BN = wide ? 128 : 64;
     p.tiles_n = (Cout + BN - 1) / BN;
@@ -1006,19 +1006,19 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
     const long npix = (long)N * H0 * W0;
     const int ci_tiles = (C1 + 63) / 64, co_tiles = (C0 + 63) / 64, KK = K * K;
     const int tiles = KK * ci_tiles * co_tiles;
-    static int wpc = -1; if (wpc < 0) { const char *e = getenv("T4K_DF_WGS_PER_CU"); wpc = e ? atoi(e) : 3; if (wpc < 1) wpc = 1; }
+    static const int wpc = std::max(1, T4K_LAB_ENV("T4K_DF_WGS_PER_CU", 3));
     long nslice = ((long)wpc * st().cu_count + tiles - 1) / tiles; if (nslice < 1) nslice = 1;      // workgroups per CU in total
     long pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; if (pps < 8 * BK) pps = 8 * BK;
     nslice = (npix + pps - 1) / pps;
     // Workgroups go to XCD (linear block id % 8) and the grid is slice-major: with a slice count that is a multiple of 8 every
     // tap / channel tile of one pixel slice lands on the SAME XCD, so the K*K-fold re-read of I and dO is served by that XCD's
     // L2 instead of crossing the fabric once per tap (a trailing slice may be empty: it writes a zero slab)
-    static int x8 = -1; if (x8 < 0) { const char *e = getenv("T4K_DF_XCD"); x8 = e ? atoi(e) : 1; }
+    static const int x8 = T4K_LAB_ENV("T4K_DF_XCD", 1);
     if (x8 && nslice >= 8) { nslice = (nslice + 7) / 8 * 8; pps = (npix + nslice - 1) / nslice; pps = (pps + BK - 1) / BK * BK; }
     {   // stride 1, same size, whole 128s of input channels, whole 64s of output channels: 128-row tiles (k_convbig_dfw; 128 -> 256 @ 8x8, N = 256: 92.0 -> 88.4 us).
         // Two or four taps of 64 / 32 channels per tile work too (T4K_CONVBIG_DFW=3) but lose: 9 taps fill 10 / 12 tap slots and the fold reads 51 slices
         // (64 -> 128 @ 16x16: 96.3 + 24 us of fold against 89 + 12)
-        static int dfw = -1; if (dfw < 0) { const char *e = getenv("T4K_CONVBIG_DFW"); dfw = e ? atoi(e) : 1; }
+        static const int dfw = T4K_LAB_ENV("T4K_CONVBIG_DFW", 1);
         const bool shape = S == 1 && P == K / 2 && (K == 1 || K == 3 || K == 5) && H1 == H0 && W1 == W0 && (C1 % 128 == 0 || (dfw >= 3 && (C1 == 32 || C1 == 64))) && C0 % 64 == 0 &&
                            npix * C1 < (1L << 29) && npix * C0 < (1L << 29) && aligned16(I) && aligned16(DO);
         if (dfw && shape) {
@@ -1050,15 +1050,15 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
             }
         }
     }
-    static int df8 = -1; if (df8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8"); df8 = e ? atoi(e) : 64; }     // 0: the 4-wave register-staged kernel; 64 / 128: pixels per stage of the 8-wave LDS-DMA kernel
+    static const int df8 = T4K_LAB_ENV("T4K_CONVBIG_DF8", 64);     // 0: the 4-wave register-staged kernel; 64 / 128: pixels per stage of the 8-wave LDS-DMA kernel
     if (df8 && npix * (C0 > C1 ? C0 : C1) / 4 + (long)4 * W1 * C1 < (1L << 31) && st().d_zero) {      // row offsets are ints in 16-byte units
         // 64-pixel stages: 64 KiB of LDS, two workgroups per CU (one's barrier under the other's MFMAs) -> up to 2 x CUs workgroups at once, all resident
         const int bkp = df8 >= 128 ? 128 : df8 >= 64 ? 64 : 32;
-        static int wpc8 = -1; if (wpc8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8_WPC"); wpc8 = e ? atoi(e) : 0; }
-        static int nstb = -1; if (nstb < 0) { const char *e = getenv("T4K_CONVBIG_DF8_NST"); nstb = e ? atoi(e) : (bkp == 32 ? 4 : 2); }
+        static const int wpc8 = T4K_LAB_ENV("T4K_CONVBIG_DF8_WPC", 0);
+        static const int nstb = T4K_LAB_ENV("T4K_CONVBIG_DF8_NST", (bkp == 32 ? 4 : 2));
         const int lds_kb = (bkp == 128 ? 2 : bkp == 64 ? (nstb == 3 ? 3 : 2) : (nstb >= 5 ? 5 : nstb == 4 ? 4 : 3)) * 128 * bkp * 4 / 1024;
         const long slots = (long)st().cu_count * (wpc8 > 0 ? wpc8 : std::max(1, std::min(160 / lds_kb, 3)));
-        static int tp2on = -1; if (tp2on < 0) { const char *e = getenv("T4K_CONVBIG_DF8_TP2"); tp2on = e ? atoi(e) : 1; }
+        static const int tp2on = T4K_LAB_ENV("T4K_CONVBIG_DF8_TP2", 1);
         const int tp2 = (tp2on && C1 == 32) ? 1 : 0;         // two taps per 64-row tile
         const int kks = tp2 ? (KK + 1) / 2 : KK;
         const int tiles8 = kks * ci_tiles * co_tiles;
@@ -1066,7 +1066,7 @@ int launch_conv_big_df(int K, int S, int P, hipStream_t hs, const float *I, cons
         long pp = (npix + ns - 1) / ns; pp = (pp + bkp - 1) / bkp * bkp; if (pp < 4 * bkp) pp = 4 * bkp;
         ns = (npix + pp - 1) / pp;
         if ((size_t)ns * C1 * KK * C0 > part_floats) return 0;
-        static int dbg8 = -1; if (dbg8 < 0) { const char *e = getenv("T4K_CONVBIG_DF8_DBG"); dbg8 = e ? atoi(e) : 0; }
+        static const int dbg8 = T4K_LAB_ENV("T4K_CONVBIG_DF8_DBG", 0);
         const int ctl = ci_tiles * co_tiles;
         Cd8 q = { I, DO, st().d_zero, part, N, H1, W1, C1, H0, W0, C0, (int)pp, ci_tiles, npix, dbg8, (int)ns, ctl, tp2 };
         const long groups = ns * ctl;

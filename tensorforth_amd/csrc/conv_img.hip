@@ -397,14 +397,14 @@ namespace t4k {
 bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, int N, int H, int W, int C1, int C0, hipStream_t hs,
                    float *bn_part, size_t bn_part_floats, int *bn_chunks) {
     if (bn_chunks) *bn_chunks = 0;
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_THIN"); on = e ? atoi(e) : 1; }
+    static const int on = T4K_LAB_ENV("T4K_CONV_THIN", 1);
     if (!on || C1 < 1 || C1 > 4 || (C0 != 32 && C0 != 64) || (long)N * H * W >= 0x7fffff00L) return false;
     if (!aligned16(I) || !aligned16(O) || (ICOPY && !aligned16(ICOPY))) return false;       // 16-byte pieces of the batch copy and of the output rows
     const long ntile = ((long)N * H * W + 31) / 32;
-    static int cap = -1; if (cap < 0) { const char *e = getenv("T4K_CONV_THIN_WG"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 1; }
+    static const int cap = std::max(1, T4K_LAB_ENV("T4K_CONV_THIN_WG", 512));
     long wg = (ntile + 3) / 4; if (wg > cap) wg = cap;         // a wave walks ntile / (4 wg) tiles with its filter in registers
     const dim3 g((unsigned)wg), b(256);
-    static int nts = -1; if (nts < 0) { const char *e = getenv("T4K_CONV_THIN_NT"); nts = e ? atoi(e) : 1; }
+    static const int nts = T4K_LAB_ENV("T4K_CONV_THIN_NT", 1);
     const bool stat = bn_part && bn_chunks && ((long)N * H * W) % 32 == 0 && (size_t)wg * 2 * C0 <= bn_part_floats;    // batch-norm sums from the epilogue: whole tiles only
     if (stat) *bn_chunks = (int)wg;
 #define T4K_THIN3(C_, T_, N_, S_) do { if (ICOPY) T4K_LAUNCH((k_conv_thin_fwd<C_, T_, true, N_, S_>), g, b, 0, hs, I, O, ICOPY, F, B, N, H, W, ntile, bn_part); \
@@ -425,10 +425,10 @@ bool conv_thin_fwd(const float *I, float *ICOPY, float *O, const float *F, const
 }
 // dF | dB partial slabs of the same layer: true when launched here, *nslice = slab rows ((9 C1 + 1) x C0 floats each) for k_conv_df_fold
 bool conv_thin_df(const float *I, const float *DO, float *part, size_t part_bytes, int N, int H, int W, int C1, int C0, int *nslice, hipStream_t hs) {
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_THIN_DF"); on = e ? atoi(e) : 1; }
+    static const int on = T4K_LAB_ENV("T4K_CONV_THIN_DF", 1);
     if (!on || C1 < 1 || C1 > 3 || (C0 != 32 && C0 != 64) || W < 2 || (long)N * H * W >= 0x7fffff00L) return false;
     const long ntile = ((long)N * H * W + 31) / 32;
-    static int cap = -1; if (cap < 0) { const char *e = getenv("T4K_CONV_THIN_DF_WG"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 1; }
+    static const int cap = std::max(1, T4K_LAB_ENV("T4K_CONV_THIN_DF_WG", 512));
     long wg = (ntile + 3) / 4; if (wg > cap) wg = cap;
     while (wg > 1 && (size_t)wg * (9 * C1 + 1) * C0 * sizeof(float) > part_bytes) wg >>= 1;
     if ((size_t)wg * (9 * C1 + 1) * C0 * sizeof(float) > part_bytes) return false;
@@ -447,7 +447,7 @@ bool conv_thin_df(const float *I, const float *DO, float *part, size_t part_byte
 // true when the block was launched here (t4k_conv2d_block_fwd falls through to its other kernels otherwise)
 bool conv_img_block_fwd(const float *I, float *ICOPY, float *O, const float *F, const float *B, const t4k_poolblock *blk,
                         int N, int H, int W, int C1, int C0, hipStream_t hs) {
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_CONV_IMG"); on = e ? atoi(e) : 1; }
+    static const int on = T4K_LAB_ENV("T4K_CONV_IMG", 1);
     if (!on || (C1 != 1 && C1 != 3) || C0 > 16 || (H & 1) || (W & 1) || blk->KS != 2 || !blk->pool_layer) return false;
     if (blk->pre_layer == T4K_L_DROPOUT || blk->post_layer == T4K_L_DROPOUT) return false;      // mask draws stay with the Philox-carrying kernels
     if ((C0 & 1) == 0 && (!aligned16(O) || !aligned16(blk->pool_out))) return false;
@@ -458,7 +458,7 @@ bool conv_img_block_fwd(const float *I, float *ICOPY, float *O, const float *F, 
     p.N = N; p.H = H; p.W = W;
     const long nwin = (long)N * (H / 2) * (W / 2);
     const unsigned grid = (unsigned)((nwin + 63) / 64);
-    static int nt = -1; if (nt < 0) { const char *e = getenv("T4K_CONV_IMG_NT"); nt = e ? atoi(e) : 1; }
+    static const int nt = T4K_LAB_ENV("T4K_CONV_IMG_NT", 1);
     if (nt) return C1 == 1 ? launch_cout<1, true>(p, C0, grid, hs) : launch_cout<3, true>(p, C0, grid, hs);
     return C1 == 1 ? launch_cout<1, false>(p, C0, grid, hs) : launch_cout<3, false>(p, C0, grid, hs);
 }

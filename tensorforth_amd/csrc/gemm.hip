@@ -397,54 +397,15 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(GemmP p) {
 // kernels, each with 1/16 of the matrix work per wave.
 // Operand layout of v_mfma_f32_32x32x2_f32: lane (l31, h) supplies A[row = l31][k] and B[k][col = l31] for one k per instruction;
 // chunk c covers k = 8c + 4h + {0..3}, as in the LDS kernels above.
-template <bool AKC, bool BKC, int CB, bool ALDS = false, bool DOA = true, bool DOB = true>       // ALDS: A points into LDS (ds_read instead of flat loads); DOA / DOB: fetch that operand
-__device__ __forceinline__ void s32_fetch(const float *__restrict__ A, const float *__restrict__ B, int M, int N, int ldk, int K, int arow, int bcol,
-                                          int cbeg, int cend, int h, float (&fa)[CB][4], float (&fb)[CB][4], int kbeg, int lda = -1) {
-    if (lda < 0) lda = ldk;                                         // A's row pitch when it is K-contiguous (an operand tile prepared in LDS has its own)
-#pragma unroll
-    for (int c = 0; c < CB; c++) {
-        const int ch = cbeg + c, k0 = kbeg + ch * 8 + 4 * h;       // K here is the END of this workgroup's k range, kbeg its start
-        const bool ok = ch < cend && k0 < K;
-        if (!DOA) {}
-        else if (ALDS) {
-            typedef __attribute__((address_space(3))) const float lds_f;
-            typedef __attribute__((address_space(3))) const v4f lds_v4;
-            lds_f *Al = (lds_f *)A;
-            if (AKC) { const v4f z = {0.f, 0.f, 0.f, 0.f}; const v4f t = ok ? *(lds_v4 *)(Al + arow * lda + k0) : z;
-                       fa[c][0] = t[0]; fa[c][1] = t[1]; fa[c][2] = t[2]; fa[c][3] = t[3]; }
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) fa[c][j] = (ok && k0 + j < K) ? Al[(k0 + j) * M + arow] : 0.f;
-            }
-        } else
-        if (AKC) {                                                  // A stored [M][K], K % 4 == 0: one 16-byte load
-            const v4f z = {0.f, 0.f, 0.f, 0.f};
-            const v4f t = ok ? *reinterpret_cast<const v4f *>(A + (long)arow * lda + k0) : z;
-            fa[c][0] = t[0]; fa[c][1] = t[1]; fa[c][2] = t[2]; fa[c][3] = t[3];
-        } else {                                                    // A stored [K][M]: the 32 lanes of a half wave read one 128-byte run per k
-#pragma unroll
-            for (int j = 0; j < 4; j++) fa[c][j] = (ok && k0 + j < K) ? A[(long)(k0 + j) * M + arow] : 0.f;
-        }
-        if (!DOB) {}
-        else if (BKC) {                                                  // B stored [N][K]
-            const v4f z = {0.f, 0.f, 0.f, 0.f};
-            const v4f t = ok ? *reinterpret_cast<const v4f *>(B + (long)bcol * ldk + k0) : z;
-            fb[c][0] = t[0]; fb[c][1] = t[1]; fb[c][2] = t[2]; fb[c][3] = t[3];
-        } else {                                                    // B stored [K][N]
-#pragma unroll
-            for (int j = 0; j < 4; j++) fb[c][j] = (ok && k0 + j < K) ? B[(long)(k0 + j) * N + bcol] : 0.f;
-        }
-    }
-}
-struct NoPro { __device__ void operator()() const {} };
-// DMA: the operand fragments come through wave-private LDS blocks filled by global_load_lds_dwordx4 (see the K loop) - `red` is then the
-// workgroup's dynamic LDS of NW x 16 KiB; k-group w's partial accumulators land at red + w RS
-template <bool AKC, bool BKC, int CB, int NW = 4, bool ALDS = false, typename PRO = NoPro, bool DMA = false, bool RST = false>   // NW waves = NW k-groups per 32x32 tile; ALDS: the A tile is prepared in LDS by `pro`, which runs while the first B fragments are in flight
+// One 32x32 output tile per workgroup, K split over its NW waves (k-groups) which meet once in LDS; the whole epilogue rides (bias, activation + dropout riders, mask
+// chain, column-sum and copy riders, split-K slabs).  The operand fragments come through wave-private LDS blocks filled by global_load_lds_dwordx4 (see the K loop):
+// `red` is the workgroup's dynamic LDS of NW x 16 KiB; k-group w's partial accumulators land at red + w RS.  (Round 6: the register-fetch form of this body -
+// k_gemm_s32 / k_gemm_dual32, row gathers of 16 bytes - is gone; shapes whose operands the DMA cannot take go to the 64x64 kernels.)
+template <bool AKC, bool BKC, int NW = 4, bool RST = false>   // NW waves = NW k-groups per 32x32 tile; RST: blocks 2, 3 of a wave's range wait in registers
 __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, float *red,
-                                              int *gate = nullptr, const int gate_mode = 0, const int gate_n = 0, const int gate_m = 0,
+                                              const int gate_mode = 0, const int gate_n = 0,
                                               const MaskChain *mc = nullptr, unsigned *slots = nullptr, const unsigned epoch = 0,
-                                              const int by = 0, const FoldRider *fe = nullptr, const ActEpi *ep1 = nullptr,
-                                              const float *Alds = nullptr, const int Ald = 0, PRO pro = PRO()) {      // Alds: this tile's 32 rows of A in LDS ([k][32] or [32][Ald]), filled by pro()
+                                              const int by = 0, const FoldRider *fe = nullptr, const ActEpi *ep1 = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int M = p.M, N = p.N, K = p.K;
     const int kbeg = by * p.kchunk, kend = min(K, kbeg + p.kchunk);      // this workgroup's k range (split-K: slab `by`)
@@ -472,11 +433,6 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     }
     const int tile = tm * p.tiles_n + tn;                  // logical id: the arrival slots are indexed by it
     const int m0 = tm * 32, n0 = tn * 32;
-    const int arow = Alds ? l31 : min(m0 + l31, M - 1), bcol = min(n0 + l31, N - 1);      // clamped: rows / columns past the edge are never stored
-    const float *Ap = Alds ? Alds : p.A; const int Am = Alds ? 32 : M, Ald_ = Alds ? Ald : K;
-    // this wave's share of the 8-deep k chunks
-    const int nch = (kend - kbeg + 7) >> 3, cpw = (nch + NW - 1) / NW;
-    const int c0 = w * cpw, c1 = min(nch, c0 + cpw);
     // the share of the tile this wave finishes: accumulator registers QN w .. QN w + QN - 1 (QN = 16 / NW), row of register r = (r & 3) + 8 (r >> 2) + 4 h
     constexpr int QN = 16 / NW;
     const int gn = n0 + l31;
@@ -502,16 +458,6 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    float fa0[CB][4], fb0[CB][4], fa1[CB][4], fb1[CB][4];
-    auto mma = [&](float (&fa)[CB][4], float (&fb)[CB][4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < CB; c++) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][2], fb[c][2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][3], fb[c][3], acc1, 0, 0, 0);
-        }
-    };
     // gate_mode 1 with per-wave slots (gate_n <= 128 reader workgroups): a wave reports as soon as its LAST operand fragments sit in
     // registers, in front of its last MFMA batch - the writers' wait then overlaps that batch, the LDS reduction and the epilogue
     const bool early = gate_mode == 1 && gate_n <= 128 && NW == 4;       // per-wave slots: 4 per reader workgroup
@@ -520,8 +466,8 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(slots + 4 * tile + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    constexpr int RS = DMA ? 4096 : 1024;                         // floats between two k-groups' partial accumulators in `red`
-    if constexpr (DMA) {
+    constexpr int RS = 4096;                                      // floats between two k-groups' partial accumulators in `red`
+    {
         // Coalesced operand fetch for slivers.  The register path above makes every wave load a gather (32 rows x 16 bytes: 64 cache-line
         // look-ups per instruction for 1 KiB, the address unit's queue stalls the wave's issue - SQ_WAIT_INST_ANY 42 % on the K-contiguous
         // forward layers).  Here a wave moves its k range in blocks of 32 k through two private LDS slots (A 4 KiB + B 4 KiB each):
@@ -529,7 +475,6 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         // no VGPR round trip, no barrier in the K loop (the blocks are the wave's own: s_waitcnt vmcnt only).
         //   K-contiguous block [32 rows][32 k]: the 16-byte quad q of row r sits at quad (q ^ ((r >> 1) & 7)) - the 16 lanes of a
         //   ds_read_b128 group ({0-3,12-15,20-27} ...) then cover all 64 banks once;  [K][M] block: [32 k][32 columns], ds_read_b32 rows.
-        static_assert(!ALDS, "DMA operands come from global memory");
         typedef __attribute__((address_space(3))) const float lds_f;
         typedef __attribute__((address_space(3))) const v4f lds_v4;
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)red;
@@ -628,25 +573,6 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
                 slot ^= 1;
             }
         } else arrive();
-    } else {
-    if (ALDS) {                                                   // the first B fragments fly while the workgroup prepares its A tile (barriers inside: every thread calls pro)
-        if (c0 < c1) s32_fetch<AKC, BKC, CB, ALDS, false, true>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
-        pro();
-    }
-    if (c0 < c1) {
-        if (ALDS) s32_fetch<AKC, BKC, CB, ALDS, true, false>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
-        else      s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, c0, c1, h, fa0, fb0, kbeg, Ald_);
-        for (int cb = c0; cb < c1; cb += 2 * CB) {
-            if (cb + CB < c1) s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, cb + CB, c1, h, fa1, fb1, kbeg, Ald_);
-            else arrive();
-            mma(fa0, fb0);
-            if (cb + CB < c1) {
-                if (cb + 2 * CB < c1) s32_fetch<AKC, BKC, CB, ALDS>(Ap, p.B, Am, N, K, kend, arow, bcol, cb + 2 * CB, c1, h, fa0, fb0, kbeg, Ald_);
-                else arrive();
-                mma(fa1, fb1);
-            }
-        }
-    } else arrive();
     }
     // the four k-groups meet in LDS: red[w][r][lane]
 #pragma unroll
@@ -703,26 +629,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmP &p, const int bx, floa
         }
     }
 }
-// one GEMM on 32x32 tiles (see gemm_s32_body): grid = (tiles + column-sum riders + copy riders, k slabs); epilogue riders as the fold launch's
-template <bool AKC, bool BKC, int CB, int NW = 4>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CB == 4 ? 3 : 2))) k_gemm_s32(GemmP p, ActEpi ep, FoldRider fr) {
-    __shared__ float red[NW * 16 * 64];
-    const int nwork = (int)gridDim.x - fr.cp_blocks;
-    if ((int)blockIdx.x >= nwork) {                              // the model's copy of the batch into its layer 0 rides along (forward.cu:39)
-        if (blockIdx.y) return;
-        const long t0 = (long)((int)blockIdx.x - nwork) * (64 * NW) + threadIdx.x, step = (long)fr.cp_blocks * (64 * NW);
-        if (fr.cp_vec) {
-            const long n4 = fr.cp_n >> 2;
-            for (long z = t0; z < n4; z += step) reinterpret_cast<float4 *>(fr.cp_dst)[z] = reinterpret_cast<const float4 *>(fr.cp_src)[z];
-            for (long z = (n4 << 2) + t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
-        } else
-            for (long z = t0; z < fr.cp_n; z += step) fr.cp_dst[z] = fr.cp_src[z];
-        return;
-    }
-    if ((int)blockIdx.x >= p.tiles_m * p.tiles_n && blockIdx.y) return;   // column-sum riders run once
-    gemm_s32_body<AKC, BKC, CB, NW>(p, blockIdx.x, red, nullptr, 0, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
-}
-// the same launch with the operands staged by LDS-DMA (gemm_s32_body<.., DMA>): dynamic LDS = NW x 16 KiB
+// one GEMM on 32x32 tiles (see gemm_s32_body): grid = (tiles + column-sum riders + copy riders, k slabs); epilogue riders as the fold launch's; dynamic LDS = NW x 16 KiB
 template <bool AKC, bool BKC, int NW, bool RST>
 __global__ void __launch_bounds__(64 * NW) k_gemm_l32(GemmP p, ActEpi ep, FoldRider fr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -739,7 +646,7 @@ __global__ void __launch_bounds__(64 * NW) k_gemm_l32(GemmP p, ActEpi ep, FoldRi
         return;
     }
     if ((int)blockIdx.x >= p.tiles_m * p.tiles_n && blockIdx.y) return;   // column-sum riders run once
-    gemm_s32_body<AKC, BKC, 4, NW, false, NoPro, true, RST>(p, blockIdx.x, lds, nullptr, 0, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
+    gemm_s32_body<AKC, BKC, NW, RST>(p, blockIdx.x, lds, 0, 0, fr.mc.d1 ? &fr.mc : nullptr, nullptr, 0, blockIdx.y, &fr, &ep);
 }
 template <bool AKC, bool BKC, int NW, bool RST>
 void launch_l32(const GemmP &p, const ActEpi &ep, const FoldRider &fr, dim3 grid, hipStream_t s) {
@@ -747,24 +654,15 @@ void launch_l32(const GemmP &p, const ActEpi &ep, const FoldRider &fr, dim3 grid
     if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_l32<AKC, BKC, NW, RST>), hipFuncAttributeMaxDynamicSharedMemorySize, NW * 16384); attr_done = true; }
     T4K_LAUNCH((k_gemm_l32<AKC, BKC, NW, RST>), grid, dim3(64 * NW), (size_t)NW * 16384, s, p, ep, fr);
 }
-// dW += dY^T X (+ dB rider) and dX = dY W of one linear layer on 32x32 tiles (see k_gemm_dual for the gate)
-// CB = k chunks (of 8) per register batch: 8 = 64 k in flight twice over (216 VGPRs, 2 workgroups per CU), 4 = half of that (4 per CU)
-template <int CB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 4 ? 3 : 2))) k_gemm_dual32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, MaskChain mc) {
-    __shared__ float red[4 * 16 * 64];
-    if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, CB>(p1, blockIdx.x, red, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
-    else                       gemm_s32_body<true, false, CB>(p2, (int)blockIdx.x - nb1, red, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
-}
-
-// k_gemm_dual32 with LDS-DMA operand blocks (gemm_s32_body<.., DMA>): 4 waves, 64 KiB of dynamic LDS.  More workgroups than resident slots are
+// dW += dY^T X (+ dB rider) and dX = dY W of one linear layer on 32x32 tiles (see k_gemm_dual for the gate): NW waves, NW x 16 KiB of dynamic LDS.  More workgroups than resident slots are
 // fine here although the dX writers spin on the dW readers' slots: a writer's readers all have LOWER workgroup ids, each XCD dispatches its
 // workgroups in id order and a reader never waits - so every reader is running or done before the first writer of its XCD takes a slot
 // (the same dispatch-order argument as the conv stack's band exchange; the wait is bounded and reported anyway).
 template <bool RST, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) k_gemm_dual_l32(GemmP p1, GemmP p2, int nb1, int t1, int t2, unsigned *slots, unsigned epoch, MaskChain mc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, 4, NW, false, NoPro, true, RST>(p1, blockIdx.x, lds, nullptr, slots ? 1 : 0, t1, t2, nullptr, slots, epoch);
-    else                       gemm_s32_body<true, false, 4, NW, false, NoPro, true, RST>(p2, (int)blockIdx.x - nb1, lds, nullptr, slots ? 2 : 0, t1, t2, &mc, slots, epoch);
+    if ((int)blockIdx.x < nb1) gemm_s32_body<false, false, NW, RST>(p1, blockIdx.x, lds, slots ? 1 : 0, t1, nullptr, slots, epoch);
+    else                       gemm_s32_body<true, false, NW, RST>(p2, (int)blockIdx.x - nb1, lds, slots ? 2 : 0, t1, &mc, slots, epoch);
 }
 
 // ---- classifier-head backward + the backward of the linear layer in front of it, ONE launch (t4k_mlp_head_bwd).
@@ -1111,187 +1009,9 @@ __global__ void __launch_bounds__(256) k_gemm_dual(GemmP p1, GemmP p2, int nb1, 
 // raw s_barrier so the DMA of later stages stays in flight across barriers.  The DMA writes LDS
 // lane-linearly (wave-uniform base + lane*16 B), so the XOR swizzle of a K-contiguous operand is
 // applied to the per-lane SOURCE address and undone on the ds_read_b128 side.
-template <int BK, bool AKC, bool BKC>
-__global__ void __launch_bounds__(256) k_gemm_glds(GemmP p) {
-    constexpr int BM = 64, BN = 64;
-    constexpr int NC = BK / 8, CH = BK / 4, SW = 64 / BK;
-    constexpr int STAGE = (BM + BN) * BK;          // floats per stage buffer
-    constexpr int NI = BK / 4;                     // 1-KiB DMA instructions per operand per stage
-    constexpr int NJ = NI / 4;                     // ... per wave
-    constexpr int NPW = 2 * NJ;                    // DMA instructions per wave per stage
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1, h = lane >> 5, l31 = lane & 31;
-    const int M = p.M, N = p.N, K = p.K;
-
-    const int T = p.tiles_m * p.tiles_n;
-    int L;
-    {
-        const int b = blockIdx.x, q8 = T >> 3, r8 = T & 7, x = b & 7, i = b >> 3;
-        L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i;
-    }
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int grp = L / per_group, first_m = grp * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (L % per_group) % gsz, tn = (L % per_group) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * p.kchunk;
-    const int kend = min(K, kbeg + p.kchunk);
-    const int nst  = (kend - kbeg) / BK;
-
-    // per-lane DMA source pointers of stage 0
-    const float *srcA[NJ], *srcB[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        const int i = w * NJ + j;
-        if (AKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
-                   srcA[j] = p.A + (long)(m0 + r) * K + kbeg + q * 4; }
-        else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
-                   srcA[j] = p.A + (long)(kbeg + kk) * M + m0 + ch * 4; }
-        if (BKC) { const int r = i * (256 / BK) + lane / CH, ql = lane % CH, q = ql ^ ((r / SW) & (CH - 1));
-                   srcB[j] = p.B + (long)(n0 + r) * K + kbeg + q * 4; }
-        else     { const int kk = i * 4 + lane / 16, ch = lane % 16;
-                   srcB[j] = p.B + (long)(kbeg + kk) * N + n0 + ch * 4; }
-    }
-    const long stepA = AKC ? BK : (long)BK * M, stepB = BKC ? BK : (long)BK * N;
-
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        float *base = lds + buf * STAGE + (w * NJ) * 256;
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[j] + kt * stepA),
-                                             (__attribute__((address_space(3))) void *)(base + j * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[j] + kt * stepB),
-                                             (__attribute__((address_space(3))) void *)(base + BM * BK + j * 256), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-
-    const int ra_ = wm * 32 + l31, rb_ = wn * 32 + l31;
-    // operand fragments of one 8-deep k chunk (lane half h holds k = 8*ci + 4*h + {0..3})
-    auto rd = [&](const float *a, const float *b, int ci, float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
-        if (AKC) { const v4f t = *reinterpret_cast<const v4f *>(a + ra_ * BK + (((ci * 2 + h) ^ ((ra_ / SW) & (CH - 1))) << 2));
-                   av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3]; }
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) av[j] = a[(ci * 8 + 4 * h + j) * BM + ra_];
-        }
-        if (BKC) { const v4f t = *reinterpret_cast<const v4f *>(b + rb_ * BK + (((ci * 2 + h) ^ ((rb_ / SW) & (CH - 1))) << 2));
-                   bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3]; }
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) bv[j] = b[(ci * 8 + 4 * h + j) * BN + rb_];
-        }
-    };
-    auto mm = [&](float (&av)[4], float (&bv)[4]) __attribute__((always_inline)) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
-    };
-    auto wait_next = [&](bool more) __attribute__((always_inline)) {      // next stage landed; later one may fly
-        if (more) { if (NPW == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                    else          asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
-        else        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-
-    if (nst > 0) issue(0, 0);
-    if (nst > 1) issue(1, 1);
-    wait_next(nst > 1);
-
-    // Software pipeline: the operands of chunk c+1 are read BEFORE the MFMAs of chunk c are issued,
-    // and the MFMAs of a stage's last chunk are issued after the barrier, behind the first reads of
-    // the next stage - the matrix pipe never waits on an LDS round trip.
-    float ca[4], cb[4];
-    if (nst > 0) rd(lds, lds + BM * BK, 0, ca, cb);
-    int buf = 0;
-    for (int kt = 0; kt < nst; kt++) {
-        int nb = buf + 2; if (nb >= 3) nb -= 3;
-        int b1 = buf + 1; if (b1 >= 3) b1 = 0;
-        if (kt + 2 < nst) issue(kt + 2, nb);                // overwrites the buffer read in stage kt-1
-        const float *a = lds + buf * STAGE, *b = a + BM * BK;
-#pragma unroll
-        for (int ci = 0; ci + 1 < NC; ci++) {
-            float na[4], nbv[4];
-            rd(a, b, ci + 1, na, nbv);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(ca, cb);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
-        }
-        wait_next(kt + 2 < nst);                            // all my reads of stage kt done; stage kt+1 visible
-        float na[4], nbv[4];
-        if (kt + 1 < nst) rd(lds + b1 * STAGE, lds + b1 * STAGE + BM * BK, 0, na, nbv);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(ca, cb);
-        if (kt + 1 < nst) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { ca[j] = na[j]; cb[j] = nbv[j]; }
-        }
-        buf = b1;
-    }
-
-    const float alpha = p.alpha, beta = p.beta;
-    const int gn = n0 + wn * 32 + l31;
-    float add[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) add[r] = 0.f;
-    if (p.pair) {
-        // Two workgroups own this tile (one K half each) so every SIMD holds two independent waves.  The first to
-        // finish parks its 64x64 partial in the workspace and raises a flag; the second adds it (a+b == b+a, so the
-        // result does not depend on who wins) and runs the epilogue.  Agent-scope release/acquire: the two
-        // workgroups may sit on different XCDs, whose L2s are not coherent with each other.
-        __shared__ int role_s;
-        const int tile_id = tm * p.tiles_n + tn;
-        int *ticket = p.sync + tile_id, *flag = p.sync + 2048 + tile_id;
-        float *slot = p.part + (long)tile_id * (BM * BN);
-        if (tid == 0) role_s = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        // The payload moves with agent-scope (write-through / cache-bypassing) stores and loads, so no fence is needed:
-        // a release fence here costs an L2 write-back per workgroup (~1 us each, serialised per XCD - measured +25 us).
-        if (role_s == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) __hip_atomic_store(&slot[r * 256 + tid], acc0[r] + acc1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my stores are acknowledged ...
-            __syncthreads();                                      // ... and so are everybody's
-            if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (tid == 0) {
-            T4K_SPIN_WAIT(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0, 3);
-            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; r++) add[r] = __hip_atomic_load(&slot[r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = (acc0[r] + acc1[r]) + add[r];
-        if (p.nsplit > 1 && !p.pair) p.part[((long)blockIdx.y * M + gm) * N + gn] = v;
-        else {
-            const long z = (long)gm * N + gn;
-            float o = v * alpha;
-            if (beta != 0.f) o += p.O[z] * beta;
-            if (p.bias) o += p.bias[gn];
-            p.O[z] = o;
-        }
-    }
-}
-
-// 8-wave variant: the same pipeline with two waves per SIMD.  Waves 4..7 take the upper half of every stage's k chunks
+// 8-wave workgroups: two waves per SIMD.  Waves 4..7 take the upper half of every stage's k chunks
 // into their own accumulators, so one wave's LDS reads and waits sit under the other's MFMAs; the halves are summed
-// through LDS in the epilogue (fixed order).
+// through LDS in the epilogue (fixed order).  (Round 6: the 4-wave form of this pipeline, k_gemm_glds, and the variant switch that selected it are gone.)
 //
 // RAGK: K need not be a whole number of stages.  The last, partial stage is one more DMA stage whose source addresses are clamped to the
 // operand's last valid 16-byte group / row (so every lane still moves 16 bytes and the vmcnt bookkeeping is unchanged); the 8-deep chunks
@@ -1766,7 +1486,7 @@ void launch_plain_(const PlainP &q, int tmq, int tnq, unsigned gx, hipStream_t s
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nn_plain<true, AKC, BKC, EPI, PAIR, RAGK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_done = true;
     }
-    static int fastpro = -1; if (fastpro < 0) { const char *e = getenv("T4K_GEMM_FASTPRO"); fastpro = e ? atoi(e) : 1; }
+    static const int fastpro = T4K_LAB_ENV("T4K_GEMM_FASTPRO", 1);
     const bool pow2 = fastpro && (tmq & (tmq - 1)) == 0 && (tnq & (tnq - 1)) == 0 && tmq >= 4 && (tmq * tnq) % 32 == 0;
     const dim3 grid(gx, PAIR ? 2 : 1);
     if (pow2) T4K_LAUNCH((k_gemm_nn_plain<true, AKC, BKC, EPI, PAIR, RAGK>),  grid, dim3(512), lds_bytes, s, q);
@@ -1779,7 +1499,7 @@ void launch_nn_plain(const GemmP &p, dim3 grid, hipStream_t s) {
 // any layout, alpha / beta / bias: interior tiles, K % 128 == 0, unsplit - or, pair = true, K % 256 == 0 and two workgroups per tile (the caller checks)
 void launch_plain_any(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s, bool pair = false, bool ragk = false) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, p.sync, p.part };
-    { static int sw = -1; if (sw < 0) { const char *e = getenv("T4K_GEMM_TT_SWAP"); sw = e ? atoi(e) : 0; } q.swap = (sw && tA && tB) ? 1 : 0; }
+    { static const int sw = T4K_LAB_ENV("T4K_GEMM_TT_SWAP", 0); q.swap = (sw && tA && tB) ? 1 : 0; }
     const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias;
     const int tmq = p.M / 64, tnq = p.N / 64;
 #define T4K_PL(A_, B_) do { if (ragk) { if (epi) launch_plain_<A_, B_, true, false, true>(q, tmq, tnq, grid.x, s); else launch_plain_<A_, B_, false, false, true>(q, tmq, tnq, grid.x, s); } \
@@ -2121,7 +1841,7 @@ void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
     PlainP q{ p.A, p.B, p.O, p.M, p.N, p.K, p.alpha, p.beta, p.bias, nullptr, nullptr };
     const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias, ragk = p.K % 64 != 0;
     {   // one 256 x 256 tile or more per CU: the 16-wave kernel (T4K_GEMM_PLAIN256: 0 off, 1 default, 2 any grid of whole 256-tiles)
-        static int p256 = -1; if (p256 < 0) { const char *e = getenv("T4K_GEMM_PLAIN256"); p256 = e ? atoi(e) : 1; }
+        static const int p256 = T4K_LAB_ENV("T4K_GEMM_PLAIN256", 1);
         const long t256 = (long)(p.M / 256) * (p.N / 256);
         if (p256 && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 32 == 0 && p.K >= 64 && (p256 >= 2 || t256 >= (long)st().cu_count) &&
             (long)p.M * p.K < (1L << 30) && (long)p.N * p.K < (1L << 30)) {
@@ -2133,7 +1853,7 @@ void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
     }
     // Two co-resident workgroups per CU on 32-deep stages once every CU gets at least two tiles (4096^2 x 1024: 261 -> 254 us, 8192 x 4096 x 512: 282 -> 264 us;
     // with one tile per CU the doubled barrier count loses: 2048^3 129.5 -> 135.4 us).  K in whole 32s is unragged for this form.  T4K_GEMM_PLAIN128_BK32 = 0 / 1 / 2 (always).
-    static int bk32 = -1; if (bk32 < 0) { const char *e = getenv("T4K_GEMM_PLAIN128_BK32"); bk32 = e ? atoi(e) : 1; }
+    static const int bk32 = T4K_LAB_ENV("T4K_GEMM_PLAIN128_BK32", 1);
     const long tiles = (long)(p.M / 128) * (p.N / 128);
     const bool two = bk32 && p.K % 32 == 0 && (bk32 >= 2 || tiles >= 2L * st().cu_count);
 #define T4K_PL(A_, B_) do { if (two) { if (epi) launch_plain128_<A_, B_, true, false, 32>(q, s); else launch_plain128_<A_, B_, false, false, 32>(q, s); } \
@@ -2141,23 +1861,6 @@ void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
                             else if (epi) launch_plain128_<A_, B_, true>(q, s); else launch_plain128_<A_, B_, false>(q, s); } while (0)
     if (!tA && !tB) T4K_PL(true, false); else if (!tA) T4K_PL(true, true); else if (!tB) T4K_PL(false, false); else T4K_PL(false, true);
 #undef T4K_PL
-}
-
-template <int BK>
-void launch_glds(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)3 * 128 * BK * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds<BK, true, false>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds<BK, true, true>),   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds<BK, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_glds<BK, false, true>),  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_done = true;
-    }
-    if (!tA && !tB) T4K_LAUNCH((k_gemm_glds<BK, true,  false>), grid, dim3(256), lds_bytes, s, p);
-    else if (!tA)   T4K_LAUNCH((k_gemm_glds<BK, true,  true>),  grid, dim3(256), lds_bytes, s, p);
-    else if (!tB)   T4K_LAUNCH((k_gemm_glds<BK, false, false>), grid, dim3(256), lds_bytes, s, p);
-    else            T4K_LAUNCH((k_gemm_glds<BK, false, true>),  grid, dim3(256), lds_bytes, s, p);
 }
 
 template <int BK, bool RAGK>
@@ -2253,17 +1956,11 @@ void launch_variant(const GemmP &p, dim3 grid, int tA, int tB, hipStream_t s) {
     else            launch_one<BM, BN, BK, false, true,  VEC, SKEW, FULL>(p, grid, s);
 }
 
-int gemm_variant() {                      // tuning knob: T4K_GEMM_VARIANT bit0 = BK64, bit1 = SKEW, bit2 = LDS-DMA pipeline, bit3 = pair mode, bit4 = 8-wave workgroups, bit5 = 128-deep stages with 2 LDS buffers (default 53)
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("T4K_GEMM_VARIANT"); v = e ? atoi(e) : 53; }
-    return v;
-}
-
 struct ColSum { const float *X; float *out; int rows, E; bool done; };
-bool plain_any_big() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_PLAIN_ANY"); v = e ? atoi(e) : 2; } return v >= 2; }   // 0 off, 1 one-tile-per-CU shapes only, 2 (default) large ones too
-bool big_dma() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_BIG_DMA"); v = e ? atoi(e) : 1; } return v != 0 && gates_ok(); }
+bool plain_any_big() { static const int v = T4K_LAB_ENV("T4K_GEMM_PLAIN_ANY", 2); return v >= 2; }   // 0 off, 1 one-tile-per-CU shapes only, 2 (default) large ones too
+bool big_dma() { static const int v = T4K_LAB_ENV("T4K_GEMM_BIG_DMA", 1); return v != 0 && gates_ok(); }
 bool capturing(hipStream_t hs) { hipStreamCaptureStatus st_ = hipStreamCaptureStatusNone; return hipStreamIsCapturing(hs, &st_) == hipSuccess && st_ != hipStreamCaptureStatusNone; }   // a replayed graph would repeat the epoch argument
-bool dual_on() { static int v = -1; if (v < 0) { const char *e = getenv("T4K_GEMM_DUAL"); v = e ? atoi(e) : 1; } return v != 0 && gates_ok(); }
+bool dual_on() { static const int v = T4K_LAB_ENV("T4K_GEMM_DUAL", 1); return v != 0 && gates_ok(); }
 // dW += dY^T X (+ dB += column sums of dY) and dX = dY W of one linear layer in a single launch (k_gemm_dual); false when the
 // shapes belong to the other kernels (deep K -> split-K, large -> 128x128 tiles).  Interior-tile shapes take it too since round 2
 // (T4K_GEMM_DUAL_FULL=0: the LDS-DMA kernels, 5 launches with their folds and the column sum: GAN round 0.356 instead of 0.318 ms of GPU time)
@@ -2277,28 +1974,27 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     auto big = [&](int m, int n) { return (long)((m + 127) / 128) * ((n + 127) / 128) >= (long)cu * 3 / 4; };
     auto splits = [&](int m, int n, int k) { return tiles(m, n) * 2 <= cu && k >= 256; };
     auto full = [](int m, int n, int k) { return m % 64 == 0 && n % 64 == 0 && k % 64 == 0; };
-    static int deepk = -1; if (deepk < 0) { const char *e = getenv("T4K_GEMM_DUAL_MAXK"); deepk = e ? atoi(e) : 1024; }
+    static const int deepk = T4K_LAB_ENV("T4K_GEMM_DUAL_MAXK", 1024);
     // deep-K shapes would go split-K + fold (2 launches per GEMM); up to K = 1024 the single dual launch, unsplit, is faster (GAN round 0.318 ms of GPU time; with T4K_GEMM_DUAL_MAXK=256: 0.341)
     const bool sp = splits(E0, E1, N) || splits(N, E1, E0);
     if (big(E0, E1) || big(N, E1) || (sp && (N > deepk || E0 > deepk))) return false;
-    static int dfull = -1; if (dfull < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULL"); dfull = e ? atoi(e) : 1; }
-    if (!dfull && (gemm_variant() & 4) && (full(E0, E1, N) || full(N, E1, E0))) return false;
+    static const int dfull = T4K_LAB_ENV("T4K_GEMM_DUAL_FULL", 1);
+    if (!dfull && (full(E0, E1, N) || full(N, E1, E0))) return false;
     const long t1 = tiles(E0, E1), t2 = tiles(N, E1), riders = (E0 + 63) / 64;
     if (t1 + riders + t2 > cu || N > 4096) return false;
-    {   // small layers: 32x32 tiles, operands fetched straight into registers (k_gemm_dual32)
-        static int s32 = -1; if (s32 < 0) { const char *e = getenv("T4K_GEMM_DUAL32"); s32 = e ? atoi(e) : 1; }
-        static int cap = -1, cap4 = -1;
-        if (cap < 0) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gemm_dual32<8>, 256, 0) != hipSuccess) nb = 1; cap = nb * cu;
-                       nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gemm_dual32<4>, 256, 0) != hipSuccess) nb = 1; cap4 = nb * cu; }
+    {   // small layers: 32x32 tiles, K split over the waves of a workgroup, operand blocks through LDS-DMA (k_gemm_dual_l32)
+        static const int s32 = T4K_LAB_ENV("T4K_GEMM_DUAL32", 1);
         auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };
         const long a1 = t32(E0, E1), a2 = t32(N, E1), ar = (E0 + 63) / 64;
-        static int maxk = -1; if (maxk < 0) { const char *e = getenv("T4K_GEMM_DUAL32_MAXK"); maxk = e ? atoi(e) : 1024; }
-        if (s32 && a1 + ar + a2 <= cap4 - 32 && a1 <= 512 && N <= maxk && E0 <= maxk && N <= 4096 && !capturing(hs)) {      // every workgroup resident (the gate spins); deep K stays with the staged kernels
+        // the gated (in-place dX) launch may hold more workgroups than fit the chip at 1-2 per CU (64*W threads, W*16 KiB of LDS): progress then rests on the
+        // dispatcher handing out workgroups in id order - the dW blocks [0, a1 + ar) never wait, the dX writers behind them wait only for those - so the
+        // id -> tile map stays the identity; a device that dispatches out of order ends in the bounded-spin error
+        if (s32 && g.d_zero && a1 + ar + a2 <= 4L * cu - 32 && a1 <= 512 && N <= 1024 && E0 <= 1024 && !capturing(hs)) {      // a wave walks at most four 32-deep blocks; deeper K stays with the staged kernels
             GemmP q1, q2;
             auto fill32 = [&](GemmP &p, const float *A, const float *B, float *O, int M, int Nn, int K, float beta) {
                 p.A = A; p.B = B; p.bias = nullptr; p.O = O; p.part = nullptr; p.M = M; p.N = Nn; p.K = K; p.C = 1;
                 p.tiles_m = (M + 31) / 32; p.tiles_n = (Nn + 31) / 32; p.kchunk = K; p.nsplit = 1;
-                p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0; p.xmap = 0; p.Z = nullptr;
+                p.alpha = 1.0f; p.beta = beta; p.pair = 0; p.sync = g.d_sync; p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0; p.xmap = 0; p.Z = g.d_zero;
             };
             fill32(q1, DY, X, DW, E0, E1, N, 1.0f);
             q1.cs_X = DY; q1.cs_out = DB; q1.cs_rows = N; q1.cs_E = E0;
@@ -2308,26 +2004,13 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
             // arrival slots: ints [512, 1024) of the stream's gate block; the epoch is this stream's launch count (never 0, slots cleared when it wraps)
             unsigned *slots = reinterpret_cast<unsigned *>(gate_for(hs, 0)) + 512;
             const unsigned epoch = next_slot_epoch(hs, slots);     // the lane's ONE counter, shared with k_head_bwd_l32 (t4k_common.h)
-            static int l32d = -1; if (l32d < 0) { const char *e = getenv("T4K_GEMM_DUAL_L32"); l32d = e ? atoi(e) : 1; }
-            if (l32d && g.d_zero && N <= 1024 && E0 <= 1024 && (a1 > 128 || (N <= 512 && E0 <= 512))) {   // coalesced operand blocks through LDS-DMA; a wave walks at most four 32-deep blocks
-                q1.Z = q2.Z = g.d_zero;
-                static int xm = -1; if (xm < 0) { const char *e = getenv("T4K_GEMM_XMAP"); xm = e ? atoi(e) : 0; }   // measured: no effect on the GAN layers (the Infinity Cache serves all eight L2s), off
-                // The gated (in-place dX) launch may hold more workgroups than fit the chip at 1-2 per CU (64*W threads, W*16 KiB of LDS): progress then rests on the
-                // dispatcher handing out workgroups in id order - the dW blocks [0, a1 + ar) never wait, the dX writers behind them wait only for those - so the
-                // id -> tile map stays the identity whenever the gate is in use; a device that dispatches out of order ends in the bounded-spin error
-                if (xm && !alias32) { q1.xmap = a1 >= 16 ? (E1 >= E0 ? 2 : 1) : 0; q2.xmap = a2 >= 16 ? (E1 >= N ? 2 : 1) : 0; }
-                const dim3 gd((unsigned)(a1 + ar + a2));
+            const dim3 gd((unsigned)(a1 + ar + a2));
 #define T4K_DL32(R_, W_) do { static bool attr_done = false; \
-                    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_dual_l32<R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, W_ * 16384); attr_done = true; } \
-                    T4K_LAUNCH((k_gemm_dual_l32<R_, W_>), gd, dim3(64 * W_), (size_t)W_ * 16384, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32); } while (0)
-                static int nw8d = -1; if (nw8d < 0) { const char *e = getenv("T4K_GEMM_DUAL_L32_NW8"); nw8d = e ? atoi(e) : 1; }
-                if ((N > 512 || E0 > 512) && nw8d) T4K_DL32(true, 8);      // deep K: 8 k-groups (per-workgroup arrival slots: a1 > 128)
-                else if (N > 256 || E0 > 256) T4K_DL32(true, 4); else T4K_DL32(false, 4);
+                if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_dual_l32<R_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, W_ * 16384); attr_done = true; } \
+                T4K_LAUNCH((k_gemm_dual_l32<R_, W_>), gd, dim3(64 * W_), (size_t)W_ * 16384, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32); } while (0)
+            if (N > 512 || E0 > 512) T4K_DL32(true, 8);            // deep K: 8 k-groups (one arrival slot per workgroup)
+            else if (N > 256 || E0 > 256) T4K_DL32(true, 4); else T4K_DL32(false, 4);
 #undef T4K_DL32
-                return true;
-            }
-            if (a1 + ar + a2 <= cap - 32) T4K_LAUNCH(k_gemm_dual32<8>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
-            else                     T4K_LAUNCH(k_gemm_dual32<4>, dim3((unsigned)(a1 + ar + a2)), dim3(256), 0, hs, q1, q2, (int)(a1 + ar), (int)a1, (int)a2, alias32 ? slots : nullptr, epoch, mc32);
             return true;
         }
     }
@@ -2341,7 +2024,7 @@ bool linear_bwd_dual(const float *X, const float *W, const float *DY, float *DX,
     p1.cs_X = DY; p1.cs_out = DB; p1.cs_rows = N; p1.cs_E = E0;
     fill(p2, DY, W, DX, N, E1, E0, 0.0f);                    // A = dY ([M][K]), B = W ([K][N])
     constexpr size_t lds_bytes = (size_t)2 * (64 + 64) * 64 * sizeof(float);
-    static int dfk = -1; if (dfk < 0) { const char *e = getenv("T4K_GEMM_DUAL_FULLK"); dfk = e ? atoi(e) : 1; }
+    static const int dfk = T4K_LAB_ENV("T4K_GEMM_DUAL_FULLK", 1);
     const bool f1 = dfk && N % 64 == 0 && E0 >= 4 && E1 >= 4, f2 = dfk && E0 % 64 == 0 && E1 >= 4;
     const dim3 grid((unsigned)(t1 + riders + t2));
     const bool alias = (const float *)DX == X || (const float *)DX == DY || (const float *)DX == W;   // only an in-place dX needs the arrival gate
@@ -2374,11 +2057,11 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     p.tiles_m = (M + BMv - 1) / BMv; p.tiles_n = (N + BMv - 1) / BMv;
     const long tiles = (long)p.tiles_m * p.tiles_n;
 
-    // Slivers (the output gives at most half the CUs a 64x64 tile, K moderate): 32x32 tiles with operands fetched straight into
-    // registers, the whole epilogue (bias, activation riders, mask chain, layer-0 copy, column sums) in the same launch - no fold
+    // Slivers (the output gives at most half the CUs a 64x64 tile, K moderate): 32x32 tiles, K split over the waves, operand blocks through
+    // LDS-DMA, the whole epilogue (bias, activation riders, mask chain, layer-0 copy, column sums) in the same launch - no fold
     {
-        static int s32 = -1; if (s32 < 0) { const char *e = getenv("T4K_GEMM_S32"); s32 = e ? atoi(e) : 1; }
-        static int maxk = -1; if (maxk < 0) { const char *e = getenv("T4K_GEMM_S32_MAXK"); maxk = e ? atoi(e) : 832; }   // measured: 256 x 512 x K wins up to K = 784 (7.6 vs 10.6 us at 512), loses at 1024 (12.8 vs 10.7 us split-K + fold)
+        static const int s32 = T4K_LAB_ENV("T4K_GEMM_S32", 1);
+        static const int maxk = T4K_LAB_ENV("T4K_GEMM_S32_MAXK", 832);   // measured: 256 x 512 x K wins up to K = 784 (7.6 vs 10.6 us at 512), loses at 1024 (12.8 vs 10.7 us split-K + fold)
         const bool akc = !tA, bkc = tB != 0;
         const bool al = (!akc || (K % 4 == 0 && aligned16(A))) && (!bkc || (K % 4 == 0 && aligned16(B)));
         const long t32 = (long)((M + 31) / 32) * ((N + 31) / 32);
@@ -2388,7 +2071,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             if (want > 1) { kc = (((K + want - 1) / want) + 7) / 8 * 8; ns = (K + kc - 1) / kc; }
             if ((size_t)ns * M * N * sizeof(float) > st().ws_bytes / 2) { ns = 1; kc = ((K + 7) / 8) * 8; }
         }
-        if (s32 && C == 1 && !big && tiles * 2 <= st().cu_count && K >= 1 && kc <= maxk && al && !capturing(S(s))) {   // kc: depth one workgroup walks
+        // operands through LDS-DMA blocks: every 16-byte DMA lane aligned and whole (other shapes: the 64x64 kernels below)
+        const bool dma_ok = st().d_zero && aligned16(A) && aligned16(B) && (akc ? K % 4 == 0 : M % 4 == 0) && (bkc ? K % 4 == 0 : N % 4 == 0);
+        if (s32 && C == 1 && !big && tiles * 2 <= st().cu_count && K >= 1 && kc <= maxk && al && dma_ok && !capturing(S(s))) {   // kc: depth one workgroup walks
             hipStream_t hs2 = S(s);
             p.tiles_m = (M + 31) / 32; p.tiles_n = (N + 31) / 32;
             p.kchunk = kc; p.nsplit = ns; p.pair = 0; p.sync = st().d_sync;
@@ -2417,12 +2102,9 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
                 }
             } else { defer->part = p.part; defer->nsplit = ns; defer->mn = mn; }
             const dim3 g32(gx, (unsigned)ns);
-            static int nw8 = -1; if (nw8 < 0) { const char *e = getenv("T4K_GEMM_S32_NW8"); nw8 = e ? atoi(e) : 1; }
-            // operands through LDS-DMA blocks (k_gemm_l32) when every 16-byte DMA lane is aligned and whole: coalesced fetch instead of row gathers
-            static int l32 = -1; if (l32 < 0) { const char *e = getenv("T4K_GEMM_L32"); l32 = e ? atoi(e) : 1; }
-            if (l32 && st().d_zero && aligned16(A) && aligned16(B) && (akc ? K % 4 == 0 : M % 4 == 0) && (bkc ? K % 4 == 0 : N % 4 == 0)) {
+            {
                 p.Z = st().d_zero;
-                static int xm = -1; if (xm < 0) { const char *e = getenv("T4K_GEMM_XMAP"); xm = e ? atoi(e) : 0; }   // measured: no effect on the GAN layers (the Infinity Cache serves all eight L2s), off
+                static const int xm = T4K_LAB_ENV("T4K_GEMM_XMAP", 0);   // measured: no effect on the GAN layers (the Infinity Cache serves all eight L2s), off
                 p.xmap = (xm && t32 >= 16) ? (N >= M ? 2 : 1) : 0;       // XCD-aware tile order: an XCD's L2 pulls its own slice of the wider operand only
                 const int nblk = (kc + 31) / 32;
                 // waves per workgroup (= k-groups) and whether a wave walks more than two blocks (RST: blocks 2, 3 wait in registers)
@@ -2435,20 +2117,12 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
                 T4K_LAUNCH_CHECK();
                 return T4K_OK;
             }
-#define T4K_S32(A_, B_) do { if (t32 * ns > 2L * st().cu_count) T4K_LAUNCH((k_gemm_s32<A_, B_, 4>), g32, dim3(256), 0, hs2, p, ep, fr); \
-                             else if (nw8 && kc >= 384)          T4K_LAUNCH((k_gemm_s32<A_, B_, 8, 8>), g32, dim3(512), 0, hs2, p, ep, fr);   /* deep k per slab: 8 k-groups */ \
-                             else                                T4K_LAUNCH((k_gemm_s32<A_, B_, 8>), g32, dim3(256), 0, hs2, p, ep, fr); } while (0)
-            if (akc && !bkc) T4K_S32(true, false); else if (akc) T4K_S32(true, true); else if (!bkc) T4K_S32(false, false); else T4K_S32(false, true);
-#undef T4K_S32
-            T4K_LAUNCH_CHECK();
-            return T4K_OK;
         }
     }
     {   // 65..128 interior tiles, K in whole 256s: two workgroups per tile on the lean kernel, combined in its epilogue (k_gemm_nn_plain<.., PAIR>) -
         // 512 x 1024 x 1024: one launch instead of split-K slabs + a fold launch.  Tickets are per tile: default stream only.
-        static int ppair = -1; if (ppair < 0) { const char *e = getenv("T4K_GEMM_PLAIN_PAIR"); ppair = e ? atoi(e) : 1; }
-        const int var0 = gemm_variant();
-        if (ppair && gates_ok() && !big && vec && C == 1 && (var0 & 4) && (var0 & 16) && (var0 & 32) && !(var0 & 64) && M % 64 == 0 && N % 64 == 0 && K % 256 == 0 && K >= 512 &&
+        static const int ppair = T4K_LAB_ENV("T4K_GEMM_PLAIN_PAIR", 1);
+        if (ppair && gates_ok() && !big && vec && C == 1 && M % 64 == 0 && N % 64 == 0 && K % 256 == 0 && K >= 512 &&
             tiles * 2 <= st().cu_count && tiles * 3 > st().cu_count && tiles <= 2048 && !defer && !(epi && epi->layer) && !rider && !cs &&
             st().d_sync && lane_of(S(s)) == 0 && (size_t)tiles * 4096 * sizeof(float) <= st().ws_bytes / 2 &&
             (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
@@ -2463,7 +2137,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     int nsplit = 1, kchunk = ((K + KG - 1) / KG) * KG; if (kchunk == 0) kchunk = KG;
     if (!big && C == 1 && tiles * 2 <= st().cu_count && K >= 4 * KG) {
         int want = (int)((st().cu_count + tiles - 1) / tiles);
-        static int sdiv = -1; if (sdiv < 0) { const char *e = getenv("T4K_GEMM_SPLIT_DIV"); sdiv = e ? atoi(e) : 1; if (sdiv < 1) sdiv = 1; }
+        static const int sdiv = std::max(1, T4K_LAB_ENV("T4K_GEMM_SPLIT_DIV", 1));
         int maxs = K / (sdiv * KG); if (want > maxs) want = maxs; if (want > 64) want = 64;
         if (want > 1) {
             kchunk = (((K + want - 1) / want) + KG - 1) / KG * KG;
@@ -2471,56 +2145,49 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
             if ((size_t)nsplit * M * N * sizeof(float) > st().ws_bytes / 2) { nsplit = 1; kchunk = ((K + KG - 1) / KG) * KG; }
         }
     }
-    const int var = gemm_variant();
-    // pair mode (variant bit 3): an interior 64x64-tiled problem that gives each CU at most one workgroup is split in
-    // two K halves combined in the epilogue => 2 workgroups (8 waves) per CU hide each other's LDS / barrier stalls
     p.pair = 0; p.sync = st().d_sync;
-    if (gates_ok() && !big && vec && nsplit == 1 && C == 1 && (var & 4) && (var & 8) && p.sync && lane_of(S(s)) == 0 && tiles <= st().cu_count && tiles <= 2048 &&   // tickets are per tile, not per stream: default stream only
-        M % 64 == 0 && N % 64 == 0 && K % 128 == 0 && K >= 256 && (size_t)tiles * 4096 * sizeof(float) <= st().ws_bytes / 2) {
-        p.pair = 1; nsplit = 2; kchunk = K / 2;
-    }
     p.kchunk = kchunk; p.nsplit = nsplit;
 
     dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)C);
     hipStream_t hs = S(s);
     // ragged M / N with whole K stages on the 8-wave LDS-DMA kernel (clamped source rows, predicated stores) when the K loop is long enough
     // to matter: unsplit products (N = 1000 classes: 1024 x 1000 x 4096 122 -> measured below) - split slivers stay with the skewed kernel
-    static int rag = -1; if (rag < 0) { const char *e = getenv("T4K_GEMM_RAGGED_DMA"); rag = e ? atoi(e) : 1; }
-    const bool ragged8 = rag && !big && vec && C == 1 && nsplit == 1 && !p.pair && (var & 4) && (var & 16) && (M % 64 != 0 || N % 64 != 0) &&
+    static const int rag = T4K_LAB_ENV("T4K_GEMM_RAGGED_DMA", 1);
+    const bool ragged8 = rag && !big && vec && C == 1 && nsplit == 1 && (M % 64 != 0 || N % 64 != 0) &&
                          kchunk % 64 == 0 && K % kchunk == 0 && M >= 4 && N >= 4 &&
                          (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);
     // ragged K (784 = 28 x 28, the GAN layer width; any K when no operand is K-contiguous): the same kernel with a partial last stage
     // (k_gemm_glds8<.., RAGK>) instead of the predicated register-staged one (1024 x 1024 x 784: 28.5 us there).  T4K_GEMM_RAGGED_K: 0 off,
     // 1 unsplit products (default), 2 split-K slabs too
-    static int ragk_on = -1; if (ragk_on < 0) { const char *e = getenv("T4K_GEMM_RAGGED_K"); ragk_on = e ? atoi(e) : 1; }
-    const bool ragk = ragk_on && !big && vec && C == 1 && !p.pair && (var & 4) && (var & 16) && !(kchunk % 64 == 0 && K % kchunk == 0) &&
+    static const int ragk_on = T4K_LAB_ENV("T4K_GEMM_RAGGED_K", 1);
+    const bool ragk = ragk_on && !big && vec && C == 1 && !(kchunk % 64 == 0 && K % kchunk == 0) &&
                       (nsplit == 1 || ragk_on >= 2) && M >= 4 && N >= 4 && K >= 8 &&
                       (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);
     p.cs_X = nullptr; p.cs_out = nullptr; p.cs_rows = 0; p.cs_E = 0;
     {   // column-sum rider: only the generic kernel carries it, and only when one workgroup per tile writes the output
         const bool full64 = !big && vec && M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
-        const bool generic = big || !vec || !((full64 || ragged8 || ragk) && (var & 4));
+        const bool generic = big || !vec || !(full64 || ragged8 || ragk);
         if (cs && generic && nsplit == 1 && C == 1 && cs->rows > 0 && cs->rows <= 4096 && cs->E > 0) {
             p.cs_X = cs->X; p.cs_out = cs->out; p.cs_rows = cs->rows; p.cs_E = cs->E; cs->done = true;
             grid.x += (unsigned)((cs->E + 63) / 64);
         }
     }
-    static int plain_big = -1; if (plain_big < 0) { const char *e = getenv("T4K_GEMM_PLAIN_BIG"); plain_big = e ? atoi(e) : 1; }
+    static const int plain_big = T4K_LAB_ENV("T4K_GEMM_PLAIN_BIG", 1);
     // interior tiles, unsplit, K >= 128 with a partial last stage: the lean kernel with a tail (any size of output)
-    static int pragk = -1; if (pragk < 0) { const char *e = getenv("T4K_GEMM_PLAIN_RAGK"); pragk = e ? atoi(e) : 2; }   // 0 off (the general kernel's tail), 1 only K % 64 != 0, 2 (default) every K % 128 != 0 (K = 960: 18.9 vs 19.6 us on the 64-deep general kernel)
+    static const int pragk = T4K_LAB_ENV("T4K_GEMM_PLAIN_RAGK", 2);   // 0 off (the general kernel's tail), 1 only K % 64 != 0, 2 (default) every K % 128 != 0 (K = 960: 18.9 vs 19.6 us on the 64-deep general kernel)
     // T4K_GEMM_PLAIN128: 0 off, 1 (default) where it wins, 2 every eligible shape (tests).  A workgroup per CU at a time either way, so the
     // choice is wave quantisation: tiles / (rounds x CUs) of each tiling, the 128x128 pipeline being ~3.5 % faster per FLOP (2048^3: 136 -> 131 us)
-    static int p128 = -1; if (p128 < 0) { const char *e = getenv("T4K_GEMM_PLAIN128"); p128 = e ? atoi(e) : 1; }
-    static int p128rag = -1; if (p128rag < 0) { const char *e = getenv("T4K_GEMM_PLAIN128_RAGK"); p128rag = e ? atoi(e) : 1; }   // 0: a partial last K stage keeps the product on 64x64 tiles
+    static const int p128 = T4K_LAB_ENV("T4K_GEMM_PLAIN128", 1);
+    static const int p128rag = T4K_LAB_ENV("T4K_GEMM_PLAIN128_RAGK", 1);   // 0: a partial last K stage keeps the product on 64x64 tiles
     auto fill_of = [](long tiles_, long cu_) { return (double)tiles_ / (double)(((tiles_ + cu_ - 1) / cu_) * cu_); };
     const long t128i = (long)(M / 128) * (N / 128), t64i = (long)((M + 63) / 64) * ((N + 63) / 64);
-    if (p128 > 0 && vec && C == 1 && nsplit == 1 && !p.pair && !p.cs_X && (var & 4) && (var & 16) && (var & 32) && !(var & 64) && M % 128 == 0 && N % 128 == 0 && (K % 64 == 0 || (p128rag && ragk_on && K % 4 == 0)) && K >= 256 &&
+    if (p128 > 0 && vec && C == 1 && nsplit == 1 && !p.cs_X && M % 128 == 0 && N % 128 == 0 && (K % 64 == 0 || (p128rag && ragk_on && K % 4 == 0)) && K >= 256 &&
         (p128 >= 2 || (t128i >= st().cu_count && fill_of(t128i, st().cu_count) * 1.035 > fill_of(t64i, st().cu_count))) &&
         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
         p.kchunk = K;
         launch_plain128(p, tA, tB, hs);
     } else
-    if (pragk && ragk_on && vec && C == 1 && nsplit == 1 && !p.pair && !p.cs_X && (var & 4) && (var & 16) && (var & 32) && !(var & 64) && M % 64 == 0 && N % 64 == 0 &&
+    if (pragk && ragk_on && vec && C == 1 && nsplit == 1 && !p.cs_X && M % 64 == 0 && N % 64 == 0 &&
         K > 128 && K % 128 != 0 && (pragk >= 2 || K % 64 != 0) &&
         (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32)) {
         p.kchunk = K;
@@ -2540,7 +2207,7 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
         const dim3 g64((unsigned)(p.tiles_m * p.tiles_n), 1, 1);
         if (K % 128 == 0) launch_glds8<128>(p, g64, tA, tB, hs); else launch_glds8<64>(p, g64, tA, tB, hs);
     } else if (big) {
-        static int bigfk = -1; if (bigfk < 0) { const char *e = getenv("T4K_GEMM_BIG_FULLK"); bigfk = e ? atoi(e) : 1; }
+        static const int bigfk = T4K_LAB_ENV("T4K_GEMM_BIG_FULLK", 1);
         // whole K stages are enough for the predicate-free pipeline: ragged M / N edges are clamped source rows + predicated stores
         const bool full = vec && kchunk % 32 == 0 && K % kchunk == 0 && M >= 4 && N >= 4 && (bigfk || (M % 128 == 0 && N % 128 == 0));
         if (full)     launch_variant<128, 128, 32, true, true, true>(p, grid, tA, tB, hs);
@@ -2551,36 +2218,27 @@ int gemm_launch(const float *A, const float *B, float *O, const float *bias, flo
     } else {
         const bool full = M % 64 == 0 && N % 64 == 0 && kchunk % 64 == 0 && K % kchunk == 0;
         if (ragk) {
-            if ((var & 32) && K >= 128 && (nsplit == 1 || kchunk % 128 == 0)) launch_glds8_ragk<128>(p, grid, tA, tB, hs); else launch_glds8_ragk<64>(p, grid, tA, tB, hs);
+            if (K >= 128 && (nsplit == 1 || kchunk % 128 == 0)) launch_glds8_ragk<128>(p, grid, tA, tB, hs); else launch_glds8_ragk<64>(p, grid, tA, tB, hs);
         } else if (ragged8) {
-            if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs); else launch_glds8<64>(p, grid, tA, tB, hs);
-        } else if (full && (var & 4)) {
-            const bool span32 = (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);   // 32-bit DMA lane offsets
-            if ((var & 16) && !p.pair && span32) {
-                static int plany = -1; if (plany < 0) { const char *e = getenv("T4K_GEMM_PLAIN_ANY"); plany = e ? atoi(e) : 1; }
-                if ((var & 32) && kchunk % 128 == 0 && !tA && !tB && nsplit == 1 && alpha == 1.0f && beta == 0.0f && !bias && !(var & 64)) launch_nn_plain(p, grid, hs);   // `matmul`
-                else if (plany && (var & 32) && kchunk % 128 == 0 && nsplit == 1 && !(var & 64)) launch_plain_any(p, grid, tA, tB, hs);   // the other layouts, alpha / beta / bias: the same lean kernel
-                else if ((var & 32) && kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs);   // bit5: 128-deep stages, 2 buffers
-                else if (var & 1) launch_glds8<64>(p, grid, tA, tB, hs); else launch_glds8<32>(p, grid, tA, tB, hs);
-            }
-            else if ((var & 1) && !p.pair) launch_glds<64>(p, grid, tA, tB, hs); else launch_glds<32>(p, grid, tA, tB, hs);   // pair: 2 x 48 KiB LDS per CU
+            if (kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs); else launch_glds8<64>(p, grid, tA, tB, hs);
         } else if (full) {
-            switch (var & 3) {
-            case 0:  launch_variant<64, 64, 32, true, false, true>(p, grid, tA, tB, hs); break;
-            case 1:  launch_variant<64, 64, 64, true, false, true>(p, grid, tA, tB, hs); break;
-            case 2:  launch_variant<64, 64, 32, true, true, true>(p, grid, tA, tB, hs); break;
-            default: launch_variant<64, 64, 64, true, true, true>(p, grid, tA, tB, hs); break;
-            }
+            const bool span32 = (size_t)M * K * sizeof(float) < ((size_t)1 << 32) && (size_t)K * N * sizeof(float) < ((size_t)1 << 32);   // 32-bit DMA lane offsets
+            static const int plany = T4K_LAB_ENV("T4K_GEMM_PLAIN_ANY", 1);
+            if (!span32) launch_variant<64, 64, 64, true, false, true>(p, grid, tA, tB, hs);          // operands of 4 GiB and more: the register-staged kernel (64-bit addresses)
+            else if (kchunk % 128 == 0 && !tA && !tB && nsplit == 1 && alpha == 1.0f && beta == 0.0f && !bias) launch_nn_plain(p, grid, hs);   // `matmul`
+            else if (plany && kchunk % 128 == 0 && nsplit == 1) launch_plain_any(p, grid, tA, tB, hs);   // the other layouts, alpha / beta / bias: the same lean kernel
+            else if (kchunk % 128 == 0) launch_glds8<128>(p, grid, tA, tB, hs);   // split-K slabs of whole 128-deep stages
+            else launch_glds8<64>(p, grid, tA, tB, hs);
         } else {
-            static int fk = -1; if (fk < 0) { const char *e = getenv("T4K_GEMM_FULLK"); fk = e ? atoi(e) : 0; }   // measured on the GAN nets: the skewed kernel is 1 % faster for ragged split-K shapes, off
+            static const int fk = T4K_LAB_ENV("T4K_GEMM_FULLK", 0);   // measured on the GAN nets: the skewed kernel is 1 % faster for ragged split-K shapes, off
             const int am = tA ? M : K, bn = tB ? K : N;     // the contiguous extents hold at least one 16-byte group (vec) - the clamp needs M, N >= 4 on the non-K-contiguous side
             if (fk && kchunk % 64 == 0 && K % kchunk == 0 && M >= 4 && N >= 4 && am >= 4 && bn >= 4) launch_variant<64, 64, 64, true, false, true>(p, grid, tA, tB, hs);   // ragged M / N, whole K stages
             else launch_variant<64, 64, 64, true, true, false>(p, grid, tA, tB, hs);
         }
     }
-    if (nsplit > 1 && !p.pair && defer && alpha == 1.0f && beta == 0.0f) {      // the consumer folds the slabs (fused head)
+    if (nsplit > 1 && defer && alpha == 1.0f && beta == 0.0f) {      // the consumer folds the slabs (fused head)
         defer->part = p.part; defer->nsplit = nsplit; defer->mn = (long)M * N;
-    } else if (nsplit > 1 && !p.pair) {
+    } else if (nsplit > 1) {
         const long mn = (long)M * N;
         ActEpi ep = {0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
         FoldRider fr = {ep, nullptr, nullptr, 0, 0, 0, MaskChain{nullptr, nullptr, nullptr, nullptr}, 0};
@@ -2708,7 +2366,7 @@ int t4k_mlp_head_fwd(const float *X, const float *W1, const float *B1, float *Y1
     T4K_REQUIRE_INIT();
     if (!X || !W1 || !Y1 || !F1 || !A1 || !W2 || !Y2 || N < 0) return fail(T4K_ERR_ARG, "t4k_mlp_head_fwd: bad argument");
     if (N == 0) return T4K_OK;
-    static int head_fold = -1; if (head_fold < 0) { const char *e = getenv("T4K_HEAD_FOLD"); head_fold = e ? atoi(e) : 1; }
+    static const int head_fold = T4K_LAB_ENV("T4K_HEAD_FOLD", 1);
     if (head_fold && !linear_small_ok(H, E1) && linear_small_ok(E2, H)) {
         XFold xf; xf.part = nullptr;
         int rc = gemm_launch(X, W1, Y1, B1, 1.0f, 0.0f, 0, 1, N, H, E1, 1, s, nullptr, nullptr, nullptr, &xf); if (rc) return rc;
@@ -2819,7 +2477,7 @@ static size_t head_bwd_lds(int N, int EA, int EB) {                // dynamic LD
 }
 int t4k_mlp_head_bwd_ok(int N, int E1, int EA, int EB) {
     if (!st().ready) return 0;
-    static int on = -1; if (on < 0) { const char *e = getenv("T4K_HEAD_BWD"); on = e ? atoi(e) : 1; }
+    static const int on = T4K_LAB_ENV("T4K_HEAD_BWD", 1);
     if (!on || st().capturing || !st().d_sync || !st().d_zero || !dual_on()) return 0;
     if (N < 1 || N > 256 || EA < 4 || EA > 256 || (EA & 3) || EB < 1 || EB > 16 || E1 < 4 || (E1 & 3)) return 0;
     auto t32 = [](int m, int n) { return (long)((m + 31) / 32) * ((n + 31) / 32); };

@@ -546,7 +546,7 @@ bool linear_small_ok(int E0, int E1) {
 int linear_small_fwd(const float *X, const float *W, const float *B, float *Y, float *P, int N, int E0, int E1, hipStream_t hs, const XFold *xfp, const ActEpi *oepp) {
     const ActEpi oep = oepp ? *oepp : ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}};
     XFold xf; if (xfp) xf = *xfp; else { xf.part = nullptr; xf.nsplit = 0; xf.mn = 0; xf.bias = nullptr; xf.Y = nullptr; xf.ep = ActEpi{0, 0.f, nullptr, nullptr, RngArg{0, 0, nullptr}}; }
-    static int thin = -1; if (thin < 0) { const char *e = getenv("T4K_LINTHIN"); thin = e ? atoi(e) : 1; }
+    static const int thin = T4K_LAB_ENV("T4K_LINTHIN", 1);
     if (thin && !xfp && !P && E0 <= 4 && N > 0) {             // thin head: a wave per row
         const int vec = (E1 % 4 == 0) && aligned16(X) && aligned16(W);
         T4K_LAUNCH(k_linthin_fwd, dim3((N + 3) / 4), dim3(256), 0, hs, X, W, B, Y, N, E0, E1, vec, oep);
@@ -581,13 +581,13 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
                       int N, int E0, int E1, bool train, hipStream_t hs, const float *MASK, float *DXM, const float *TGT, float *DY2,
                       const float *MASKB, float *DXMB) {
     {   // thin head (E0 <= 4): row-group workgroups, no arrival gate, the last one folds the dW | dB partials
-        static int thin = -1; if (thin < 0) { const char *e = getenv("T4K_LINTHIN"); thin = e ? atoi(e) : 1; }
+        static const int thin = T4K_LAB_ENV("T4K_LINTHIN", 1);
         constexpr int RA = 8;
         const int G = (N + RA - 1) / RA;
         const bool tr = train && DW;
         int *tk = gate_for(hs, 2);                               // ints 8.. of the stream's gate block: the ticket (zero between launches)
         float *part = ws_for(hs) ? ws_for(hs) + st().ws_bytes / 8 : nullptr;      // second half of the stream's workspace (transient column-sum partials; the first half may hold a conv stack's deferred dF partials)
-        static int tcw = -1; if (tcw < 0) { const char *e = getenv("T4K_LINTHIN_CW"); tcw = e ? atoi(e) : 8; }
+        static const int tcw = T4K_LAB_ENV("T4K_LINTHIN_CW", 8);
         if (thin && tr && tcw && E0 <= 4 && N >= 1 && N <= 1024 && DB && (!TGT || tk) && E1 >= 8) {          // trained: column stripes, nothing crosses workgroups
             const size_t ldsb = sizeof(float) * ((size_t)N * 4 + 256 * 4);
             if (tcw == 16) T4K_LAUNCH(k_linthin_bwd_cols<16>, dim3((E1 + 15) / 16), dim3(256), ldsb, hs, X, W, DY, DX, DW, DB, N, E0, E1, tk, MASK, DXM, TGT, const_cast<float *>(DY), DY2, MASKB, DXMB);
@@ -601,7 +601,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
         }
     }
     {   // column-sliced kernel: batches that fit LDS whole (N x (E0 + 16) floats), every output of dW in one thread (E0 x 16 <= 256)
-        static int cols_on = -1; if (cols_on < 0) { const char *e = getenv("T4K_LINSMALL_COLS"); cols_on = e ? atoi(e) : 1; }
+        static const int cols_on = T4K_LAB_ENV("T4K_LINSMALL_COLS", 1);
         const size_t ldsc = sizeof(float) * ((size_t)N * E0 + (size_t)E0 * LSC_CW + (size_t)N * LSC_CW + 256);
         int *gatec = TGT ? gate_for(hs, 0) : nullptr;            // the one shared counter (ints 0.. of the stream's gate block; zero between launches)
         const int nwg = (E1 + LSC_CW - 1) / LSC_CW;
@@ -626,7 +626,7 @@ bool linear_small_bwd(const float *X, const float *W, const float *DY, float *DX
     const bool alias = DX && nB > 0 && (const float *)DX == X;
     if (TGT && !alias && nB > 0) return false;                             // the in-place `out -= target` needs the arrival counters (unless no dW workgroup reads dY: frozen layer)
     State &g = st();
-    static int gate_on = -1; if (gate_on < 0) { const char *e = getenv("T4K_LINSMALL_GATE"); gate_on = e ? atoi(e) : 1; }
+    static const int gate_on = T4K_LAB_ENV("T4K_LINSMALL_GATE", 1);
     int *gate = gate_for(hs, 0);                                           // nullptr: a stream the library does not know -> no private counters
     if (alias && (nA + nB > g.cu_count || !g.d_sync || !gate || !gate_on || !gates_ok())) return false;   // the arrival counter needs every workgroup resident
     size_t lds = sizeof(float) * (size_t)(E0 * E1 + RA * E0);

@@ -326,7 +326,7 @@ static int opt_step_impl(int kind, const t4k_param_rec *tab_dev, const t4k_param
     unsigned long long skip = 0;
     int nfold = 0;
     if (g.pending & 1) {
-        static int on = -1; if (on < 0) { const char *e = getenv("T4K_OPT_FOLD"); on = e ? atoi(e) : 1; }
+        static const int on = T4K_LAB_ENV("T4K_OPT_FOLD", 1);
         bool ok = on && tab_dev && tab_host && kind >= 0 && kind <= 2 && n_tensors > 0 && n_tensors <= 64 && n_chunks > 0 && pf.hs == S(s) && !g.capturing;
         for (int q = 0; ok && q < pf.fa.nseg; q++) {              // every pending segment must be a whole gradient tensor of this table
             int hit = -1;

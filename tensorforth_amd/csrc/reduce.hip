@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(BLK) k_dbn_apply(const float *__restrict__ W, 
 // stage 1 of the chunked statistics: 16-byte loads where the tensors allow (T4K_BN_PART4=0: the scalar kernel)
 template <int MODE>
 static void launch_bn_part(const float *X, const float *Y, float *part, long NHW, int C, int rpc, long nch, hipStream_t hs) {
-    static int v4 = -1; if (v4 < 0) { const char *e = getenv("T4K_BN_PART4"); v4 = e ? atoi(e) : 1; }
+    static const int v4 = T4K_LAB_ENV("T4K_BN_PART4", 1);
     const bool vec = v4 && (C % 4) == 0 && ((((uintptr_t)X) | ((uintptr_t)(Y ? Y : X))) & 15) == 0;
     if (vec) T4K_LAUNCH(k_bn_part4<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, hs, X, Y, part, NHW, C, rpc);
     else     T4K_LAUNCH(k_bn_part<MODE>, dim3((unsigned)nch, (C + 63) / 64), dim3(BLK), 0, hs, X, Y, part, NHW, C, rpc);

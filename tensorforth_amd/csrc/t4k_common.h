@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
 #include "../../include/t4k.h"
 
 namespace t4k {
@@ -48,6 +50,15 @@ struct State {
 };
 State &st();
 inline bool gates_ok() { return !st().gates_off; }
+// Environment switches.  The RELEASE library reads a short, documented list through env_int / getenv; every engine-selection and
+// tuning knob the rounds accumulated (T4K_GEMM_*, T4K_CONV*, T4K_STACK_SPLIT ...) is a LAB switch: read only by the `make LAB=1` build
+// (libt4hip_lab.so, tools/experiments/*), a compile-time constant = the measured-best default in the release build.
+inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#ifdef T4K_LAB
+#define T4K_LAB_ENV(name, dflt) t4k::env_int(name, dflt)
+#else
+#define T4K_LAB_ENV(name, dflt) (dflt)
+#endif
 inline unsigned long thread_key() { static thread_local char k; return (unsigned long)(uintptr_t)&k; }   // cheap per-thread identity
 // every kernel launch of the library goes through this macro and is counted: bench.py prints the MEASURED launches per step
 #define T4K_LAUNCH(kernel, ...) do { ++t4k::st().launches; hipLaunchKernelGGLInternal((kernel), __VA_ARGS__); } while (0)

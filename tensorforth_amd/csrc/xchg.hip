@@ -143,7 +143,7 @@ XchgDev xchg_begin(bool generic) {
     const long base = (generic ? (long)2 * x.world * x.n : 0) + (long)(ep & 1) * x.world * per;
     for (int r = 0; r < x.world; r++) d.win[r] = x.win[r] + base;
     d.per = per;
-    static long ms = -1; if (ms < 0) { const char *e = getenv("T4K_XCHG_TIMEOUT_MS"); ms = e ? atol(e) : 20000; }   // how long a rank waits for a peer's element
+    static const long ms = t4k::env_int("T4K_XCHG_TIMEOUT_MS", 20000);   // how long a rank waits for a peer's element
     d.patience = (unsigned long long)ms * 100000ull;
     return d;
 }

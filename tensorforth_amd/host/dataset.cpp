@@ -149,7 +149,7 @@ static t4k_stream_t feed_stream() {
     if (!tried) { tried = true; if (t4k_stream_create_plain(&s) != T4K_OK) s = nullptr; }
     return s;
 }
-static const bool g_prefetch = getenv("T4_FEED_PREFETCH") ? atoi(getenv("T4_FEED_PREFETCH")) != 0 : true;
+static const bool g_prefetch = env_flag("T4_FEED_PREFETCH", true);
 void Dataset::release_ring() {
     for (int i = 0; i < RING; i++) {
         if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]);

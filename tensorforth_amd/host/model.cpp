@@ -99,13 +99,13 @@ Model &Model::add(int fn, uint32_t n, DU bias, uint16_t *opt) {
 Model *Model::current = nullptr;
 void (*Model::grad_hook)(int, long, long, void *) = nullptr;
 void *Model::grad_hook_user = nullptr;
-bool Model::use_fusion = getenv("T4_FUSE") ? atoi(getenv("T4_FUSE")) != 0 : true;
-bool Model::use_stack  = getenv("T4_STACK") ? atoi(getenv("T4_STACK")) != 0 : true;
-bool Model::use_head_bwd = getenv("T4_HEAD_BWD") ? atoi(getenv("T4_HEAD_BWD")) != 0 : true;    // classifier-head backward and the linear layer in front of it in ONE launch (round 6: k_head_bwd_l32, 9.7 us; T4_HEAD_BWD=0: head on column stripes + dual GEMM, 6.9 + 5.6 us)
-bool Model::use_stack_head = getenv("T4_STACK_HEAD") ? atoi(getenv("T4_STACK_HEAD")) != 0 : true;   // T4_STACK_HEAD=0: the classifier head behind a conv stack keeps its own launches
-bool Model::use_lazy_dx0 = getenv("T4_LAZY_DX0") ? atoi(getenv("T4_LAZY_DX0")) != 0 : true;
-bool Model::use_opt_fold = getenv("T4_OPT_FOLD") ? atoi(getenv("T4_OPT_FOLD")) != 0 : true;   // T4_OPT_FOLD=0: the conv stack's partial fold keeps its own launch behind the backward
-bool Model::use_graphs = getenv("T4_GRAPH") ? atoi(getenv("T4_GRAPH")) != 0 : false;
+bool Model::use_fusion = env_flag("T4_FUSE", true);
+bool Model::use_stack  = env_flag("T4_STACK", true);
+bool Model::use_head_bwd = env_flag("T4_HEAD_BWD", true);    // classifier-head backward and the linear layer in front of it in ONE launch (round 6: k_head_bwd_l32, 9.7 us; T4_HEAD_BWD=0: head on column stripes + dual GEMM, 6.9 + 5.6 us)
+bool Model::use_stack_head = env_flag("T4_STACK_HEAD", true);   // T4_STACK_HEAD=0: the classifier head behind a conv stack keeps its own launches
+bool Model::use_lazy_dx0 = env_flag("T4_LAZY_DX0", true);
+bool Model::use_opt_fold = env_flag("T4_OPT_FOLD", true);   // T4_OPT_FOLD=0: the conv stack's partial fold keeps its own launch behind the backward
+bool Model::use_graphs = env_flag("T4_GRAPH", false);
 bool Model::use_side   = getenv("T4_SIDE")  ? atoi(getenv("T4_SIDE"))  != 0 : false;
 
 // Lazy dX of the first layer.  `in = dx` (backprop.cu:185) leaves the gradient w.r.t. the input batch in layer 0 and in the first conv
@@ -302,7 +302,7 @@ Model &Model::forward(Tensor &input) {
 // data parallel: batch-norm statistics span all ranks during TRAINING passes only (every rank runs those in lock step); an
 // evaluation pass (`0 trainable`, possibly on one rank only) uses the rank's own statistics and issues no collective
 static void dp_bn_mode(bool train) {
-    static const bool want = getenv("T4_DP_SYNC_BN") ? atoi(getenv("T4_DP_SYNC_BN")) != 0 : true;
+    static const bool want = env_flag("T4_DP_SYNC_BN", true);
     if (t4k_comm_world() > 0) t4k_comm_sync_batchnorm(train && want);
 }
 void Model::run_forward(Tensor &input) {
@@ -614,8 +614,8 @@ Model &Model::backprop(Tensor &tgt) {
 // Off by default: with a one-rank communicator the two cross-stream edges on the main stream (RCCL's own ordering of the final
 // reduction behind the early one + the join) cost +16 us per step (0.129 -> 0.145 ms), about what hiding a 400 KB all-reduce
 // can win back on 8 GPUs - to be decided with measurements on an 8-GPU box.
-int  Model::dp_overlap = getenv("T4_DP_OVERLAP") ? atoi(getenv("T4_DP_OVERLAP")) : 0;       // 0 off, 1 on for world > 1, 2 also for a one-rank communicator (tests)
-long Model::dp_bucket  = getenv("T4_DP_BUCKET") ? atol(getenv("T4_DP_BUCKET")) : 16384;          // floats per early all-reduce (64 KiB)
+int  Model::dp_overlap = (int)env_long("T4_DP_OVERLAP", 0);       // 0 off, 1 on for world > 1, 2 also for a one-rank communicator (tests)
+long Model::dp_bucket  = env_long("T4_DP_BUCKET", 16384);          // floats per early all-reduce (64 KiB)
 void Model::grads_ready(int i, Tensor &in) {
     if (!(train && gslab && in.grad[2] && in.grad[3] && !in.grad[2]->owns)) return;
     const long off = (long)(in.grad[2]->data - gslab->data);
@@ -631,7 +631,7 @@ void Model::dp_flush() {
     if (!comm_s_) { chk(t4k_stream_create(&comm_s_), "comm stream"); t4k_event_create(&dp_ev_[0]); t4k_event_create(&dp_ev_[1]); }
     t4k_event_record(dp_ev_[0], stream()); t4k_stream_wait_event(comm_s_, dp_ev_[0]);            // the range is complete on the main stream
     chk(t4k_allreduce_sum(gslab->data + dp_pend_lo_, dp_done_lo_ - dp_pend_lo_, comm_s_), "allreduce (overlapped)");
-    static const bool tr = getenv("T4_DP_TRACE") != nullptr;
+    static const bool tr = env_long("T4_DP_TRACE", 0) != 0;
     if (tr) fprintf(stderr, "dp: early all-reduce of slab [%ld, %ld)\n", dp_pend_lo_, dp_done_lo_);
     dp_done_lo_ = dp_pend_lo_; dp_busy_ = true;
 }
@@ -649,7 +649,7 @@ void Model::dp_begin_backward() {
     dp_done_lo_ = dp_pend_lo_ = numel;
 }
 // T4_DP_XCHG=0: the slab is all-reduced by a collective of its own (RCCL, or the exchange's generic kernel) in front of the optimizer
-static const bool use_xchg = getenv("T4_DP_XCHG") ? atoi(getenv("T4_DP_XCHG")) != 0 : true;
+static const bool use_xchg = env_flag("T4_DP_XCHG", true);
 void Model::dp_finish() {                                // before the update: reduce what is left, join the communication stream
     dp_in_opt_ = false;
     if (!gslab || (t4k_comm_world() <= 0 && !t4k_xchg_active())) return;
@@ -661,7 +661,7 @@ void Model::dp_finish() {                                // before the update: r
         return;
     }
     if (rest > 0) chk(t4k_allreduce_sum(gslab->data, rest, stream()), "allreduce");
-    static const bool tr = getenv("T4_DP_TRACE") != nullptr;
+    static const bool tr = env_long("T4_DP_TRACE", 0) != 0;
     if (tr) fprintf(stderr, "dp: final all-reduce of slab [0, %ld) of %ld\n", rest, numel);
     if (dp_busy_) { t4k_event_record(dp_ev_[1], comm_s_); t4k_stream_wait_event(stream(), dp_ev_[1]); dp_busy_ = false; }
     dp_done_lo_ = dp_pend_lo_ = -1; dp_mixed_ = false;
@@ -845,7 +845,7 @@ const float *Model::bstep(int i, Tensor &in, Tensor &out, const float *dy, bool 
                 // discriminator: linear, leakyrelu, dropout, linear, leakyrelu, dropout, linear, sigmoid) - t4k_mlp_block_bwd, see t4k_mlp_head_bwd
                 // (measured on the GAN nets, N = 256, 256-wide runs: 28.5 us against 9 + 11.7 us apart - re-reading two 256 KB masks per tile costs more than
                 // reading the finished dY1; opt-in with T4_HEAD_BWD=2)
-                static const bool runs_too = getenv("T4_HEAD_BWD") && atoi(getenv("T4_HEAD_BWD")) >= 2;
+                static const bool runs_too = env_long("T4_HEAD_BWD", 1) >= 2;
                 if (tg && use_head_bwd && runs_too && i >= 3 && at(i - 3).grad_fn == T4K_L_LINEAR && (!train || (at(i - 3).grad[2] && at(i - 3).grad[3]))) {
                     Tensor &big = at(i - 3);
                     const Run *r1 = nullptr;

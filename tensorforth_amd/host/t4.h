@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <functional>
@@ -18,6 +19,9 @@
 #include "../../include/t4k.h"
 
 namespace t4 {
+// Environment switches of the host (the documented list: DESIGN.md section 9) are read through these two helpers
+inline bool env_flag(const char *name, bool dflt) { const char *e = getenv(name); return e ? atoi(e) != 0 : dflt; }
+inline long env_long(const char *name, long dflt) { const char *e = getenv(name); return e ? atol(e) : dflt; }
 
 typedef float DU;
 constexpr DU DU_EPS = 1.0e-6f;
@@ -300,7 +304,7 @@ private:
     static bool use_fusion;                    // T4_FUSE=0 keeps one launch per layer
     std::vector<char> stack_fresh_;            // per first-op index: the latest forward took the stack kernel (so what it saved for the backward is current)
     std::vector<int> stack_end_;              // last op of a conv stack -> its first op (run_backward), rebuilt after finalize
-    bool stack_single_ = getenv("T4_STACK_SINGLE") ? atoi(getenv("T4_STACK_SINGLE")) != 0 : true;    // single-stage stacks too (round 3: slower, off; round 4, with the lazy first-layer dX and the fold inside the optimizer: the t4_40a net nn_c 0.0637 -> 0.0459 ms per step at N = 128)
+    bool stack_single_ = true;    // single-stage stacks too (round 3: slower, off; round 4, with the lazy first-layer dX and the fold inside the optimizer: the t4_40a net nn_c 0.0637 -> 0.0459 ms per step at N = 128)
     static bool use_head_bwd;                  // T4_HEAD_BWD=0: head backward and the linear layer in front of it as separate launches
     int also_ready_ = -1;                      // a second layer whose gradients the last bstep launch produced (run_backward reports it)
     static bool use_stack_head;                // T4_STACK_HEAD=0: conv stack and classifier head as separate launches

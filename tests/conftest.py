@@ -41,6 +41,6 @@ def oracle():
 def t4k():
     """The product library, initialised on cuda:0.  Fails loudly (no fallback)."""
     from tensorforth_amd.lib import load
-    h = load()
+    h = load(os.environ.get("T4K_LIB") or None)          # T4K_LIB: the LAB library (tests/test_gpu_switches.py lab matrix)
     h.init(0)
     return h

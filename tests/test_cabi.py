@@ -63,6 +63,19 @@ def test_release_library_has_no_lab_switches():
         assert name + b"\0" not in blob, name               # as a C string of its own (what getenv would be handed); comments of the embedded source may mention it
     assert b"#define CS_LAB_" not in blob
     assert b"defined(CS_LAB_NOW1)" in blob                    # (the embedded device source keeps the guarded text; nothing can define the macro)
+    # round 6: the engine-selection / tuning knobs (T4K_LAB_ENV, csrc/t4k_common.h) are compile-time constants of the release build
+    for name in (b"T4K_GEMM_S32", b"T4K_GEMM_DUAL", b"T4K_GEMM_PLAIN128", b"T4K_CONVBIG8", b"T4K_CONV_THIN", b"T4K_STACK_SPLIT", b"T4K_LINTHIN", b"T4K_HB_LAB", b"T4K_GEMM_VARIANT"):
+        assert name + b"\0" not in blob, name
+    # ... and the release libraries read a short documented list: every T4K_* / T4_* name they hold as a C string
+    import re
+    names = set(re.findall(rb"\0(T4K?_[A-Z0-9_]{3,})\0", blob + open(os.path.join(ROOT, "tensorforth_amd", "libten4.so"), "rb").read()))
+    names = {n.decode() for n in names if not n.startswith((b"T4K_ERR", b"T4K_L_", b"T4K_OK", b"T4K_OP"))}
+    documented = {"T4K_RCCL_PATH", "T4K_XCHG_TIMEOUT_MS", "T4K_CACHE_DIR", "T4K_STACK_JIT", "T4K_STACK_DISK_CACHE",
+                  "T4_FUSE", "T4_STACK", "T4_HEAD_BWD", "T4_STACK_HEAD", "T4_LAZY_DX0", "T4_OPT_FOLD", "T4_GRAPH", "T4_SIDE", "T4_FEED_PREFETCH",
+                  "T4_DP_SYNC_BN", "T4_DP_OVERLAP", "T4_DP_BUCKET", "T4_DP_TRACE", "T4_DP_XCHG", "T4_TB_FIXED_TIME", "T4_TB_LOGDIR", "T4_TB_RUN",
+                  "T4_DEVICE", "T4_SEED", "T4_SLAB_MB", "T4_HOLD_WARN"}
+    assert names <= documented, sorted(names - documented)
+    assert len(documented) <= 30
 
 
 def test_conv_stack_code_objects_are_cached_on_disk(tmp_path):

@@ -77,11 +77,11 @@ bye
 
 
 def test_reader_thread_never_touches_the_deferred_fold(corpus):
-    """the conv stack's backward leaves its dF | dB fold to the optimizer launch (T4K_OPT_FOLD=1, default) while the feed's reader thread
+    """the conv stack's backward leaves its dF | dB fold to the optimizer launch (T4_OPT_FOLD=1, default) while the feed's reader thread
     waits on events through the C-ABI.  That thread must neither run the fold a second time nor clear the bit: 44 dataset-fed steps with the fold
-    inside the optimizer launch print bit for bit what the stand-alone fold (T4K_OPT_FOLD=0) prints, repeatedly (the race was intermittent)."""
-    want = run_vm(TEN4, source=TRAIN, seed=5, cwd=corpus, env_extra={"T4K_OPT_FOLD": "0"})
+    inside the optimizer launch print bit for bit what the stand-alone fold (T4_OPT_FOLD=0) prints, repeatedly (the race was intermittent)."""
+    want = run_vm(TEN4, source=TRAIN, seed=5, cwd=corpus, env_extra={"T4_OPT_FOLD": "0"})
     assert "w0" in want and "?" not in want.replace("-> ok", ""), want[-600:]
     for rep in range(6):
-        got = run_vm(TEN4, source=TRAIN, seed=5, cwd=corpus, env_extra={"T4K_OPT_FOLD": "1"})
+        got = run_vm(TEN4, source=TRAIN, seed=5, cwd=corpus, env_extra={"T4_OPT_FOLD": "1"})
         assert compare(got, want, rtol=0, atol=0) == [], rep

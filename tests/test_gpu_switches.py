@@ -1,7 +1,7 @@
 """GPU: the non-default dispatch paths of the GEMM / linear kernels cannot rot, and the gated one-launch kernels survive a busy device.
 
-* every `T4K_GEMM_*` / head switch (csrc/gemm.hip, linear_small.hip) is flipped in a process of its own and the integer-exact products
-  are re-run: plain / transposed / alpha-beta GEMMs incl. ragged and sliver shapes, and the linear layer both ways (forward with bias,
+* the integer-exact products run on the default dispatch, with the gated kernels switched off, and (LAB library, opt-in) under every
+  `T4K_GEMM_*` / head LAB switch (csrc/gemm.hip, linear_small.hip), each in a process of its own: plain / transposed / alpha-beta GEMMs incl. ragged and sliver shapes, and the linear layer both ways (forward with bias,
   backward dW += dY^T X, dB += column sums, dX = dY W written IN PLACE over X - the arrival-gate path) - entries in {-2..2} keep every
   fp32 sum exact, so whatever kernel the switch selects must reproduce numpy's integer result bit for bit;
 * the same set runs while a bandwidth-hogging elementwise kernel chain occupies the device on another stream (the situation of a
@@ -21,7 +21,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.environ["T4_ROOT"])
 import numpy as np, torch
 from tensorforth_amd.lib import load
-k = load(); k.init(0)
+k = load(os.environ.get("T4K_LIB") or None); k.init(0)
+if os.environ.get("GATES_OFF") == "1": k.lib.t4k_gates_enable(0)
 k.call("t4k_set_default_stream", None)
 p = lambda t: t.data_ptr()
 up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -70,12 +71,19 @@ print("FAILS", fails)
 sys.exit(1 if fails else 0)
 '''
 
-SWITCHES = [{}, {"T4K_GEMM_L32": "0"}, {"T4K_GEMM_DUAL_L32": "0"}, {"T4K_GEMM_L32": "0", "T4K_GEMM_DUAL_L32": "0"}, {"T4K_LINTHIN": "0"}, {"T4K_LINTHIN_CW": "0"}, {"T4K_LINTHIN_CW": "16"}, {"T4K_GEMM_XMAP": "1"}, {"T4K_GEMM_DUAL_L32_NW8": "0"},
-            {"T4K_GEMM_DUAL": "0"}, {"T4K_GEMM_DUAL32": "0"}, {"T4K_GEMM_S32": "0"}, {"T4K_GEMM_DUAL": "0", "T4K_GEMM_DUAL32": "0", "T4K_GEMM_S32": "0"},
-            {"T4K_GEMM_FULLK": "0"}, {"T4K_GEMM_FASTPRO": "0"}, {"T4K_GEMM_RAGGED_DMA": "0"}, {"T4K_GEMM_PLAIN_BIG": "0"}, {"T4K_GEMM_BIG_DMA": "0"},
-            {"T4K_GEMM_BIG_FULLK": "0"}, {"T4K_GEMM_DUAL_FULL": "0"}, {"T4K_GEMM_DUAL_FULLK": "0"}, {"T4K_GEMM_SPLIT_DIV": "2"}, {"T4K_GEMM_S32_NW8": "0"},
-            {"T4K_GEMM_S32_MAXK": "256"}, {"T4K_GEMM_DUAL_MAXK": "256"}, {"T4K_GEMM_DUAL32_MAXK": "128"}, {"T4K_HEAD_FOLD": "0"}, {"T4K_LINSMALL_GATE": "0"}, {"T4K_LINSMALL_COLS": "0"}, {"T4K_LINSMALL_COLS": "2"},
-            {"T4K_GEMM_PLAIN_PAIR": "0"}, {"T4K_GEMM_PLAIN128": "0"}, {"T4K_GEMM_PLAIN128": "2"}, {"T4K_GEMM_PLAIN128_RAGK": "0"}, {"T4K_GEMM_PLAIN128_BK32": "0"}, {"T4K_GEMM_PLAIN128_BK32": "2"}, {"T4K_GEMM_PLAIN256": "0"}, {"T4K_GEMM_PLAIN256": "2"}, {"T4K_GEMM_PLAIN_RAGK": "0"}, {"T4K_GEMM_PLAIN_RAGK": "1"}, {"T4K_GEMM_PLAIN_ANY": "0"}, {"T4K_GEMM_PLAIN_ANY": "1"}, {"T4K_GEMM_RAGGED_K": "0"}, {"T4K_GEMM_RAGGED_K": "2"}, {"T4K_GEMM_RAGGED_K": "2", "T4K_GEMM_S32": "0"}, {"T4K_GEMM_VARIANT": "21"}, {"T4K_GEMM_VARIANT": "37"}, {"T4K_GEMM_VARIANT": "61"}, {"T4K_GEMM_VARIANT": "5"}]
+# Round 6: the engine-selection knobs are LAB switches - compile-time constants in the release library (csrc/t4k_common.h T4K_LAB_ENV), read from the
+# environment only by `make -C tensorforth_amd/csrc LAB=1` (libt4hip_lab.so).  The release suite runs the products on the DEFAULT dispatch (+ the busy-device
+# case); the switch matrix runs against the LAB library when that has been built and T4K_TEST_LAB=1 asks for it (a lab bench, not part of the driver's suite).
+LAB_LIB = os.path.join(ROOT, "tensorforth_amd", "libt4hip_lab.so")
+LAB_SWITCHES = [{"T4K_LINTHIN": "0"}, {"T4K_LINTHIN_CW": "0"}, {"T4K_LINTHIN_CW": "16"}, {"T4K_GEMM_XMAP": "1"},
+                {"T4K_GEMM_DUAL": "0"}, {"T4K_GEMM_DUAL32": "0"}, {"T4K_GEMM_S32": "0"}, {"T4K_GEMM_DUAL": "0", "T4K_GEMM_DUAL32": "0", "T4K_GEMM_S32": "0"},
+                {"T4K_GEMM_FULLK": "0"}, {"T4K_GEMM_FASTPRO": "0"}, {"T4K_GEMM_RAGGED_DMA": "0"}, {"T4K_GEMM_PLAIN_BIG": "0"}, {"T4K_GEMM_BIG_DMA": "0"},
+                {"T4K_GEMM_BIG_FULLK": "0"}, {"T4K_GEMM_DUAL_FULL": "0"}, {"T4K_GEMM_DUAL_FULLK": "0"}, {"T4K_GEMM_SPLIT_DIV": "2"},
+                {"T4K_GEMM_S32_MAXK": "256"}, {"T4K_GEMM_DUAL_MAXK": "256"}, {"T4K_HEAD_FOLD": "0"}, {"T4K_LINSMALL_GATE": "0"}, {"T4K_LINSMALL_COLS": "0"}, {"T4K_LINSMALL_COLS": "2"},
+                {"T4K_GEMM_PLAIN_PAIR": "0"}, {"T4K_GEMM_PLAIN128": "0"}, {"T4K_GEMM_PLAIN128": "2"}, {"T4K_GEMM_PLAIN128_RAGK": "0"}, {"T4K_GEMM_PLAIN128_BK32": "0"}, {"T4K_GEMM_PLAIN128_BK32": "2"},
+                {"T4K_GEMM_PLAIN256": "0"}, {"T4K_GEMM_PLAIN256": "2"}, {"T4K_GEMM_PLAIN_RAGK": "0"}, {"T4K_GEMM_PLAIN_RAGK": "1"}, {"T4K_GEMM_PLAIN_ANY": "0"},
+                {"T4K_GEMM_RAGGED_K": "0"}, {"T4K_GEMM_RAGGED_K": "2"}, {"T4K_GEMM_RAGGED_K": "2", "T4K_GEMM_S32": "0"}]
+lab = pytest.mark.skipif(not (os.path.exists(LAB_LIB) and os.environ.get("T4K_TEST_LAB") == "1"), reason="LAB switch matrix: make -C tensorforth_amd/csrc LAB=1 and T4K_TEST_LAB=1")
 
 
 def _run(tmp_path, env_extra):
@@ -85,35 +93,32 @@ def _run(tmp_path, env_extra):
     assert r.returncode == 0, "%s\n%s\n%s" % (env_extra, r.stdout[-3000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("sw", SWITCHES, ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()) or "defaults")
-def test_integer_exact_products_under_every_dispatch_switch(tmp_path, sw):
-    _run(tmp_path, sw)
+def test_integer_exact_products_on_the_default_dispatch(tmp_path):
+    _run(tmp_path, {})
 
 
 def test_gated_kernels_while_another_stream_hogs_the_device(tmp_path):
     _run(tmp_path, {"HOG": "1"})
 
 
-def test_conv_kernel_on_the_lean_pipeline_and_its_variants_match_the_oracle():
-    """k_convbig8 (csrc/conv_big.hip: forward / dX of many-channel stride-1 layers on the dense GEMM's 8-wave LDS-DMA pipeline) takes every qualifying layer of the
-    conv parity tests by default; T4K_CONVBIG8=0 none (k_convbig).  T4K_CONVBIG8_BK32: 32-channel stages with two workgroups per CU - 2 = on every grid,
-    0 = never (default: grids of two or more tiles per CU); T4K_CONVBIG8_NT=1: streaming stores in the epilogue."""
-    _conv_tests("0")
-    for env in ({"T4K_CONVBIG8_BK32": "2"}, {"T4K_CONVBIG8_BK32": "0"}, {"T4K_CONVBIG8_NT": "1"}, {"T4K_CONVBIG_DFW": "0"}, {"T4K_CONVBIG_DFW": "3"}, {"T4K_CONVBIG_DFW": "4"},
-                {"T4K_CONV_BN_RIDER": "0"}, {"T4K_BN_PART4": "0"}):
-        _conv_tests(None, env)
+def test_integer_exact_products_with_the_gated_kernels_switched_off(tmp_path):
+    """t4k_gates_enable(0) (what the library does by itself after a timed-out wait): no kernel whose workgroups wait for each other is chosen."""
+    _run(tmp_path, {"GATES_OFF": "1"})
 
 
-def test_conv_parity_without_the_thin_input_kernel_and_with_other_grids():
-    """k_conv_thin_fwd / k_conv_thin_df (csrc/conv_img.hip: image in, 32 / 64 channels out) off -> the generic gather kernels take those layers again; a
-    workgroup cap of 1 makes one workgroup walk every tile (the pipelined loop at its longest), 100000 gives every wave a single tile."""
-    for env in ({"T4K_CONV_THIN": "0"}, {"T4K_CONV_THIN_WG": "1"}, {"T4K_CONV_THIN_WG": "100000"}, {"T4K_CONV_THIN_NT": "0"}, {"T4K_CONV_DF_WG": "2048", "T4K_CONV_THIN_DF": "0"},
-                {"T4K_CONV_THIN_DF_WG": "1"}, {"T4K_CONV_THIN_DF_WG": "100000"}):
-        _conv_tests(None, env)
+@lab
+@pytest.mark.parametrize("sw", LAB_SWITCHES, ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_lab_integer_exact_products_under_every_dispatch_switch(tmp_path, sw):
+    _run(tmp_path, dict(sw, T4K_LIB=LAB_LIB))
 
 
-def _conv_tests(v, extra=None):
-    env = dict(os.environ, **({"T4K_CONVBIG8": v} if v is not None else {}), **(extra or {}))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
-                        "-k", "test_conv2d or many_channels or random_shapes or second_destination or batchnorm"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+@lab
+def test_lab_conv_parity_under_the_conv_engine_switches():
+    """k_convbig8 / k_conv_thin_* variants (csrc/conv_big.hip, conv_img.hip): the conv parity tests under every LAB switch of the conv engines."""
+    for env in ({"T4K_CONVBIG8": "0"}, {"T4K_CONVBIG8_BK32": "2"}, {"T4K_CONVBIG8_BK32": "0"}, {"T4K_CONVBIG8_NT": "1"}, {"T4K_CONVBIG_DFW": "0"}, {"T4K_CONVBIG_DFW": "3"}, {"T4K_CONVBIG_DFW": "4"},
+                {"T4K_CONV_BN_RIDER": "0"}, {"T4K_BN_PART4": "0"}, {"T4K_CONV_THIN": "0"}, {"T4K_CONV_THIN_WG": "1"}, {"T4K_CONV_THIN_WG": "100000"}, {"T4K_CONV_THIN_NT": "0"},
+                {"T4K_CONV_DF_WG": "2048", "T4K_CONV_THIN_DF": "0"}, {"T4K_CONV_THIN_DF_WG": "1"}, {"T4K_CONV_THIN_DF_WG": "100000"}):
+        e = dict(os.environ, T4K_LIB=LAB_LIB, **env)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                            "-k", "test_conv2d or many_channels or random_shapes or second_destination or batchnorm"], capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+        assert r.returncode == 0, str(env) + r.stdout[-3000:] + r.stderr[-2000:]
