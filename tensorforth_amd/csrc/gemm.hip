@@ -1842,8 +1842,10 @@ void launch_plain128(const GemmP &p, int tA, int tB, hipStream_t s) {
     const bool epi = p.alpha != 1.0f || p.beta != 0.0f || p.bias, ragk = p.K % 64 != 0;
     {   // one 256 x 256 tile or more per CU: the 16-wave kernel (T4K_GEMM_PLAIN256: 0 off, 1 default, 2 any grid of whole 256-tiles)
         static const int p256 = T4K_LAB_ENV("T4K_GEMM_PLAIN256", 1);
-        const long t256 = (long)(p.M / 256) * (p.N / 256);
-        if (p256 && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 32 == 0 && p.K >= 64 && (p256 >= 2 || t256 >= (long)st().cu_count) &&
+        const long t256 = (long)(p.M / 256) * (p.N / 256), t128 = 4 * t256, cu = st().cu_count;
+        // wave quantisation: 4352^2 is 289 tiles of 256^2 - two rounds, the second 13 % full - but 1156 tiles of 128^2 at 90 % fill; the 256-tile pipeline is worth ~4 % per FLOP
+        auto fill_of = [](long tiles_, long cu_) { return (double)tiles_ / (double)(((tiles_ + cu_ - 1) / cu_) * cu_); };
+        if (p256 && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 32 == 0 && p.K >= 64 && (p256 >= 2 || (t256 >= cu && fill_of(t256, cu) * 1.04 > fill_of(t128, cu))) &&
             (long)p.M * p.K < (1L << 30) && (long)p.N * p.K < (1L << 30)) {
 #define T4K_P256(A_, B_) do { if (epi) launch_plain256_<A_, B_, true>(q, s); else launch_plain256_<A_, B_, false>(q, s); } while (0)
             if (!tA && !tB) T4K_P256(true, false); else if (!tA) T4K_P256(true, true); else if (!tB) T4K_P256(false, false); else T4K_P256(false, true);

@@ -310,6 +310,7 @@ int t4k_opt_chunked(int kind, const t4k_param_rec *tab_dev, int n_tensors, int n
 static int opt_step_impl(int kind, const t4k_param_rec *tab_dev, const t4k_param_rec *tab_host, int n_tensors, int n_chunks,
                          float lr, float b1, float b2, float wd, const float *slab, long slab_n, t4k_stream_t s) {
     State &g = st();
+    std::lock_guard<std::recursive_mutex> pending_lock(pending_mu());      // the deferred fold is consumed (or flushed) exactly once, whoever else reaches an entry point meanwhile
     const bool dp = slab && xchg().connected && (xchg().world > 1 || xchg().self);
     bool slab_ok = dp && tab_dev && tab_host && n_tensors > 0 && n_tensors <= 64 && n_chunks > 0 && slab_n <= xchg().n && !g.capturing && kind >= 0 && kind <= 2;
     for (int i = 0; slab_ok && i < n_tensors; i++) if (tab_host[i].DG < slab || tab_host[i].DG + tab_host[i].n > slab + slab_n) slab_ok = false;

@@ -98,7 +98,7 @@ void t4k_shutdown(void) {
     if (g.ws) { (void)hipFree(g.ws); g.ws = nullptr; }
     if (g.own_stream && g.stream) { (void)hipStreamDestroy(g.stream); }
     g.stream = nullptr; g.own_stream = false;
-    g.pending = 0; g.pending_owner = 0;                 // deferred work dies with its workspace and stream (a later t4k_init must not flush into freed memory)
+    g.pending = 0;                 // deferred work dies with its workspace and stream (a later t4k_init must not flush into freed memory)
     (void)t4k_xchg_destroy();
     g.ready = false;
 }

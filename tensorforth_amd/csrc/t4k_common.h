@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <mutex>
 #include "../../include/t4k.h"
 
 namespace t4k {
@@ -43,9 +44,9 @@ struct State {
     unsigned    slot_epoch[16] = {};  // per stream lane: launch count of the kernels that tag the arrival slots (next_slot_epoch)
     unsigned long long launches = 0;  // kernels launched by the library since t4k_init (t4k_launch_count)
     bool        gates_off = false;    // no kernel that makes workgroups wait for each other is chosen any more (t4k_gates_enable(0), or set by spin_check() after a timed-out wait)
-    int         pending = 0;          // work a launch left for the NEXT entry point (pending.h): bit 0 = a conv stack's dF | dB partial fold
-    unsigned long pending_owner = 0;  // the thread that left it (thread_key()): only THAT thread flushes or consumes it - a helper thread of the host (the dataset
-                                      // reader waits on events through t4k_event_sync) must neither run the fold a second time nor clear the bit
+    int         pending = 0;          // work a launch left for the NEXT entry point: bit 0 = a conv stack's dF | dB partial fold.  Set, flushed and consumed under pending_mu():
+                                      // whichever thread reaches an entry point first flushes (a gradient read from a second thread must see the folded dF | dB);
+                                      // the one entry point a helper thread of the host calls while the model thread trains - t4k_event_wait, the dataset reader - never flushes
     char        err[512] = {0};
 };
 State &st();
@@ -59,7 +60,6 @@ inline int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 #else
 #define T4K_LAB_ENV(name, dflt) (dflt)
 #endif
-inline unsigned long thread_key() { static thread_local char k; return (unsigned long)(uintptr_t)&k; }   // cheap per-thread identity
 // every kernel launch of the library goes through this macro and is counted: bench.py prints the MEASURED launches per step
 #define T4K_LAUNCH(kernel, ...) do { ++t4k::st().launches; hipLaunchKernelGGLInternal((kernel), __VA_ARGS__); } while (0)
 // what a drawing kernel receives: eager = (base, seed) by value and state == nullptr; inside a graph = the device copy
@@ -126,9 +126,10 @@ int  spin_check();                       // runtime.hip: T4K_OK, or T4K_ERR_HIP 
 // entry point, folds them inside the optimizer launch (fold + update = one launch); EVERY other entry point (they all start with
 // T4K_REQUIRE_INIT) first runs the stand-alone fold on the stream of the backward, so whatever the caller does next - read a gradient
 // tensor, accumulate a second backward, all-reduce the slab - sees exactly what the undeferred path would have left.
-void flush_pending();                    // conv_stack.hip
+void flush_pending();                    // conv_stack.hip (takes pending_mu())
+std::recursive_mutex &pending_mu();      // conv_stack.hip
 #define T4K_REQUIRE_INIT_NOFLUSH() do { if (!t4k::st().ready) return t4k::fail(T4K_ERR_NODEVICE, "t4k_init not called or no gfx950 device"); } while (0)
-#define T4K_REQUIRE_INIT() do { T4K_REQUIRE_INIT_NOFLUSH(); if (t4k::st().pending && t4k::st().pending_owner == t4k::thread_key()) t4k::flush_pending(); } while (0)
+#define T4K_REQUIRE_INIT() do { T4K_REQUIRE_INIT_NOFLUSH(); if (t4k::st().pending) t4k::flush_pending(); } while (0)
 #define T4K_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) return t4k::hip_fail(_e, #call); } while (0)
 #define T4K_LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return t4k::hip_fail(_e, "kernel launch"); } while (0)
 
