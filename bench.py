@@ -53,17 +53,35 @@ def dry_run(rank, world, args):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout())
     dist.barrier()
+    ones = torch.ones(1); dist.all_reduce(ones, op=dist.ReduceOp.SUM)             # "negotiation": who is there
+    if os.environ.get("T4_BENCH_TEST_DIE_RANK") == str(rank):                    # test hook (tests/test_bench_launch.py): a rank that dies behind the negotiation
+        os._exit(7)
     t0 = time.perf_counter(); dist.barrier(); dt = time.perf_counter() - t0
     tmax = torch.tensor([dt]); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    ones = torch.ones(1); dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    all_alive(dist, torch, world, None)                                          # a line is printed only by a job whose ranks are ALL still there
     if rank == 0:
         print(json.dumps({"metric": BASELINE_METRIC, "value": None, "unit": "images/s", "n_gpus": int(ones.item()), "steps": 0, "warmup": 0,
                           "dry_run": True, "config": {"workload": "launch / rendezvous / reduction plumbing only", "parallelism": "dp%d" % world,
                                                       "allreduce": "gloo"}}), flush=True)
     dist.barrier(); dist.destroy_process_group()
     return 0
+
+
+def pg_timeout():
+    """Bound of every torch.distributed collective of the bench (T4_BENCH_PG_TIMEOUT_S, default 600 s): a rank that dies behind the rendezvous makes the
+    survivors' next collective fail - they exit non-zero instead of waiting for the default 30 minutes (VERDICT r5 #9c)."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("T4_BENCH_PG_TIMEOUT_S", "600")))
+
+
+def all_alive(dist, torch, world, device):
+    """Every rank answers, or the caller dies with the collective's error (non-zero exit, no JSON line)."""
+    t = torch.ones(1, device=device) if device is not None else torch.ones(1)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if int(round(float(t.item()))) != world:
+        raise SystemExit("bench: %d of %d ranks alive at the end of the run" % (int(round(float(t.item()))), world))
 
 
 def cpu_workers(mode_args, n_workers, timeout=120):
@@ -165,23 +183,43 @@ def extras(vm_cls, local, ms_step, args, torch):
     t0 = time.perf_counter(); c.eval("200 steps\n"); torch.cuda.synchronize()
     out["t4_40a_net_ms_per_step"] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
     c.close()
-    # ---- the reference-equal-work step: the same timed loop with the first layer's dX stored every step (T4_LAZY_DX0=0, what the reference's backprop
-    # always does, backprop.cu:185,240).  The switch is read when the host library loads, so the figure comes from a child process of this very script.
-    if os.environ.get("T4_LAZY_DX0", "1") != "0":
+    # ---- the reference's t4_42a-style CIFAR net (3 x [conv3x3 + batchnorm + relu + maxpool + dropout] + linear head, N = 256, AdamW) - the words of
+    # tools/forth/cifar_steps.4th, HBM-resident synthetic batch; bytes / FLOP by SURVEY 8(d)'s rule (tools/cifar_roofline.py).  The reference quotes sec / epoch
+    # for this net (examples/t4_42a.4th:49); here it is a per-step figure under the driver's clock.
+    try:
+        cf = vm_cls(device=local, seed=42)
+        src = open(os.path.join(ROOT, "tools", "forth", "cifar_steps.4th")).read().split("net 5 steps")[0]
+        txt = cf.eval(src + "net 5 steps\n")
+        assert "?" not in txt.replace("-> ok", ""), txt
+        torch.cuda.synchronize()
+        nst = 60
+        t0 = time.perf_counter(); cf.eval("%d steps\n" % nst); torch.cuda.synchronize()
+        cms = (time.perf_counter() - t0) / nst * 1e3
+        cf.close()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cifar_roofline.py"), "%.5f" % cms], capture_output=True, text=True, timeout=60)
+        cr = json.loads(r.stdout.strip().splitlines()[-1])
+        out["cifar_step_ms"] = round(cms, 4)
+        out["cifar"] = {"workload": cr["workload"], "steps_timed": nst, "images_per_s": round(256 / (cms * 1e-3), 1), "algorithmic_bytes_per_step": cr["algorithmic_bytes_per_step"],
+                        "flop_per_step": cr["flop_per_step"], "bound": cr["bound"], "mfma_frac": cr["mfma_frac"], "hbm_frac": cr["hbm_frac"]}
+    except Exception as ex:                                      # never lose the main line over an extra
+        out["cifar_note"] = "cifar leg failed: %r" % (ex,)
+    # ---- the product's DEFAULT plan: the same timed loop with the first layer's dX left to the first word that reads it (T4_LAZY_DX0=1).  The switch is
+    # read when the host library loads, so the figure comes from a child process of this very script.
+    if os.environ.get("T4_LAZY_DX0", "1") == "0":
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--net", args.net, "--batch", str(args.batch),
                                 "--no-extras", "--no-cpu-baseline", "--gemm-iters", "1", "--sustain-s", "0"], capture_output=True, text=True, timeout=600,
-                               env=dict(os.environ, T4_LAZY_DX0="0"))
+                               env=dict(os.environ, T4_LAZY_DX0="1"))
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode == 0 and line:
                 e = json.loads(line[-1])
-                out["eager_ms_per_step"] = e["ms_per_step"]
-                out["eager_note"] = "T4_LAZY_DX0=0 (first layer's dX stored every step, as the reference does): %s launches per step, %s images/s, roofline_step.frac %s on %d algorithmic bytes" % (
+                out["lazy_dx0_ms_per_step"] = e["ms_per_step"]
+                out["lazy_dx0_note"] = "T4_LAZY_DX0=1 (the product's default: the first layer's dX produced when a word reads it, not every step): %s launches per step, %s images/s, roofline_step.frac %s on %d algorithmic bytes" % (
                     e["config"]["launches_per_step"], e["value"], e["roofline_step"]["frac"], e["roofline_step"]["algorithmic_bytes_per_step"])
             else:
-                out["eager_note"] = "eager leg failed: " + (r.stderr or r.stdout)[-300:]
+                out["lazy_dx0_note"] = "lazy leg failed: " + (r.stderr or r.stdout)[-300:]
         except Exception as ex:                                  # never lose the main line over an extra
-            out["eager_note"] = "eager leg failed: %r" % (ex,)
+            out["lazy_dx0_note"] = "lazy leg failed: %r" % (ex,)
     # ---- dataset-fed step: IDX file -> pinned double buffer (reader thread) -> one staging launch -> forward backprop nn.sgd
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as d:
@@ -231,6 +269,9 @@ def main():
         return dry_run(rank, world, args)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); must be set before the HIP runtime starts
+    # The headline step does the REFERENCE's work: the first layer's dX is stored every step (backprop.cu:185,240).  The product's default leaves that tensor
+    # to the first word that reads it (T4_LAZY_DX0=1); its figure is the `lazy_dx0_ms_per_step` extra.  The switch is read when the host library loads.
+    os.environ.setdefault("T4_LAZY_DX0", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -243,7 +284,7 @@ def main():
     if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=pg_timeout())
 
     from tensorforth_amd import lib as t4lib, pymodel
     from tensorforth_amd.vm import VM
@@ -361,8 +402,29 @@ def main():
             tmax = torch.tensor([sdt], device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); sdt = float(tmax.cpu()[0])
         sustained = (sdt / n_sus * 1e3, n_sus)
     loss_txt = vm.eval("img forward lbl loss.ce .")       # a fresh forward: after backprop the output tensor holds out - target (reference in-place convention)
+    # ---- N > 1, day-one numbers of the exchange (VERDICT r5 #9a; never measured on real xGMI so far): every rank's known-sum probe times, and the EXPOSED
+    # exchange time per step = the step above minus the same loop run by every rank on its own (exchange and communicator dropped: the single-GPU step, same
+    # process, same clocks).  DESIGN section 6 predicts 5-8 us at 8 ranks.  The replicas diverge from here on - nothing after this reads their weights.
+    dp_extra = None
+    if dp and native and world > 1 and os.environ.get("T4_BENCH_DP_EXTRA", "1") != "0":
+        try:
+            probes = [None] * world
+            dist.all_gather_object(probes, (neg or {}).get("xchg_probe_us"))
+            if xchg:
+                k.lib.t4k_xchg_destroy()
+            k.lib.t4k_comm_destroy()
+            run(max(args.warmup, 5)); barrier()
+            t1 = time.perf_counter(); run(args.steps); barrier()
+            solo = torch.tensor([(time.perf_counter() - t1) / args.steps * 1e3], device="cuda"); dist.all_reduce(solo, op=dist.ReduceOp.MAX)
+            dp_extra = {"xchg_probe_us_per_rank": probes, "solo_ms_per_step": round(float(solo.cpu()[0]), 4),
+                        "exchange_exposed_us_per_step": round((dt / args.steps * 1e3 - float(solo.cpu()[0])) * 1e3, 2),
+                        "note": "exposed = ms_per_step (all ranks, exchange inside the optimizer launch) - the same loop with every rank stepping alone (max over ranks)"}
+        except Exception as ex:                                  # an extra never costs the line (T4_BENCH_DP_EXTRA=0 skips it)
+            dp_extra = {"note": "dp extra failed: %r" % (ex,)}
 
     out = None
+    if dp and rank != 0:
+        all_alive(dist, torch, world, torch.device("cuda", local))       # (rank 0 asks in front of its print)
     if rank == 0:
         net = NETS[args.net]
         gemm_traffic, step_traffic, traffic_src = measured_traffic()
@@ -370,8 +432,8 @@ def main():
             step_traffic = None                                # the counter pass is of the default workload
         step_bytes_eager = N * net["bytes_per_img"] + 4 * net["params"] * 7      # k_opt = 7 for SGD; SURVEY 8(d): every layer-boundary tensor incl. the first layer's dX
         lazy_dx0 = os.environ.get("T4_LAZY_DX0", "1") != "0"
-        # the timed step does not produce the first layer's dX (nobody reads it in a training loop; it is made on demand): its write + read
-        # (2 x 4 B per input element) is not counted as work done.  The reference-equal-work figure (eager store) is `eager_ms_per_step` below.
+        # a step run with T4_LAZY_DX0=1 does not produce the first layer's dX (nobody reads it in a training loop; it is made on demand): its write + read
+        # (2 x 4 B per input element) is then not counted as work done.  The headline (default of this script) is the eager, reference-equal step.
         step_bytes = step_bytes_eager - (2 * 4 * N * 28 * 28 if lazy_dx0 else 0)
         out = {
             "metric": BASELINE_METRIC,   # `value` = CNN train images/sec; the GEMM TFLOP/s (% of MFMA peak) part is the `roofline` object
@@ -379,7 +441,7 @@ def main():
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t4_30e %s LeNet-style CNN (examples/t4_30e.4th), 28x28x1, batch %d per GPU, "
-                                   "copy-in + forward + backprop + nn.sgd(0.01), dropout on" % (args.net, N),
+                                   "copy-in + forward + backprop + nn.sgd(0.01), dropout on, %s" % (args.net, N, "first layer's dX left to the first reader (T4_LAZY_DX0=1)" if lazy_dx0 else "every layer's dX stored every step incl. the first layer's (the reference's work)"),
                        "global_batch": N * world, "parallelism": "dp%d" % world, "host": "C++ eForth VM (libten4.so) -> C-ABI (libt4hip.so)", "launches_per_step": round(launches, 2), "launches_source": "t4k_launch_count() around the timed loop", "conv_stack": stack_mode, "allreduce": ("one-shot peer exchange inside the optimizer launch (csrc/xchg.hip)" if xchg else ("rccl-native-in-vm" if native else ("torch.distributed" if dp else None))),
                        "allreduce_fallback_reason": neg["reason"] if neg else None, "ranks_seen": neg["ranks_seen"] if neg else None,
                        "final_loss_ce": loss_txt.split()[0] if loss_txt.split() else None,
@@ -390,6 +452,8 @@ def main():
                               "algorithmic_bytes_per_step": step_bytes, "algorithmic_bytes_per_step_eager": step_bytes_eager,
                               "first_layer_dx": "on demand (T4_LAZY_DX0=1): its 2 x 4 B per input element are not in algorithmic_bytes_per_step" if lazy_dx0 else "stored every step"},
         }
+        if dp_extra:
+            out["dp"] = dp_extra
         if sustained:
             out["sustained_ms_per_step"] = round(sustained[0], 4)
             out["sustained_steps"] = sustained[1]
@@ -480,6 +544,8 @@ def main():
                                    "gemm_1024_host_gflops": round(flops / gdt / 1e9, 2),
                                    "gemm_1024_host_gflops_all_cores": round(all_gflops, 1), "gemm_all_cores_workers": len(gr),
                                    "gemm_note": "reference's blocked host GEMM (tensor.cu:97-123 restated): one thread on the full 1024^3 product, then %d workers on %d-row slabs for ~2 s" % (len(gr), rows)}
+        if dp:
+            all_alive(dist, torch, world, torch.device("cuda", local))   # a line is printed only by a job whose ranks are ALL still there
         print(json.dumps(out), flush=True)
     if dp:
         if xchg:

@@ -134,6 +134,7 @@ int t4k_comm_sync_batchnorm(int on);
 int t4k_xchg_create(long slab_floats, int rank, int world, void *handle64);
 int t4k_xchg_connect(const void *handles /* world x 64 bytes, rank order */);
 int t4k_xchg_allreduce(float *buf, long n, t4k_stream_t s);   /* in-place SUM over the ranks through the windows (any n; rank order: deterministic) */
+int t4k_xchg_trust(int on);                        /* the launcher's verdict on the known-sum probe (tensorforth_amd/dp.py): waits are bounded by 2 s until it is 1, by T4K_XCHG_TIMEOUT_MS (20 s) after */
 int t4k_xchg_self(int on);                         /* measurement: a one-rank job takes the exchanging optimizer launch too (bench.py dp_overhead_us) */
 int t4k_xchg_active(void);                         /* 1 when t4k_opt_step_dp will exchange (connected and world > 1, or self mode) */
 int t4k_xchg_world(void);                          /* 0 = not connected */

@@ -297,6 +297,7 @@ int t4k_opt_step_dp(int kind, const t4k_param_rec *tab, const t4k_param_rec *, i
     return t4k_opt_multi(kind, tab, nt, 0, lr, b1, b2, wd, st);
 }
 int t4k_xchg_world(void) { return 0; }
+int t4k_xchg_trust(int) { return T4K_OK; }
 int t4k_xchg_active(void) { return 0; }
 
 // the sample-resident conv stack is a launch-count optimisation of the product: the oracle VM always runs the separate layers

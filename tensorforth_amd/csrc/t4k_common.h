@@ -320,7 +320,7 @@ __device__ __forceinline__ bool cs_fold16(const CsFoldArgs &a, int blk, CsFoldSm
 // ---- one-shot peer exchange (xchg.hip): every rank owns a window of 64-bit words {epoch, value}; a rank PUSHES its element into slot
 // `rank` of every peer's window and SUMS the slots of its own window in rank order once their tags carry the call's epoch
 constexpr int T4K_XCHG_MAX = 8;
-struct Xchg { bool connected = false, self = false; int rank = 0, world = 0; long n = 0; unsigned long long *win[T4K_XCHG_MAX] = {}; unsigned epoch_slab = 0, epoch_gen = 0; };
+struct Xchg { bool connected = false, self = false, trusted = false; int rank = 0, world = 0; long n = 0; unsigned long long *win[T4K_XCHG_MAX] = {}; unsigned epoch_slab = 0, epoch_gen = 0; };
 Xchg &xchg();
 struct XchgDev { unsigned long long *win[T4K_XCHG_MAX]; long per; unsigned long long patience; unsigned epoch; int rank, world; };   // windows already offset to the call's region and parity; patience in 100 MHz ticks
 XchgDev xchg_begin(bool generic);                    // host: the device view of the next call (advances the region's epoch)

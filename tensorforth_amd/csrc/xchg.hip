@@ -117,6 +117,7 @@ int t4k_xchg_allreduce(float *buf, long n, t4k_stream_t s) {
 }
 int t4k_xchg_world(void) { return xchg().connected ? xchg().world : 0; }
 int t4k_xchg_rank(void)  { return xchg().connected ? xchg().rank : 0; }
+int t4k_xchg_trust(int on) { xchg().trusted = on != 0; return T4K_OK; }
 int t4k_xchg_destroy(void) {
     Xchg &x = xchg();
     if (!L.win && !x.connected) return T4K_OK;
@@ -144,7 +145,9 @@ XchgDev xchg_begin(bool generic) {
     for (int r = 0; r < x.world; r++) d.win[r] = x.win[r] + base;
     d.per = per;
     static const long ms = t4k::env_int("T4K_XCHG_TIMEOUT_MS", 20000);   // how long a rank waits for a peer's element
-    d.patience = (unsigned long long)ms * 100000ull;
+    // until the launcher has seen the known-sum probe succeed on every rank (t4k_xchg_trust) a wait gives up after 2 s at most: a peer that mapped the windows
+    // but never runs (a partitioned / shared device, a rank that died behind the rendezvous) must cost the ladder seconds, not the first training step 20 s
+    d.patience = (unsigned long long)(x.trusted ? ms : std::min(ms, 2000L)) * 100000ull;
     return d;
 }
 // in-place SUM over ranks of n floats on stream hs, in pieces of the scratch region

@@ -153,17 +153,27 @@ def negotiate_reduction(lib, rank, world, device, want_native=True, want_xchg=Tr
         if good:                                              # self-check: sum over ranks of (rank + 1) * i must be i * world (world + 1) / 2, on both window parities
             probe = torch.arange(70000, dtype=torch.float32, device=device) % 1000
             run = xchg_allreduce or (lambda v: lib.t4k_xchg_allreduce(v.data_ptr(), v.numel(), None) or lib.t4k_sync(None))
+            import time
+            on_gpu = device is not None and str(device).startswith("cuda")
+            res["xchg_probe_us"] = []                          # this rank's wall time of each probe call (the first carries first-use costs)
             for _ in range(2):
                 v = (probe * (rank + 1)).contiguous()
-                if device is not None and str(device).startswith("cuda"):
+                if on_gpu:
                     torch.cuda.synchronize()
+                dist.barrier()                                 # the probe's time is the exchange's, not the wait for a rank that is still uploading
+                t0 = time.perf_counter()
                 rc = run(v)
+                if on_gpu:
+                    torch.cuda.synchronize()
+                res["xchg_probe_us"].append(round((time.perf_counter() - t0) * 1e6, 1))
                 good = all_min(rc == 0 and bool(torch.equal(v, probe * (world * (world + 1) // 2))))
                 why = "the exchange failed its known-sum self-check"
                 if not good:
                     break
         res["xchg"] = good
         if good:
+            if hasattr(lib, "t4k_xchg_trust"):
+                lib.t4k_xchg_trust(1)                          # from here on a late peer gets the full patience (T4K_XCHG_TIMEOUT_MS)
             res["ranks_seen"]["xchg"] = lib.t4k_xchg_world()
         else:
             res["reason"] = "one-shot peer exchange not used (%s) - the slab goes through RCCL" % why

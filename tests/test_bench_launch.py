@@ -38,6 +38,16 @@ def test_dry_run_spawns_two_ranks_that_rendezvous():
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["value"] is None and rec["config"]["parallelism"] == "dp2"
 
 
+def test_a_rank_that_dies_behind_the_negotiation_fails_the_job_without_a_line():
+    """VERDICT r5 #9c: rank 1 of a 3-rank job exits right after the ranks have counted each other.  The survivors' next collective fails within the
+    process-group timeout (T4_BENCH_PG_TIMEOUT_S), they exit non-zero and NO rank prints a JSON line - a job that lost a rank never leaves a record."""
+    import time
+    t0 = time.time()
+    rc, rec, err = _run(["--gpus", "3", "--dry-run"], {"T4_BENCH_TEST_DIE_RANK": "1", "T4_BENCH_PG_TIMEOUT_S": "10"}, timeout=300)
+    assert rc != 0 and rec is None, (rc, rec, err[-600:])
+    assert time.time() - t0 < 200
+
+
 def test_world_size_mismatch_is_an_error_not_a_one_rank_record():
     rc, rec, err = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
     assert rc == 2 and rec is None and "WORLD_SIZE=1" in err
