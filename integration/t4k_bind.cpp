@@ -191,6 +191,87 @@ Tensor &Tensor::zeros()    { warn(t4k_memset(data, 0, sizeof(DU) * numel, nullpt
 Tensor &Tensor::map(math_op op, DU v) { warn(t4k_math((int)op, data, v, (long)numel, nullptr), "tensor#map"); return *this; }
 Tensor &Tensor::normalize(DU avg, DU std) { warn(t4k_ts_op(T4K_SUB, data, avg, data, (long)numel, nullptr), "normalize"); warn(t4k_ts_op(T4K_DIV, data, std, data, (long)numel, nullptr), "normalize"); return *this; }
 void Tensor::d2h(DU *h, DU *d, int bsz) { t4k_memcpy_d2h(h, d, (size_t)bsz, nullptr); t4k_sync(nullptr); }
+// ---- the tensor debugger (tensor.cu:587-684: _dump, _view, show) - what `1 trace` / `2 trace` print of the layer tensors.  The reference reads managed
+// memory through the device pointer; here the page is copied to the host first (d2h), everything else is the reference's text.
+void Tensor::_dump(DU *dv, U32 H, U32 W, U32 C) {
+    std::vector<DU> hb((size_t)H * W * C); d2h(hb.data(), dv, (int)(sizeof(DU) * hb.size())); DU *v = hb.data();
+    const DU  hw = I2D(H) * W, sr = sqrtf(hw);
+    const U32 sh = UINT(hw / sr) + ((hw - sr*sr) > DU0 ? 1 : 0);
+    const U32 h  = W > 1 ? H : (hw < 36.0 ? 1 : sh);
+    const U32 w  = W > 1 ? W : (hw < 36.0 ? H : UINT(sr));
+    std::vector<DU> csum(C, DU0);
+    for (U32 i = 0; i < h; i++) {
+        INFO("\n");
+        DU sum = DU0;
+        for (U32 k = 0; k < C; k++) {
+            for (U32 j = 0; j < w; j++) {
+                U64 n = j + i * w;
+                if (n >= hw) { INFO(" ...."); continue; }
+                DU  r = v[k + n * C];
+                INFO("%5.2f", r);
+                sum += r;
+                csum[k] += r;
+            }
+            INFO("|");
+        }
+        INFO("Σ=%6.3f", sum);
+    }
+    if (h > 1) {
+        INFO("\nΣΣ=");
+        for (U32 k = 0; k < C; k++) INFO("%6.3f ", csum[k]);
+    }
+}
+void Tensor::_view(DU *dv, U32 H, U32 W, U32 C, DU mean, DU scale) {
+    std::vector<DU> hb((size_t)H * W * C); d2h(hb.data(), dv, (int)(sizeof(DU) * hb.size())); DU *v = hb.data();
+    auto map = [](DU x) {
+        static const char *lk = " `.-:;!+*ixekO#@";     /// 16 shades
+        static const int   sz = 16;
+        int i = (int)((x + 1.0) * sz/2);
+        return lk[i < 0 ? 0 : (i < sz ? i : sz-1)];
+    };
+    const U64 hw = H * W, sr = (U64)sqrtf(hw);
+    const U32 sh = (hw / sr) + ((hw - sr*sr) > 0L ? 1 : 0);
+    const U32 w  = W > 1 ? W : (hw < 36L ? H : sr);
+    const U32 h  = W > 1 ? H : (hw < 36L ? 1 : sh);
+    std::vector<DU> csum(C, DU0);
+    for (U32 i = 0; i < h; i++) {
+        INFO("\n");
+        for (U32 k = 0; k < C; k++) {
+            for (U32 j = 0; j < w; j++) {
+                U64 n = j + i * w;
+                if (n >= hw) { INFO("  "); continue; }
+                DU r0 = v[k + (j>0 ? n - 1 : n) * C];
+                DU r1 = v[k + n * C];
+                DU x0 = (r0 - mean) * scale;
+                DU x1 = (((r0 + r1) * 0.5) - mean) * scale;
+                INFO("%c%c", map(x0), map(x1));  /// double width
+                csum[k] += r1;
+            }
+            INFO("|");
+        }
+    }
+    if (h > 1) {
+        INFO("\nΣΣ=");
+        for (U32 k = 0; k < C; k++) INFO("%6.3f ", csum[k]);
+    }
+    INFO("\n");
+}
+int Tensor::show(bool dump) {
+    const U32 N  = this->N(), H = this->H(), W = this->W(), C = this->C();
+    const U64 hw = (U64)H * W;
+    DU mean  = avg();
+    DU scale = 0.5 / std();            /// P=95%
+    for (U32 n = 0; n < N; n++) {
+        DU *d = slice(n);
+        if (dump || hw < 100) {
+            INFO("\nn=%d", n);
+            _dump(d, H, W, C);
+        }
+        if (hw > 36L) _view(d, H, W, C, mean, scale);
+    }
+    INFO("\n");
+    return 0;
+}
 
 // ===================================================================================================== mu/mmu.cu:208-262
 // headers from the host-side object pool, data from HBM.  (talloc / mark_free / sweep / obj2du keep their reference bodies.)

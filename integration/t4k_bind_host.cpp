@@ -210,18 +210,31 @@ using mu::Tensor;
 // ===================================================================================================== nn/forward.cu:27-113
 Model &Model::forward(Tensor &input) {
     Tensor &n0 = (*this)[0];
+    if (*_trace) input.show(true);                        // preview of the input (forward.cu:31)
     if (input.numel != n0.numel) {
         ERROR("nn#forward dataset wrong shape[%d,%d,%d,%d] != model input[%d,%d,%d,%d]\n", input.N(), input.H(), input.W(), input.C(), n0.N(), n0.H(), n0.W(), n0.C());
         return *this;
     }
     n0 = input;                                           // the batch is copied into layer 0
+    auto info = [](DU t, int i, Tensor &in, Tensor &out) {  // forward.cu:44-50
+        INFO("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] Σ/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]",
+            t, i, nname(in.grad_fn), in.N(), in.H(), in.W(), in.C(),
+            in.sum() / in.N() / in.C(), in.xparm,
+            out.N(), out.H(), out.W(), out.C());
+    };
     NLOG("\nModel::forward starts trace=%d {", *_trace);
-    const DU t0 = System::clock();
+    DU t0 = System::clock(), t1 = t0, tt;
     for (int i = 0; i < (int)numel - 1; i++) {
         Tensor &in = (*this)[i], &out = (*this)[i + 1];
-        if (*_trace) INFO("\n%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f => out[%2d,%2d,%2d,%2d]", i, nname(in.grad_fn), in.N(), in.H(), in.W(), in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
+        if (*_trace) { info((tt = System::clock()) - t1, i, in, out); t1 = tt; }
         _fstep(in, out);
-        if (*_trace && _check_nan(out)) { ERROR("nn#forward Nan in %s\n", nname(in.grad_fn)); this->err = 1; break; }
+        if (*_trace && _check_nan(out)) {
+            ERROR("nn#forward Nan in %s\n", nname(in.grad_fn));
+            INFO("in=");  in.show(true);
+            INFO("out="); out.show(true);
+            this->err = 1; break;
+        }
+        if (*_trace > 1) out.show(true);
     }
     if (input.is_dataset()) { onehot((mu::Dataset &)input); _hit = hit(true); }
     NLOG("\n} Model::forward %5.2f ms\n", System::clock() - t0);
@@ -267,21 +280,32 @@ int Model::_bprep(Tensor &tgt) {
         ERROR("Model#bprep: Onehot wrong shape[%d,%d,%d,%d] != [%d,%d,%d,%d]\n", tgt.N(), tgt.H(), tgt.W(), tgt.C(), out.N(), out.H(), out.W(), out.C());
         return 1;
     }
+    NLOG("Model::bprep input(onehot) numel=%ld OK {\n", (long)tgt.numel);
     switch ((*this)[-2].grad_fn) {
     case L_LINEAR: case L_SIGMOID: case L_SOFTMAX: case L_LOGSMAX: out -= tgt; break;   // dLoss = out - target
     default: out = tgt; break;                                                            // a pre-computed dLoss passes through
     }
+    if (*_trace) out.show(true);                          // the loss derivative (backprop.cu:104)
+    NLOG("}\n");
     return 0;
 }
 Model &Model::backprop(Tensor &tgt) {
+    auto trace = [](DU t, int i, Tensor &in, Tensor &out) {   // backprop.cu:40-47
+        INFO("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'Σ/n=%6.2f [%2d,%2d,%2d,%2d]",
+            t, i, nname(in.grad_fn),
+            in.N(), in.H(), in.W(), in.C(), in.xparm,
+            out.sum() / out.N() / out.C(),
+            out.N(), out.H(), out.W(), out.C());
+    };
     if (_bprep(tgt)) return *this;
     NLOG("\nModel::backprop starts trace=%d train=%d {", *_trace, train);
-    const DU t0 = System::clock();
+    DU t0 = System::clock(), t1 = t0, tt;
     for (int i = (int)numel - 2, j = 0; i >= 0; i--, j++) {
         Tensor &in = (*this)[i], &out = (*this)[i + 1];
-        if (*_trace) INFO("\n%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out[%2d,%2d,%2d,%2d]", i, nname(in.grad_fn), in.N(), in.H(), in.W(), in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
+        if (*_trace) { trace((tt = System::clock()) - t1, i, in, out); t1 = tt; }
         _bstep(in, out, j == 0);
-        if (*_trace && _check_nan(in)) { ERROR("nn#backprop Nan %s\n", nname(in.grad_fn)); this->err = 1; break; }
+        if (*_trace && _check_nan(in)) { ERROR("nn#backprop Nan %s\n", nname(in.grad_fn)); in.show(); out.show(); this->err = 1; break; }
+        if (*_trace > 1) in.show(true);
     }
     NLOG("\n} Model::backprop %5.2f ms\n", System::clock() - t0);
     return *this;

@@ -2,12 +2,15 @@
 // Restates src/nn/model.cpp:82-310, forward.cu:28-113, backprop.cu:39-140, gradient.cu:19-169,
 // loss.cpp:16-136 on top of the t4k_* C-ABI.  Everything is launched asynchronously on one
 // stream; the host only synchronises when a scalar (loss, hit) is read back.
+#include <chrono>
 #include "t4.h"
 #include <algorithm>
 
 namespace t4 {
 
 #define NLOG(...) do { if (trace && *trace) hprintf(__VA_ARGS__); } while (0)
+#define TSHOW(t, dump) hputs(fmt_show((t), (dump)))                     /* Tensor::show(dump) */
+static double trace_ms() { static const auto t0 = std::chrono::steady_clock::now(); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }   // System::clock()
 
 Tensor &Model::T4(uint32_t n, uint32_t h, uint32_t w, uint32_t c) { return Store::get().tensor(n, h, w, c); }
 Tensor &Model::VEC(uint64_t n) { return Store::get().tensor(n); }
@@ -282,6 +285,7 @@ void Model::end_capture(GraphSlot &slot, bool capturing) {
 // ---------------------------------------------------------------- forward
 Model &Model::forward(Tensor &input) {
     Tensor &n0 = at(0);
+    if (trace && *trace) TSHOW(input, true);             // preview of the input (forward.cu:31)
     if (input.numel != n0.numel) {
         hprintf("nn#forward dataset wrong shape[%d,%d,%d,%d] != model input[%d,%d,%d,%d]\n",
                input.N(), input.H(), input.W(), input.C(), n0.N(), n0.H(), n0.W(), n0.C());
@@ -290,13 +294,16 @@ Model &Model::forward(Tensor &input) {
     finalize(); current = this;
     hit_flags_pending_ = false;
     NLOG("\nModel::forward starts trace=%d {", *trace);
+    const double tf0 = trace_ms();
     if (!replay(g_fwd_, input.data, (int)train, nullptr)) {
         const bool cap = capturing_;
         run_forward(input);
         end_capture(g_fwd_, cap);
     }
+    if (input.type == T_DATASET && trace && *trace) traced_onehot_hit((Dataset &)input);
+    else
     if (input.type == T_DATASET && !hit_flags_pending_) onehot_hit((Dataset &)input);   // labels -> one-hot rows and the hit count, one launch (or none: they rode in the conv stack's head forward)
-    NLOG("\n} Model::forward\n");
+    NLOG("\n} Model::forward %5.2f ms\n", trace_ms() - tf0);
     return *this;
 }
 // data parallel: batch-norm statistics span all ranks during TRAINING passes only (every rank runs those in lock step); an
@@ -331,13 +338,17 @@ void Model::run_forward(Tensor &input) {
                 Tensor &m = *at(i).grad[4];
                 chk(t4k_dropout_mask(m.data, (long)m.numel, fork()), "rand"); masks = true;
             }
+    tl_ = trace_ms();
     stack_fresh_.assign(layer.size(), 0);                // which conv stacks this forward ran through t4k_conv_stack_fwd (their saved state is current)
     const float *x = input.data;
     for (int i = 0; i + 1 < L; i++) {
         Tensor &in = at(i), &out = at(i + 1);
-        if (trace && *trace)
-            hprintf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
+        if (trace && *trace) {                          // forward.cu:44-58: time since the previous layer's line, the layer, its input's sum per sample and channel
+            const double tt = trace_ms();
+            hprintf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] \xCE\xA3/n=%6.2f p=%6.3f => out[%2d,%2d,%2d,%2d]", tt - tl_, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.sum() / in.N() / in.C(), in.xparm, out.N(), out.H(), out.W(), out.C());
+            tl_ = tt;
+        }
         if (masks && in.grad_fn == T4K_L_DROPOUT) { join(); masks = false; }
         if (fused && run_of_[i] >= 0) {                 // one launch for the whole element-wise run
             const Run &r = runs_[run_of_[i]];
@@ -456,7 +467,13 @@ void Model::run_forward(Tensor &input) {
             continue;
         }
         x = fstep(in, out, x);
-        if (trace && *trace && out.has_nan()) { hprintf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+        if (trace && *trace && out.has_nan()) {
+            hprintf("nn#forward Nan in %s\n", LAYER_NAME[in.grad_fn]);
+            hprintf("in=");  TSHOW(in, true);
+            hprintf("out="); TSHOW(out, true);
+            err = true; break;
+        }
+        if (trace && *trace > 1) TSHOW(out, true);      // `2 trace`: every layer's output (forward.cu:68)
     }
     join();
 }
@@ -527,6 +544,36 @@ void Model::onehot_hit(Dataset &d) {                    // Model::onehot(Dataset
     chk(t4k_onehot_hit(d.label, hot->data, out.data, d.batch_sz, (int)E, hit_pin, stream()), "nn#onehot+hit");
     hit_pending_ = true;
 }
+void Model::traced_onehot_hit(Dataset &d) {             // the same two steps with the text `1 trace` / `2 trace` add (loss.cpp:47-107): synchronous, on host copies
+    Tensor &out = at(-1);
+    const uint32_t E = (uint32_t)out.HWC(), N = (uint32_t)d.batch_sz;
+    onehot(d);
+    std::vector<float> h, o; std::vector<uint32_t> lab(N);
+    hot->to_host(h); out.to_host(o);
+    if (N) { t4k_memcpy_d2h(lab.data(), d.label, sizeof(uint32_t) * N, stream()); t4k_sync(stream()); }
+    NLOG("\n  Model::onehot(ds) {\n");
+    if (*trace > 1)
+        for (uint32_t n = 0; n < N; n++) {
+            std::string l = "    n=" + std::to_string(n) + " {"; char b[16];
+            for (uint32_t e = 0; e < E; e++) { snprintf(b, sizeof(b), "%2.0f%c", h[(size_t)n * E + e], e == lab[n] ? '*' : ' '); l += b; }
+            hputs(l + "}\n");
+        }
+    NLOG("  } Model::onehot(ds)");
+    NLOG("\n  Model::hit {\n");
+    int cnt = 0;
+    for (uint32_t n = 0; n < out.N(); n++) {
+        const float *on = o.data() + (size_t)n * E, *hn = h.data() + (size_t)n * E;
+        uint32_t m = 0; for (uint32_t e = 1; e < E; e++) if (on[e] > on[m]) m = e;       // first maximum
+        cnt += (int)hn[m];
+        if (*trace > 1) {
+            std::string l = "    "; char b[24];
+            for (uint32_t e = 0; e < E; e++) { snprintf(b, sizeof(b), "%4.2f%c", on[e], fabsf(hn[e] - 1.0f) < DU_EPS ? (e == m ? '#' : '*') : (e == m ? '<' : ' ')); l += b; }
+            snprintf(b, sizeof(b), " n=%d cnt=%d\n", (int)n, cnt); hputs(l + b);
+        }
+    }
+    NLOG("  } Model::hit=%d", cnt);
+    hit_ = (int)dp_sum((DU)cnt); hit_pending_ = false; hit_flags_pending_ = false;
+}
 void Model::hit_lazy() {                                 // count on the GPU now, read it back only if somebody asks (`nn.hit`)
     if (!hot) { hit_ = 0; hit_pending_ = false; return; }
     Tensor &out = at(-1);
@@ -572,6 +619,7 @@ DU Model::loss(Loss op, Tensor &tgt) {                  // loss.cpp:119-136: non
     }
     if (loss_t) *loss_t = out; else loss_t = &Store::get().copy(out);
     const DU z = loss_t->loss(op, tgt);                  // = sum over the local rows / N_local
+    { static const char *opn[] = { "MSE", "BCE", "CE", "NLL" }; NLOG("  Model#loss: %s=%6.3f\n", opn[(int)op & 3], z); }
     const int world = t4k_comm_world();
     return (world < 2 || !train) ? z : SCALAR(dp_sum(z) / (DU)world);   // equal shards (the batch size is fixed by nn.model): mean of the rank means = whole-batch mean
 }
@@ -598,13 +646,13 @@ Model &Model::backprop(Tensor &tgt) {
         return *this;
     }
     finalize();
-    NLOG("\nModel::backprop starts trace=%d train=%d {", *trace, (int)train);
+    const double tb0 = trace_ms();
     if (!replay(g_bwd_, tgt.data, (int)train, nullptr)) {
         const bool cap = capturing_;
         run_backward(tgt);
         end_capture(g_bwd_, cap);
     }
-    NLOG("\n} Model::backprop\n");
+    NLOG("\n} Model::backprop %5.2f ms\n", trace_ms() - tb0);
     return *this;
 }
 // ---- data parallel overlap.  The slab fills tail-first (last layer's dW|dB first, tests/test_gpu_embed.py pins the order).
@@ -675,6 +723,7 @@ void Model::run_backward(Tensor &tgt) {
     const bool fused = use_fusion && !(trace && *trace) && !concurrent();
     int skip = 0;                                       // layers already handled by the prep launch
     const float *dy0 = nullptr;                         // ... and where they left the gradient (default: the output tensor)
+    NLOG("Model::bprep input(onehot) numel=%ld OK {\n", (long)tgt.numel);     // _bprep backprop.cu:84-106 (under trace nothing is fused: the loss derivative is a launch of its own)
     switch (at(-2).grad_fn) {
     case T4K_L_SIGMOID: case T4K_L_SOFTMAX: case T4K_L_LOGSMAX:
         if (fused && layer.size() > 3 && at(-3).grad_fn == T4K_L_LINEAR) { prep_tgt_ = &tgt; skip = 1; break; }   // rides in the linear backward launch
@@ -693,12 +742,19 @@ void Model::run_backward(Tensor &tgt) {
         chk(t4k_copy(tgt.data, out.data, (long)out.numel, s), "bprep"); break;
     }
     }
+    if (trace && *trace) TSHOW(out, true);              // the loss derivative (backprop.cu:104)
+    NLOG("}\n");
+    NLOG("\nModel::backprop starts trace=%d train=%d {", *trace, (int)train);
+    tl_ = trace_ms();
     const float *dy = dy0 ? dy0 : out.data;             // where the gradient w.r.t. the current layer's output lives
     for (int i = (int)layer.size() - 2 - skip, j = skip; i >= 0; i--, j++) {
         Tensor &in = at(i), &o = at(i + 1);
-        if (trace && *trace)
-            hprintf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", 0.0, i, LAYER_NAME[in.grad_fn],
+        if (trace && *trace) {                          // backprop.cu:40-58
+            const double tt = trace_ms();
+            hprintf("\n%6.2f:%3d> %s [%2d,%2d,%2d,%2d] p=%6.3f <= out'\xCE\xA3/n=%6.2f [%2d,%2d,%2d,%2d]", tt - tl_, i, LAYER_NAME[in.grad_fn],
                    in.N(), in.H(), in.W(), in.C(), in.xparm, o.sum() / o.N() / o.C(), o.N(), o.H(), o.W(), o.C());
+            tl_ = tt;
+        }
         if (fused && use_stack && j > 0) {              // does a sample-resident conv stack END at op i?  [conv + run] x n backward in ONE launch (+ the partial fold)
             if (stack_end_.empty()) {                   // op index of a stack's last op -> its first op (conv layer), built once per finalize
                 stack_end_.assign(layer.size(), -1);
@@ -746,7 +802,8 @@ void Model::run_backward(Tensor &tgt) {
             continue;
         }
         grads_ready(i, in);
-        if (trace && *trace && in.has_nan()) { hprintf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); err = true; break; }
+        if (trace && *trace && in.has_nan()) { hprintf("nn#backprop Nan %s\n", LAYER_NAME[in.grad_fn]); TSHOW(in, false); TSHOW(o, false); err = true; break; }
+        if (trace && *trace > 1) TSHOW(in, true);       // `2 trace`: every layer's dX (backprop.cu:67)
     }
     join();
 }

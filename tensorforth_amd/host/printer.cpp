@@ -1,5 +1,6 @@
 // printer.cpp - text forms of scalars, tensors and models; this defines what "same output" means
 // for a .4th run.  Follows src/io/aio.cpp:38-57, aio_tensor.cpp:16-58,141-226, aio_model.cpp:65-141.
+#include <math.h>
 #include "t4.h"
 #include <iomanip>
 #include <sstream>
@@ -123,6 +124,78 @@ std::string fmt_model(Model &m) {                        // aio_model.cpp:65-99
         o << parm_s(in, out) << '\n';
     }
     return o.str();
+}
+
+// ---- the tensor debugger of the trace levels (`1 trace`: input preview and the loss derivative; `2 trace`: every layer tensor) - Tensor::show / _dump / _view,
+// src/mu/tensor.cu:587-684.  A page [H][W][C] is printed channel by channel: numbers "%5.2f" with row sums, then (pages of more than 36 cells) a 16-shade
+// character picture, two characters per cell (the left neighbour, and the mean of the two), scaled so that +-2 sigma of the whole tensor spans the shades.
+static void dump_page(std::string &o, const float *v, uint32_t H, uint32_t W, uint32_t C) {
+    char b[64];
+    const float hw = (float)H * W, sr = sqrtf(hw);
+    const uint32_t sh = (uint32_t)(hw / sr) + ((hw - sr * sr) > 0.f ? 1 : 0);
+    const uint32_t h = W > 1 ? H : (hw < 36.0f ? 1 : sh), w = W > 1 ? W : (hw < 36.0f ? H : (uint32_t)sr);
+    std::vector<float> csum(C, 0.f);
+    for (uint32_t i = 0; i < h; i++) {
+        o += "\n";
+        float sum = 0.f;
+        for (uint32_t k = 0; k < C; k++) {
+            for (uint32_t j = 0; j < w; j++) {
+                const uint64_t n = j + (uint64_t)i * w;
+                if ((float)n >= hw) { o += " ...."; continue; }
+                const float r = v[k + n * C];
+                snprintf(b, sizeof(b), "%5.2f", r); o += b;
+                sum += r; csum[k] += r;
+            }
+            o += "|";
+        }
+        snprintf(b, sizeof(b), "\xCE\xA3=%6.3f", sum); o += b;
+    }
+    if (h > 1) {
+        o += "\n\xCE\xA3\xCE\xA3=";
+        for (uint32_t k = 0; k < C; k++) { snprintf(b, sizeof(b), "%6.3f ", csum[k]); o += b; }
+    }
+}
+static void view_page(std::string &o, const float *v, uint32_t H, uint32_t W, uint32_t C, float mean, float scale) {
+    static const char shades[] = " `.-:;!+*ixekO#@";
+    auto shade = [](float x) { const int i = (int)((x + 1.0) * 16 / 2); return shades[i < 0 ? 0 : (i < 16 ? i : 15)]; };
+    char b[64];
+    const uint64_t hw = (uint64_t)H * W, sr = (uint64_t)sqrtf((float)hw);
+    const uint32_t sh = (uint32_t)(hw / sr) + ((hw - sr * sr) > 0 ? 1 : 0);
+    const uint32_t w = W > 1 ? W : (hw < 36 ? H : (uint32_t)sr), h = W > 1 ? H : (hw < 36 ? 1 : sh);
+    std::vector<float> csum(C, 0.f);
+    for (uint32_t i = 0; i < h; i++) {
+        o += "\n";
+        for (uint32_t k = 0; k < C; k++) {
+            for (uint32_t j = 0; j < w; j++) {
+                const uint64_t n = j + (uint64_t)i * w;
+                if (n >= hw) { o += "  "; continue; }
+                const float r0 = v[k + (j > 0 ? n - 1 : n) * C], r1 = v[k + n * C];
+                const float x0 = (r0 - mean) * scale, x1 = (float)(((r0 + r1) * 0.5) - mean) * scale;
+                o += shade(x0); o += shade(x1);
+                csum[k] += r1;
+            }
+            o += "|";
+        }
+    }
+    if (h > 1) {
+        o += "\n\xCE\xA3\xCE\xA3=";
+        for (uint32_t k = 0; k < C; k++) { snprintf(b, sizeof(b), "%6.3f ", csum[k]); o += b; }
+    }
+    o += "\n";
+}
+std::string fmt_show(Tensor &t, bool dump) {
+    std::string o; char b[32];
+    const uint32_t N = t.N(), H = t.H(), W = t.W(), C = t.C();
+    const uint64_t hw = (uint64_t)H * W, page = hw * C;
+    const float mean = t.avg(), scale = (float)(0.5 / t.std());      // (0.5 / std: P = 95 %)
+    std::vector<float> h; t.to_host(h);
+    for (uint32_t n = 0; n < N; n++) {
+        const float *d = h.data() + (uint64_t)n * page;
+        if (dump || hw < 100) { snprintf(b, sizeof(b), "\nn=%d", (int)n); o += b; dump_page(o, d, H, W, C); }
+        if (hw > 36) view_page(o, d, H, W, C, mean, scale);
+    }
+    o += "\n";
+    return o;
 }
 
 } // namespace t4

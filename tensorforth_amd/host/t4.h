@@ -46,6 +46,7 @@ int  chk(int rc, const char *what);  // prints t4k_last_error() on failure (prin
 // Host-layer diagnostics (model / tensor / dataset messages): printed through the VM's output buffer when a VM is attached, so that
 // embedded users (ten4_eval / ten4_output, vm.py) see them and they stay in order with the text the words print; stdout otherwise.
 void hprintf(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void hputs(const std::string &text);                     // the same sink, unformatted, any length
 void set_host_sink(void (*fn)(const char *text, void *user), void *user);
 void get_host_sink(void (**fn)(const char *text, void *user), void **user);
 // TensorBoard sink (host/tboard.cpp): inactive - the words only print the reference's hint - until a log directory is given
@@ -255,7 +256,8 @@ struct Model : Obj {
     int  hit(bool recalc = true);
     DU   dp_sum(DU v);                         // SUM over the data-parallel ranks (identity without a communicator)
     void onehot_hit(Dataset &d);               // forward(dataset): one-hot rows + hit count in one launch
-    void hit_lazy();                           // forward(dataset): enqueue the count, defer the read-back
+    void hit_lazy();
+    void traced_onehot_hit(Dataset &d);                           // forward(dataset): enqueue the count, defer the read-back
     bool hit_pending_ = false;
     DU   loss(Loss op);
     DU   loss(Loss op, Tensor &tgt);
@@ -304,6 +306,7 @@ private:
     static bool use_fusion;                    // T4_FUSE=0 keeps one launch per layer
     std::vector<char> stack_fresh_;            // per first-op index: the latest forward took the stack kernel (so what it saved for the backward is current)
     std::vector<int> stack_end_;              // last op of a conv stack -> its first op (run_backward), rebuilt after finalize
+    double tl_ = 0;                                      // trace levels: clock of the previous layer's line
     bool stack_single_ = true;    // single-stage stacks too (round 3: slower, off; round 4, with the lazy first-layer dX and the fold inside the optimizer: the t4_40a net nn_c 0.0637 -> 0.0459 ms per step at N = 128)
     static bool use_head_bwd;                  // T4_HEAD_BWD=0: head backward and the linear layer in front of it as separate launches
     int also_ready_ = -1;                      // a second layer whose gradients the last bstep launch produced (run_backward reports it)
@@ -350,6 +353,7 @@ std::string fmt_scalar(DU v, int base);                 // src/io/aio.cpp:38-57
 std::string fmt_objname(Obj &o, bool view);             // "T2[2,3]" etc, src/io/aio_tensor.cpp:16-58
 std::string fmt_tensor(Tensor &t, int thres = 0);                      // src/io/aio_tensor.cpp:141-226
 std::string fmt_model(Model &m);                        // src/io/aio_model.cpp:65-141
+std::string fmt_show(Tensor &t, bool dump);              // Tensor::show src/mu/tensor.cu:587-684 (trace levels 1 / 2)
 std::string fmt_parm(Tensor &in, Tensor &out);          // src/io/aio_model.cpp:103-141 (layer parameter text)
 int model_save(Model &m, const char *fname);            // src/io/aio_model.cpp:16-35,143-181 (.t4 model file)
 int model_load(Model &m, const char *fname);            // src/io/aio_model.cpp:38-60,206-238 (parameter section)

@@ -41,6 +41,7 @@ void hprintf(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     if (g_sink) g_sink(buf, g_sink_user); else fputs(buf, stdout);
 }
+void hputs(const std::string &text) { if (g_sink) g_sink(text.c_str(), g_sink_user); else fputs(text.c_str(), stdout); }   // text of any length (hprintf formats into 1 KiB)
 int chk(int rc, const char *what) {
     if (rc != T4K_OK) hprintf("%s failed: %s\n", what, t4k_last_error());     // print-and-continue (ten4_types.h:25)
     return rc;

@@ -43,6 +43,33 @@ def normalise_refhost(text):
     return "tensorForth v4.0\n" + "\n".join(out) + "\n\ntensorForth done.\n"
 
 
+_TRACE_DROP = (r"^vm0> ", r"^NetVM::", r"^} NetVM::", r"^\\ ", r"^tensorForth", r"^VM\[", r"^ForthVM", r"^TensorVM", r"^NetVM", r"^\*\*\* redefined", r"^ *::", r"^\s*$",
+               r"^tenvm#", r"^\d+> tenvm#", r"^} tenvm#")
+
+
+def normalise_trace(text):
+    """What a run at `1 trace` / `2 trace` prints of the MODEL (src/nn/forward.cu:31-76, backprop.cu:40-107, loss.cpp, model.cpp: input preview, a line per
+    layer with its sum per sample and channel, the layer dumps of level 2, the loss derivative, Model::add / loss / onehot / hit lines) - and everything a
+    `0 trace` run prints.  Dropped: the VM-level trace (vm0> stack pushes, NetVM:: / tenvm# word brackets: not on the nn path), the start-up chatter, the
+    optimizer's block (Model::sgd / adam ... and #grad_alloc: per-tensor sums around every update and raw pointers - not restated by the product).  Masked:
+    the clock fields."""
+    import re
+    out = []; skip = False
+    for l in text.split("\n"):
+        if re.match(r"^Model::(sgd|adam|adamw) starts", l) or l.startswith("  #grad_alloc {"):
+            skip = True
+        if skip:
+            if re.match(r"^} Model::(sgd|adam|adamw)", l) or l.startswith("  } #grad_alloc"):
+                skip = False
+            continue
+        if any(re.match(p, l) for p in _TRACE_DROP):
+            continue
+        l = re.sub(r"^\s*-?\d+\.\d\d:(\s*\d+> )", r"<t>:\1", l)
+        l = re.sub(r"(} Model::(forward|backprop))\s+-?[\d.]+ ms", r"\1 <t> ms", l)
+        out.append(l.rstrip())
+    return "\n".join(out) + "\n"
+
+
 def normalise_oracle_vm(text):
     lines = text.splitlines()
     return "tensorForth v4.0\n" + "\n".join(lines[1:]) + "\n"
@@ -84,6 +111,11 @@ def main():
         with open(os.path.join(ROOT, "tests", "golden", "vm", name + ".out"), "w") as f:
             f.write(out)
         print("golden", name, "(oracle VM: decided hazard)" if name in HAZARD else "(reference VM)")
+    # trace levels: the reference's example t4_30d.4th UNCHANGED (it runs at `2 trace`; README.md:340-371 shows such a log) and cnn_step at `1 trace`
+    for tname, src in (("t4_30d", "/root/reference/examples/t4_30d.4th"), ("cnn_step_trace1", os.path.join(ROOT, "tests", "scripts_trace", "cnn_step_trace1.4th"))):
+        with open(os.path.join(ROOT, "tests", "golden", "refhost", "trace_" + tname + ".out"), "w") as f:
+            f.write(normalise_trace(run(REFHOST, src, d)))
+        print("golden trace", tname, "(reference VM)")
     # f-4 fixture: the reference's TensorBoard writer under a pinned clock
     tb = os.path.join(d, "tb")
     os.makedirs(tb)
