@@ -66,6 +66,28 @@ for (Nb, E0, E1) in [(128, 100, 980), (128, 10, 100), (256, 512, 784), (256, 1, 
           and np.array_equal(gB.cpu().numpy().astype(np.int64), dBv + 1) and np.array_equal(dXd.cpu().numpy().astype(np.int64), dX))
     if not ok:
         fails.append(("linear", Nb, E0, E1, rc, k.lib.t4k_last_error()))
+# the one-launch head backward (k_head_bwd_l32: dW1 || dX1 tiles that recompute dY1, column riders, the target-store rider - three kinds of workgroups
+# that wait for each other through epoch-tagged slots) on integer operands, twice in a row
+for (Nb, E1, EA, EB) in [(128, 980, 100, 10), (64, 512, 64, 16), (160, 256, 64, 10)]:
+    if k.lib.t4k_mlp_head_bwd_ok(Nb, E1, EA, EB) != 1:
+        continue                                              # (gates off: the host takes the two-launch path)
+    X1, W1, X2, W2 = ints(Nb, E1), ints(EA, E1), ints(Nb, EA), ints(EB, EA)
+    Pm, Tm = rng.integers(0, 3, (Nb, EB)).astype(np.float32), rng.integers(0, 2, (Nb, EB)).astype(np.float32)
+    Mk = rng.integers(0, 2, (Nb, EA)).astype(np.float32)
+    G2 = (Pm - Tm).astype(np.float64); DX2 = G2 @ W2.astype(np.float64); Y1 = DX2 * Mk
+    want = {"P": G2, "Y2": G2, "X2": DX2, "Y1": Y1, "DW2": 1 + G2.T @ X2.astype(np.float64), "DB2": 1 + G2.sum(0),
+            "DW1": 1 + Y1.T @ X1.astype(np.float64), "DB1": 1 + Y1.sum(0), "X1": Y1 @ W1.astype(np.float64)}
+    for rep in range(2):
+        d = {n_: up(v) for n_, v in dict(X1=X1, W1=W1, X2=X2, W2=W2, P=Pm, T=Tm, M=Mk).items()}
+        for n_, shp in (("Y1", (Nb, EA)), ("Y2", (Nb, EB))): d[n_] = torch.zeros(shp, device="cuda")
+        for n_, shp in (("DW1", (EA, E1)), ("DB1", (EA,)), ("DW2", (EB, EA)), ("DB2", (EB,))): d[n_] = torch.ones(shp, device="cuda")     # gradients ACCUMULATE
+        busy()
+        rc = k.lib.t4k_mlp_head_bwd(p(d["X2"]), p(d["W2"]), p(d["P"]), p(d["T"]), p(d["Y2"]), p(d["M"]), p(d["Y1"]), p(d["DW2"]), p(d["DB2"]),
+                                    p(d["X1"]), p(d["W1"]), p(d["DW1"]), p(d["DB1"]), Nb, E1, EA, EB, None)
+        rc = rc or k.lib.t4k_sync(None)
+        bad = [n_ for n_, w_ in want.items() if not np.array_equal(d[n_].cpu().numpy().astype(np.float64), w_)]
+        if rc != 0 or bad:
+            fails.append(("head_bwd", Nb, E1, EA, EB, rep, rc, bad, k.lib.t4k_last_error()))
 torch.cuda.synchronize()
 print("FAILS", fails)
 sys.exit(1 if fails else 0)
