@@ -326,10 +326,13 @@ void Model::_bstep(Tensor &in, Tensor &out, bool last_layer) {
 }
 
 // ===================================================================================================== nn/gradient.cu:20-126
+#define M2X(i)     (in.mtum[i] ? _mmu->OBJ2X(*in.mtum[i]) : 0)
 Model &Model::grad_alloc(t4_optimizer op) {                // :19-59 momentum / second-moment tensors, by optimizer (as written: a model that
-    for (int i = 0; i < (int)numel - 1; i++) {             // took its first step with nn.sgd keeps mtum[2] = NULL for a later nn.adam)
+    NLOG("  #grad_alloc {\n");                             // took its first step with nn.sgd keeps mtum[2] = NULL for a later nn.adam)
+    for (int i = 0; i < (int)numel - 1; i++) {
         Tensor &in = (*this)[i];
         Tensor *w = in.grad[0], *b = in.grad[1];
+        NLOG("    %3d> %8s w,b[%d,%d] ", i, nname(in.grad_fn), w ? 1 : 0, b ? 1 : 0);
         switch (op) {
         case OPTI_SGD:  in.mtum[0] = w; in.mtum[2] = NULL; in.mtum[1] = b; in.mtum[3] = NULL; break;
         case OPTI_SGDM:
@@ -341,19 +344,36 @@ Model &Model::grad_alloc(t4_optimizer op) {                // :19-59 momentum / 
             if (b && !in.mtum[1]) { in.mtum[1] = &T4(*b).zeros(); in.mtum[3] = &T4(*b).zeros(); }
             break;
         }
+        NLOG("mtum=%zx,%zx,%zx,%zx\n", (size_t)M2X(0), (size_t)M2X(1), (size_t)M2X(2), (size_t)M2X(3));
     }
+    NLOG("  } #grad_alloc\n");
     return *this;
 }
-Model &Model::gradient(const char *nm, t4_optimizer op, GdFunc fn, DU *parm) {
-    NLOG("\nModel::%s starts (%s) lr=%7.4f {\n", nm, train ? "training" : "testing", parm[0]);
+Model &Model::gradient(const char *nm, t4_optimizer op, GdFunc fn, DU *parm) {   // :63-126, with its trace text
+    auto step = [this, fn, parm](const char k, Tensor &g, Tensor &dg, Tensor &m, Tensor &v) {
+        NLOG("     %c[%2d,%2d,%2d,%2d] Σ=%6.3f - %6.3f", k, g.N(), g.H(), g.W(), g.C(), g.sum(), dg.sum());
+        if (*_trace > 1 && g.numel < T4_DIM_SQ) {
+            INFO("\nbefore %c =", k); Tensor::_dump(g.data, g.H(), g.W(), g.C());
+            INFO("\nbefore d%c=", k); Tensor::_dump(dg.data, dg.H(), dg.W(), dg.C());
+            fn(parm, g, dg, m, v);
+            INFO("\nafter  %c =", k); Tensor::_dump(g.data, g.H(), g.W(), g.C());
+            INFO("\nafter  d%c=", k); Tensor::_dump(dg.data, dg.H(), dg.W(), dg.C());
+            INFO("\n");
+        }
+        else fn(parm, g, dg, m, v);
+        NLOG(" => %cΣ=%6.3f\n", k, g.sum());
+    };
+    NLOG("\nModel::%s starts (%s) batch_sz=%d, lr=%7.4f, mtum/b1=%6.3f, b2=%6.3f {\n", nm, train ? "trainning" : "testing", (*this)[1].N(), parm[0], parm[1], parm[2]);
     if (_iter++ == 0 && epoch == 0) grad_alloc(op);
     if (!train) return *this;
+    DU t0 = System::clock();
     for (int i = 0; i < (int)numel - 1; i++) {
         Tensor &in = (*this)[i];
-        if (in.mtum[0]) { fn(parm, *in.grad[0], *in.grad[2], *in.mtum[0], *in.mtum[2]); if (*_trace && _check_nan(*in.grad[0])) { ERROR("nn::grad.w Nan %s\n", nname(in.grad_fn)); this->err = 1; break; } }
-        if (in.mtum[1]) { fn(parm, *in.grad[1], *in.grad[3], *in.mtum[1], *in.mtum[3]); if (*_trace && _check_nan(*in.grad[1])) { ERROR("nn::grad.b Nan %s\n", nname(in.grad_fn)); this->err = 1; break; } }
+        NLOG("  %d> %s\n", i, nname(in.grad_fn));
+        if (in.mtum[0]) { step('w', *in.grad[0], *in.grad[2], *in.mtum[0], *in.mtum[2]); if (*_trace && _check_nan(*in.grad[0])) { ERROR("nn::grad.w Nan %s\n", nname(in.grad_fn)); in.grad[0]->show(); this->err = 1; break; } }
+        if (in.mtum[1]) { step('b', *in.grad[1], *in.grad[3], *in.mtum[1], *in.mtum[3]); if (*_trace && _check_nan(*in.grad[1])) { ERROR("nn::grad.b Nan %s\n", nname(in.grad_fn)); in.grad[1]->show(); this->err = 1; break; } }
     }
-    NLOG("} Model::%s\n", nm);
+    NLOG("} Model::%s %5.2f ms\n", nm, System::clock() - t0);
     return *this;
 }
 } // namespace t4::nn

@@ -988,8 +988,10 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
     finalize();
     const bool first = (iter++ == 0 && epoch == 0);
     if (first || tab_kind != op) {                      // grad_alloc gradient.cu:19-59 (+ re-allocation when the optimizer is switched mid-run,
+        if (first) NLOG("  #grad_alloc {\n");
         for (int i = 0; i + 1 < (int)layer.size(); i++) {   //   where the reference would read the SGD alias / a null V)
             Tensor &in = at(i); Tensor *w = in.grad[0], *b = in.grad[1];
+            if (first) NLOG("    %3d> %8s w,b[%d,%d] mtum=<pool offsets>\n", i, LAYER_NAME[in.grad_fn], w ? 1 : 0, b ? 1 : 0);   // (the reference prints its pool offsets of m / v here)
             Tensor *g[2] = { w, b };
             for (int k = 0; k < 2; k++) {
                 if (!g[k]) continue;
@@ -998,10 +1000,30 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
                 if (op != OPTI_SGDM && !in.mtum[k + 2]) in.mtum[k + 2] = &T4(g[k]->N(), g[k]->H(), g[k]->W(), g[k]->C()).zeros();
             }
         }
+        if (first) NLOG("  } #grad_alloc\n");
         build_table(op);
     }
     if (!train) return *this;
     if (!tab_dev || tab_kind != op) build_table(op);
+    // trace levels (gradient.cu:66-79,95-99): per layer, per parameter tensor the sums of the parameter and of its gradient before the update and the
+    // parameter's sum after it; `2 trace`: small tensors (< 256 elements) dumped before and after.  The update itself is ONE launch over all tensors
+    // here, so the "before" halves are collected first and the text is assembled behind the launch (the tensors are independent: same numbers).
+    struct TrLine { int layer; char k; Tensor *g, *dg; std::string head, before; };
+    std::vector<TrLine> trl;
+    const double tg0 = trace_ms();
+    if (trace && *trace)
+        for (int i = 0; i + 1 < (int)layer.size(); i++) {
+            Tensor &in = at(i);
+            for (int k = 0; k < 2; k++) {
+                if (!in.mtum[k] || !in.grad[k] || !in.grad[k + 2]) continue;
+                Tensor &g = *in.grad[k], &dg = *in.grad[k + 2];
+                char b[160]; const char c = k ? 'b' : 'w';
+                snprintf(b, sizeof(b), "     %c[%2d,%2d,%2d,%2d] \xCE\xA3=%6.3f - %6.3f", c, g.N(), g.H(), g.W(), g.C(), g.sum(), dg.sum());
+                TrLine t{ i, c, &g, &dg, b, "" };
+                if (*trace > 1 && g.numel < 256) t.before = std::string("\nbefore ") + c + " =" + fmt_dump(g) + "\nbefore d" + c + "=" + fmt_dump(dg);
+                trl.push_back(t);
+            }
+        }
     const int kind = (op == OPTI_ADAM) ? 1 : (op == OPTI_ADAMW ? 2 : 0);
     const float p[4] = { lr, b1, b2, wd };
     // data parallel: every rank holds a shard of the batch; SUM the gradient slab (raw batch sums, quirk a-19) in-order
@@ -1027,7 +1049,19 @@ Model &Model::gradient(const char *nm, Optim op, DU lr, DU b1, DU b2, DU wd) {  
         t4k_opt_snapshot(nullptr, nullptr); w0_saved_ = false;
         hprintf("nn#%s: weight snapshot not taken - the first layer's deferred dX is no longer available\n", nm);
     }
-    NLOG("} Model::%s\n", nm);
+    if (trace && *trace) {
+        size_t q = 0;
+        for (int i = 0; i + 1 < (int)layer.size(); i++) {
+            hprintf("  %d> %s\n", i, LAYER_NAME[at(i).grad_fn]);
+            for (; q < trl.size() && trl[q].layer == i; q++) {
+                const TrLine &t = trl[q];
+                hputs(t.head);
+                if (!t.before.empty()) hputs(t.before + "\nafter  " + t.k + " =" + fmt_dump(*t.g) + "\nafter  d" + t.k + "=" + fmt_dump(*t.dg) + "\n");
+                hprintf(" => %c\xCE\xA3=%6.3f\n", t.k, t.g->sum());
+            }
+        }
+    }
+    NLOG("} Model::%s %5.2f ms\n", nm, trace_ms() - tg0);
     return *this;
 }
 Model &Model::sgd(DU lr, DU b) { return gradient("sgd", ZEQ(b) ? OPTI_SGD : OPTI_SGDM, lr, iter ? b : 0.0f, 0, 0); }   // `_iter ? b : 0` gradient.cu:139

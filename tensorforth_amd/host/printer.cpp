@@ -183,6 +183,11 @@ static void view_page(std::string &o, const float *v, uint32_t H, uint32_t W, ui
     }
     o += "\n";
 }
+std::string fmt_dump(Tensor &t) {                           // Tensor::_dump(data, H, W, C) of the whole tensor's first page (gradient.cu:70-74 hands it g.H(), g.W(), g.C())
+    std::string o; std::vector<float> h; t.to_host(h);
+    dump_page(o, h.data(), t.H(), t.W(), t.C());
+    return o;
+}
 std::string fmt_show(Tensor &t, bool dump) {
     std::string o; char b[32];
     const uint32_t N = t.N(), H = t.H(), W = t.W(), C = t.C();

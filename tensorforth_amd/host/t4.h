@@ -353,6 +353,7 @@ std::string fmt_scalar(DU v, int base);                 // src/io/aio.cpp:38-57
 std::string fmt_objname(Obj &o, bool view);             // "T2[2,3]" etc, src/io/aio_tensor.cpp:16-58
 std::string fmt_tensor(Tensor &t, int thres = 0);                      // src/io/aio_tensor.cpp:141-226
 std::string fmt_model(Model &m);                        // src/io/aio_model.cpp:65-141
+std::string fmt_dump(Tensor &t);                        // Tensor::_dump of a parameter tensor (optimizer trace, gradient.cu:70-74)
 std::string fmt_show(Tensor &t, bool dump);              // Tensor::show src/mu/tensor.cu:587-684 (trace levels 1 / 2)
 std::string fmt_parm(Tensor &in, Tensor &out);          // src/io/aio_model.cpp:103-141 (layer parameter text)
 int model_save(Model &m, const char *fname);            // src/io/aio_model.cpp:16-35,143-181 (.t4 model file)

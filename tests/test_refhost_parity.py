@@ -129,8 +129,9 @@ def test_committed_goldens_are_the_reference_vms_output(refhost, workdir, name):
 # ---- trace levels (VERDICT r5 missing #3 / task 7b).  The reference's default trace level is 1 (ten4_config.h:19) and README.md:340-371 validates t4_30d with a
 # `2 trace` log: input preview, a line per layer (layer, shape, sum per sample and channel, parameter, output shape), layer dumps, the loss derivative, Model::add /
 # loss lines.  The nn part of that text comes from forward.cu / backprop.cu (restated against the reference's headers in integration/t4k_bind_host.cpp, the dumps
-# Tensor::show / _dump / _view in t4k_bind.cpp) and from the reference's real model.cpp / loss.cpp.  tools/regen_vm_goldens.normalise_trace says what is dropped
-# (VM-level trace, the optimizer's block) and masked (clock fields); everything else must agree line for line, numbers as printed.
+# Tensor::show / _dump / _view in t4k_bind.cpp; gradient.cu's optimizer block - #grad_alloc, the sums around every update, the small tensors' dumps of level 2) and from
+# the reference's real model.cpp / loss.cpp.  tools/regen_vm_goldens.normalise_trace says what is dropped (the VM-level trace) and masked (clock fields, the pool offsets
+# #grad_alloc prints); everything else must agree line for line, numbers as printed.
 TRACE_RUNS = [("t4_30d", None), ("cnn_step_trace1", os.path.join(ROOT, "tests", "scripts_trace", "cnn_step_trace1.4th"))]
 
 

@@ -50,20 +50,16 @@ _TRACE_DROP = (r"^vm0> ", r"^NetVM::", r"^} NetVM::", r"^\\ ", r"^tensorForth", 
 def normalise_trace(text):
     """What a run at `1 trace` / `2 trace` prints of the MODEL (src/nn/forward.cu:31-76, backprop.cu:40-107, loss.cpp, model.cpp: input preview, a line per
     layer with its sum per sample and channel, the layer dumps of level 2, the loss derivative, Model::add / loss / onehot / hit lines) - and everything a
-    `0 trace` run prints.  Dropped: the VM-level trace (vm0> stack pushes, NetVM:: / tenvm# word brackets: not on the nn path), the start-up chatter, the
-    optimizer's block (Model::sgd / adam ... and #grad_alloc: per-tensor sums around every update and raw pointers - not restated by the product).  Masked:
-    the clock fields."""
+    `0 trace` run prints, the optimizer's block included (gradient.cu:19-126: #grad_alloc, per layer and parameter tensor the sums around the update, the
+    small tensors' dumps at level 2).  Dropped: the VM-level trace (vm0> stack pushes, NetVM:: / tenvm# word brackets: not on the nn path), the start-up
+    chatter.  Masked: the clock fields and the pool offsets #grad_alloc prints."""
     import re
-    out = []; skip = False
+    out = []
     for l in text.split("\n"):
-        if re.match(r"^Model::(sgd|adam|adamw) starts", l) or l.startswith("  #grad_alloc {"):
-            skip = True
-        if skip:
-            if re.match(r"^} Model::(sgd|adam|adamw)", l) or l.startswith("  } #grad_alloc"):
-                skip = False
-            continue
         if any(re.match(p, l) for p in _TRACE_DROP):
             continue
+        l = re.sub(r"(w,b\[\d,\d\] )mtum=.*$", r"\1mtum=<pool offsets>", l)              # #grad_alloc: the reference prints the pool offsets of its m / v tensors
+        l = re.sub(r"(} Model::(sgd|adam|adamw))\s+-?[\d.]+ ms", r"\1 <t> ms", l)
         l = re.sub(r"^\s*-?\d+\.\d\d:(\s*\d+> )", r"<t>:\1", l)
         l = re.sub(r"(} Model::(forward|backprop))\s+-?[\d.]+ ms", r"\1 <t> ms", l)
         out.append(l.rstrip())
