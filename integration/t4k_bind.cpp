@@ -416,6 +416,17 @@ Tensor &Model::onehot(mu::Dataset &dset) {
     warn(t4k_memcpy_h2d(lab, dset.label, sizeof(U32) * (size_t)dset.batch_sz, nullptr), "nn#onehot");
     if ((U32)dset.batch_sz < N) _hot->zeros();
     warn(t4k_onehot((const uint32_t *)lab, _hot->data, dset.batch_sz, (int)E, nullptr), "nn#onehot");
+    NLOG("\n  Model::onehot(ds) {\n");                    // loss.cpp:62-69: the text of its host loop
+    if (*_trace > 1) {
+        std::vector<DU> h((size_t)N * E); Tensor::d2h(h.data(), _hot->data, (int)(sizeof(DU) * h.size()));
+        for (U32 n = 0; n < (U32)dset.batch_sz; n++) {
+            const U32 m = dset.label[n];
+            INFO("    n=%d {", n);
+            for (U32 e = 0; e < E; e++) INFO("%2.0f%c", h[(size_t)n * E + e], e == m ? '*' : ' ');
+            INFO("}\n");
+        }
+    }
+    NLOG("  } Model::onehot(ds)");
     return *_hot;
 }
 int Model::hit(bool recalc) {
@@ -423,6 +434,23 @@ int Model::hit(bool recalc) {
     Tensor &out = (*this)[-1];
     int *c = (int *)(scratch() + 8);
     warn(t4k_hit(out.data, _hot->data, (int)out.N(), (int)out.HWC(), c, nullptr), "nn#hit");
-    return _hit = read_int(c);
+    _hit = read_int(c);
+    NLOG("\n  Model::hit {\n");                           // loss.cpp:96-104
+    if (*_trace > 1) {
+        const U32 N = out.N(), E = (U32)out.HWC();
+        std::vector<DU> o((size_t)N * E), h((size_t)N * E);
+        Tensor::d2h(o.data(), out.data, (int)(sizeof(DU) * o.size())); Tensor::d2h(h.data(), _hot->data, (int)(sizeof(DU) * h.size()));
+        U32 cnt = 0;
+        for (U32 n = 0; n < N; n++) {
+            const DU *on = o.data() + (size_t)n * E, *hn = h.data() + (size_t)n * E;
+            U32 m = 0; for (U32 e = 1; e < E; e++) if (on[e] > on[m]) m = e;
+            cnt += D2I(hn[m]);
+            INFO("    ");
+            for (U32 e = 0; e < E; e++) INFO("%4.2f%c", on[e], EQ(hn[e], DU1) ? (e == m ? '#' : '*') : (e == m ? '<' : ' '));
+            INFO(" n=%d cnt=%d\n", n, cnt);
+        }
+    }
+    NLOG("  } Model::hit=%d", _hit);
+    return _hit;
 }
 } // namespace t4::nn

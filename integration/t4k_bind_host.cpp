@@ -187,19 +187,25 @@ void Dataset::normalize(DU mean, DU scale) {
     _mean = mean;
     if (ZEQ(scale)) { ERROR("scale == 0?\n"); _scale = 1.0f; } else _scale = 1.0f / scale;
 }
-int Dataset::fetch(char *ds_name, bool rewind, bool trace) {
+int Dataset::fetch(char *ds_name, bool rewind, bool trace) {   // dataset.cu:64-121, trace text included
+    static const char *fn = "dataset#fetch";
+    if (trace) INFO("  %s %s batch[%d] {\n", fn, ds_name ? ds_name : (rewind ? "rewind" : ""), batch_id);
     ld::Corpus *cp = ld::Loader::get(*this, ds_name);
-    if (!cp) { ERROR("  } dataset#fetch => not found in Loader\n"); return -1; }
+    if (!cp) { ERROR("  } %s => not found in Loader\n", fn); return -1; }
     if (ds_name) {                                        // first use: dimensions from the corpus
-        if (cp->init(N(), trace) == NULL) { ERROR("  } dataset#fetch => corpus init failed!\n"); return -2; }
+        if (cp->init(N(), trace) == NULL) { ERROR("  } %s => corpus init failed!\n", fn); return -2; }
         dataset_size = cp->corpus_sz;
         _reshape(cp->N, cp->H, cp->W, cp->C);
     }
     if (rewind) { cp->rewind(); batch_id = done = 0; }
-    if (!cp->fetch(batch_id, trace)) { ERROR("  } dataset#fetch => corpus fetch failed\n"); return -3; }
-    batch_sz = cp->batch_sz; done = cp->eof;
-    if (trace) INFO("  dataset#fetch => batch[%d] %d record(s)%s\n", batch_id, batch_sz, done ? ", completed" : "");
-    _load(cp->data, cp->label, batch_sz);                 // t4k_bind.cpp: one H2D copy + u8 -> f32 on the GPU
+    if (!cp->fetch(batch_id, trace)) { ERROR("  } %s => corpus fetch failed\n", fn); return -3; }
+    int n = batch_sz = cp->batch_sz; done = cp->eof;
+    if (trace) {
+        INFO("  } %s => batch[%d] ", fn, batch_id);
+        if (done) INFO("completed, no more data.\n");
+        else      INFO("%d record(s) loaded\n", n);
+    }
+    _load(cp->data, cp->label, n);                        // t4k_bind.cpp: one H2D copy + u8 -> f32 on the GPU
     batch_id++;
     return 0;
 }

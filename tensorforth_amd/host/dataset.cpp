@@ -25,7 +25,7 @@ static std::map<std::string, Corpus *> &corpora() {      // Loader::init src/ld/
 }
 static uint32_t be32(FILE *f) { uint8_t b[4] = {0, 0, 0, 0}; if (fread(b, 1, 4, f) != 4) return 0; return (b[0] << 24) | (b[1] << 16) | (b[2] << 8) | b[3]; }
 
-bool Corpus::init(int batch) {
+bool Corpus::init(int batch, bool trace) {
     idle();
     if (N != batch) for (int sl = 0; sl < 2; sl++) { if (pix[sl]) { t4k_host_free(pix[sl]); pix[sl] = nullptr; } if (lab[sl]) { t4k_host_free(lab[sl]); lab[sl] = nullptr; } }
     N = batch;
@@ -35,12 +35,15 @@ bool Corpus::init(int batch) {
     if (cifar) {                                         // 1 label byte + 3x32x32 planar bytes per sample
         H = W = 32; C = 3;
         fseek(fd, 0, SEEK_END); corpus_sz = (int)(ftell(fd) / 3073); fseek(fd, 0, SEEK_SET);
+        if (trace) hprintf("\tCIFAR-10 samples: [%d][%d,%d,%d]\n", corpus_sz, H, W, C);      // cifar10.cpp:44
         return true;
     }
     fl = fopen(f_label.c_str(), "rb");
     if (!fl) { hprintf("failed to open file %s\n", f_label.c_str()); return false; }
-    be32(fl); const uint32_t n1 = be32(fl);              // label magic 0x0801, count
-    be32(fd); const uint32_t n = be32(fd); H = be32(fd); W = be32(fd); C = 1;   // image magic 0x0803
+    const uint32_t x1 = be32(fl), n1 = be32(fl);         // label magic 0x0801, count
+    if (trace) hprintf("\tMNIST label: magic=%08x => [%d]\n", x1, n1);                             // mnist.cpp:43
+    const uint32_t x0 = be32(fd), n = be32(fd); H = be32(fd); W = be32(fd); C = 1;   // image magic 0x0803
+    if (trace) hprintf("\tMNIST image: magic=%08x => [%d][%d,%d,%d]\n", x0, n, H, W, C);            // mnist.cpp:51
     if (n != n1) { hprintf("Mnist::init label count %d != image count %d\n", n1, n); return false; }
     corpus_sz = n;
     return true;
@@ -162,12 +165,15 @@ void Dataset::release_ring() {
     mark_bid = -1;
     data = nullptr; label = nullptr; ring_numel = 0;
 }
+int *Dataset::trace = nullptr;
 int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
+    const bool tr = trace && *trace;                     // the words' trace level (sys.cpp:171-189 hands it down): the reference's text of a fetch
+    if (tr) hprintf("  dataset#fetch %s batch[%d] {\n", ds_name ? ds_name : (rewind ? "rewind" : ""), batch_id);
     if (ds_name) {
         auto it = corpora().find(ds_name);
         if (it == corpora().end()) { hprintf("  } dataset#fetch => not found in Loader\n"); return -1; }
         cp = it->second;
-        if (!cp->init(N())) { hprintf("  } dataset#fetch => corpus init failed!\n"); return -2; }
+        if (!cp->init(N(), tr)) { hprintf("  } dataset#fetch => corpus init failed!\n"); return -2; }
         dataset_size = cp->corpus_sz;
         numel = (uint64_t)cp->N * cp->H * cp->W * cp->C;
         rank = 4; shape[0] = cp->H; shape[1] = cp->W; shape[2] = cp->C; shape[3] = cp->N;
@@ -209,6 +215,11 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     }
     data = dbuf[r]; label = lbuf[r]; batch_sz = dev_n[r];
     done = ((long)b * cp->N + batch_sz >= cp->corpus_sz) ? 1 : 0;
+    if (tr) {                                            // mnist.cpp:88-90 / cifar10.cpp:71-73, dataset.cu:101-106
+        hprintf("\t%s batch[%d] loaded=%ld/%d done=%d\n", cp->cifar ? "CIFAR-10" : "Mnist", b, (long)b * cp->N + batch_sz, cp->corpus_sz, done);
+        hprintf("  } dataset#fetch => batch[%d] ", b);
+        if (done) hprintf("completed, no more data.\n"); else hprintf("%d record(s) loaded\n", batch_sz);
+    }
     if (!done) {
         // ---- batch b + 1 goes to its buffer on the side stream if the reader already holds it (full batches only); a cold start just asks for it
         const int b1 = b + 1, r1 = b1 % RING;

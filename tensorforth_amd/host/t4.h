@@ -186,7 +186,7 @@ struct Corpus {
     std::string name, f_data, f_label;
     int N = 0, H = 0, W = 0, C = 0, corpus_sz = 0;
     FILE *fd = nullptr, *fl = nullptr;
-    bool init(int batch);                      // src/ld/mnist.cpp:21-62 (IDX header, big endian)
+    bool init(int batch, bool trace = false);  // src/ld/mnist.cpp:21-62 (IDX header, big endian), cifar10.cpp:21-50
     bool cifar = false;
     int  n_batches() const { return N > 0 ? (corpus_sz + N - 1) / N : 0; }
     // double-buffered pinned staging: slot s = batch & 1 holds u8 pixels + u32 labels of one batch; a persistent
@@ -223,6 +223,7 @@ struct Dataset : Tensor {
     Dataset() { for (int i = 0; i < RING; i++) dev_bid[i] = -1; }
     void set_norm(DU m, DU s) { mean = m; scale = 1.0f / s; }
     int  fetch(const char *ds_name, bool rewind);
+    static int *trace;                         // the VM's trace level (null: off): Dataset::fetch prints the reference's text at level >= 1
     void release_ring();
 };
 

@@ -14,11 +14,12 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-VM::VM() : pmem_(PMEM_SZ, 0) { base() = 10; }
+VM::VM() : pmem_(PMEM_SZ, 0) { base() = 10; Dataset::trace = &trace_lvl; }        // (the dataset words print the reference's fetch text at trace level >= 1)
 static void vm_sink(const char *t, void *u) { ((VM *)u)->host_msg(t); }
 VM::~VM() {
     void (*fn)(const char *, void *); void *user; get_host_sink(&fn, &user);
     if (user == this) set_host_sink(nullptr, nullptr);
+    if (Dataset::trace == &trace_lvl) Dataset::trace = nullptr;
 }
 namespace {
 // host-layer messages (hprintf / chk) reach the VM that is EXECUTING: the sink is process-global, several VMs may be embedded
@@ -130,14 +131,15 @@ void VM::nest() {
         case P_KEY:  PUSH((DU)getchar()); break;
         default:
             if (udf) { rs_.push_back((DU)ip_); ip_ = ioff; }
-            else { dict_[ioff].xt(); if (hold_) msg_pos_ = out_.size(); }   // (a serviced word: later diagnostics follow what the service printed)
+            else { const size_t h0 = holds_; dict_[ioff].xt(); if (holds_ != h0) msg_pos_ = out_.size(); }   // (a word that was SERVICED: the reference flushes the VM's text there - later diagnostics follow it; words behind it in the same
+                                                                                                              //  colon word print into the buffer again, host messages go in front of that - the reference's printf / fout interleaving)
         }
     }
 }
 void VM::call(int w) {
     Word &c = dict_[w];
     if (c.udf) { rs_.push_back((DU)ip_); ip_ = c.pfa; nest(); }
-    else { c.xt(); if (hold_) msg_pos_ = out_.size(); }
+    else { const size_t h0 = holds_; c.xt(); if (holds_ != h0) msg_pos_ = out_.size(); }
 }
 
 // ---------------------------------------------------------------- outer interpreter

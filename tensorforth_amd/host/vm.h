@@ -46,7 +46,8 @@ private:
     bool compile_ = false, stop_ = false, query_ = true;
     size_t msg_pos_ = 0;
     void hold_begin() { msg_pos_ = out_.size(); }          // a host service starts: everything buffered so far is flushed first, the service's own messages follow it
-    void hold_end() { hold_ = true; msg_pos_ = out_.size(); }
+    void hold_end() { hold_ = true; holds_++; msg_pos_ = out_.size(); }
+    size_t holds_ = 0;                                    // host services so far (a word that ended in one is where the reference flushes)
     bool hold_ = false;                       // a word asked for host service (reference: state = HOLD, eforth.h:85-92): the outer interpreter
                                               // drops the rest of the input line (sys.cpp:101-108 clears the buffer after resume(), vm.cpp:59)
     std::string line_; size_t pos_ = 0;

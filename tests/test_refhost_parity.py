@@ -153,6 +153,26 @@ def test_trace_level_output_of_the_model_equals_the_reference_vms(refhost, workd
         assert f.read() == ref, "stale golden: run tools/regen_vm_goldens.py"
 
 
+@needs_ref
+@pytest.mark.parametrize("level", [1, 2])
+def test_trace_levels_of_a_dataset_fed_epoch_equal_the_reference_vms(refhost, workdir, level):
+    """tests/scripts/mnist_epoch.4th with its `0 trace` turned into `1 trace` / `2 trace` (edited on the text read here): the dataset path's text on top of the model's -
+    `dataset#fetch` brackets (dataset.cu:70-106), the loaders' header and batch lines (the reference's real src/ld/mnist.cpp), `Model::onehot(ds)` / `Model::hit` with their
+    per-sample lines at level 2 (loss.cpp:47-107), the optimizer block of every step - and the INTERLEAVING of the VM's buffered output with the host's printf text inside a
+    colon-word loop (the reference flushes the VM's text where a word is serviced: the loss printed by `.` appears in front of the NEXT fetch's bracket).  78 426 / 444 167 lines;
+    no golden is committed for these (6 / 35 MB) - the comparison is live."""
+    from regen_vm_goldens import normalise_trace
+    src = open(os.path.join(SCRIPTS, "mnist_epoch.4th")).read()
+    assert "\n0 trace\n" in src
+    src = src.replace("\n0 trace\n", "\n%d trace\n" % level, 1)
+    ref = normalise_trace(_run(refhost, src, workdir)); own = normalise_trace(_run(TEN4_ORACLE, src, workdir))
+    assert "dataset#fetch" in ref and "Model::hit=" in ref and len(ref.splitlines()) > 50000
+    if ref != own:
+        import difflib
+        d = list(difflib.unified_diff(ref.splitlines(), own.splitlines(), lineterm="", n=0))
+        assert not d, "\n".join(d[:40])
+
+
 def test_trace_level_output_of_the_product_host_equals_the_committed_reference_log(workdir):
     """the same comparison without the reference tree: the committed log of the reference VM (tests/golden/refhost/trace_cnn_step_trace1.out) against the
     product's host over the oracle, at `1 trace`"""
