@@ -215,11 +215,21 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     }
     data = dbuf[r]; label = lbuf[r]; batch_sz = dev_n[r];
     done = ((long)b * cp->N + batch_sz >= cp->corpus_sz) ? 1 : 0;
-    if (tr) {                                            // mnist.cpp:88-90 / cifar10.cpp:71-73, dataset.cu:101-106
+    const bool first_batch_of_corpus = !cp->names_shown_latch;
+    if (tr) {                                            // mnist.cpp:88-90 / cifar10.cpp:71-73,122-132, dataset.cu:101-106
+        if (cp->cifar && first_batch_of_corpus) {             // the first batch a CIFAR corpus ever reads: its class names, 16 to a line (cifar10.cpp dump_1st; `first` = the label block did not exist yet)
+            static const char *nm[] = { "plane", "car", "bird", "cat", "deer", "dog", "frog ", "horse", "ship ", "truck", "ERROR" };
+            std::vector<uint32_t> lab((size_t)batch_sz);
+            if (batch_sz) { t4k_memcpy_d2h(lab.data(), label, sizeof(uint32_t) * (size_t)batch_sz, stream()); t4k_sync(stream()); }
+            std::string o; char b16[16];
+            for (int i2 = 0; i2 < batch_sz; i2++) { snprintf(b16, sizeof(b16), "%-5s%c", nm[lab[i2] < 10 ? lab[i2] : 10], ((i2 + 1) % 16) ? ' ' : '\n'); o += b16; }
+            hputs(o);
+        }
         hprintf("\t%s batch[%d] loaded=%ld/%d done=%d\n", cp->cifar ? "CIFAR-10" : "Mnist", b, (long)b * cp->N + batch_sz, cp->corpus_sz, done);
         hprintf("  } dataset#fetch => batch[%d] ", b);
         if (done) hprintf("completed, no more data.\n"); else hprintf("%d record(s) loaded\n", batch_sz);
     }
+    cp->names_shown_latch = true;
     if (!done) {
         // ---- batch b + 1 goes to its buffer on the side stream if the reader already holds it (full batches only); a cold start just asks for it
         const int b1 = b + 1, r1 = b1 % RING;

@@ -188,6 +188,7 @@ struct Corpus {
     FILE *fd = nullptr, *fl = nullptr;
     bool init(int batch, bool trace = false);  // src/ld/mnist.cpp:21-62 (IDX header, big endian), cifar10.cpp:21-50
     bool cifar = false;
+    bool names_shown_latch = false;            // a batch of this corpus has been fetched before (cifar10.cpp: `first` = its label block did not exist yet)
     int  n_batches() const { return N > 0 ? (corpus_sz + N - 1) / N : 0; }
     // double-buffered pinned staging: slot s = batch & 1 holds u8 pixels + u32 labels of one batch; a persistent
     // reader thread fills a slot (after the event of the launch that last read it) while the GPU works on earlier batches

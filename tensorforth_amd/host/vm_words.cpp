@@ -462,7 +462,7 @@ void VM::init_nn() {
             DU scale = POP(); int mean = POPi();
             Dataset &ds = (Dataset &)st().du2obj(tos_);
             hold_begin();
-            char b[96]; snprintf(b, sizeof(b), "  OP_NORM(mean=%d, scale=%g)\n", mean, scale); pstr(b);
+            hprintf("  OP_NORM(mean=%d, scale=%g)\n", mean, scale);          // a plain printf in the reference (sys.cpp:181): in front of the fetch's trace text
             ds.set_norm((DU)mean, scale); ds.fetch(nullptr, true);
             hold_end();
         } else { DU std = POP(), avg = POP(); if (TOS1T()) TTOS().normalize(std, avg); }

@@ -44,7 +44,7 @@ def normalise_refhost(text):
 
 
 _TRACE_DROP = (r"^vm0> ", r"^NetVM::", r"^} NetVM::", r"^\\ ", r"^tensorForth", r"^VM\[", r"^ForthVM", r"^TensorVM", r"^NetVM", r"^\*\*\* redefined", r"^ *::", r"^\s*$",
-               r"^tenvm#", r"^\d+> tenvm#", r"^} tenvm#")
+               r"^tenvm#", r"^\d+> tenvm#", r"^} tenvm#", r"^} \d+> tenvm#")
 
 
 def normalise_trace(text):
