@@ -148,6 +148,11 @@ def extras(vm_cls, local, ms_step, args, torch):
     import subprocess
     import tempfile
     out = {}
+    # The extras run on the product's DEFAULT launch plan (first layer's dX on demand), as in every earlier round - only the headline loop above and `gan_round_eager_ms`
+    # below store it every step.  The switch is process-wide (ten4_set_lazy_dx0) and read at every backprop.
+    from tensorforth_amd import vm as t4vm
+    headline_plan = t4vm.set_lazy_dx0(1)
+    out["extras_plan"] = "product default (first layer's dX on demand, T4_LAZY_DX0=1); the headline loop ran with T4_LAZY_DX0=%d" % headline_plan
     # ---- config #4: t4_40b GAN nets, N = 256, Adam beta1 = 0.5 (tools/forth/gan_steps.4th), one `train_d train_g` round
     g = vm_cls(device=local, seed=4321)
     txt = g.eval(GAN_SRC)
@@ -162,6 +167,16 @@ def extras(vm_cls, local, ms_step, args, torch):
                   "rounds_timed": rounds, "algorithmic_bytes_per_round": gb, "hbm_frac": round(gb / gdt / 1e9 / PEAK_HBM_GBS, 5),
                   "flop_per_round": gf, "mfma_frac": round(gf / gdt / 1e12 / PEAK_F32_MFMA_TFLOPS, 5)}
     g.close()
+    # the same round with every layer's dX stored every step, the generator's and the discriminator's first layers included (the reference's work)
+    t4vm.set_lazy_dx0(0)
+    g = vm_cls(device=local, seed=4321)
+    txt = g.eval(GAN_SRC)
+    assert "?" not in txt.replace("-> ok", ""), txt
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); g.eval("%d rounds real forward REAL loss.bce drop\n" % rounds); torch.cuda.synchronize()
+    out["gan_round_eager_ms"] = round((time.perf_counter() - t0) / rounds * 1e3, 4)
+    g.close()
+    t4vm.set_lazy_dx0(1)
     # ---- config #5's strong-scaling denominator: the same net at batch 1024 on ONE GPU (8 x 128 sharded is the weak-scaling line above)
     b = vm_cls(device=local, seed=1234)
     txt = b.eval("0 trace\n1024 28 28 1 nn.model 0.5 10 conv2d 2 maxpool relu 0.5 20 conv2d 0.5 dropout 2 maxpool relu flatten 100 linear 0.5 dropout 10 linear softmax constant net\n"
@@ -242,6 +257,7 @@ def extras(vm_cls, local, ms_step, args, torch):
             v.close()
         finally:
             os.chdir(cwd)
+    t4vm.set_lazy_dx0(headline_plan)
     return out
 
 

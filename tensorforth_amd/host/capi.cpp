@@ -62,5 +62,6 @@ long ten4_store(ten4_vm *h, const float *src, long n) {
     return n;
 }
 void ten4_set_grad_hook(ten4_vm *, ten4_grad_hook_fn fn, void *user) { t4::Model::grad_hook = fn; t4::Model::grad_hook_user = user; }
+int ten4_set_lazy_dx0(int on) { return t4::Model::set_lazy_dx0(on != 0) ? 1 : 0; }
 
 } // extern "C"

@@ -275,6 +275,7 @@ struct Model : Obj {
     // the slab (the big linear layers finish first) while the convolution layers are still back-propagating.
     static void (*grad_hook)(int layer, long off, long n, void *user);
     static void *grad_hook_user;
+    static bool set_lazy_dx0(bool on) { const bool was = use_lazy_dx0; use_lazy_dx0 = on; return was; }   // ten4_set_lazy_dx0 (include/ten4.h)
     void  finalize();                          // build the gradient slab + side stream (first forward / backprop)
     void  invalidate();                        // drop captured graphs (layers added, shapes changed)
     static bool use_graphs, use_side;          // T4_GRAPH=0 / T4_SIDE=0 switch them off (debugging)

@@ -21,6 +21,15 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
 
 
+def set_lazy_dx0(on):
+    """Process-wide launch-plan switch (ten4_set_lazy_dx0, the run-time form of T4_LAZY_DX0); returns the previous setting."""
+    _lib.load()
+    so = ctypes.CDLL(os.path.join(_HERE, "libten4.so"))
+    so.ten4_set_lazy_dx0.restype = ctypes.c_int
+    so.ten4_set_lazy_dx0.argtypes = [ctypes.c_int]
+    return so.ten4_set_lazy_dx0(1 if on else 0)
+
+
 class VM:
     def __init__(self, device=0, seed=1234, trace=0):
         _lib.load()                                      # imports torch first, then libt4hip.so (one HIP runtime)
