@@ -182,9 +182,14 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     if (!cp) { hprintf("  } dataset#fetch => not found in Loader\n"); return -1; }
     die_if_no_backend();
     if (rewind) {                                        // also after `normalize`: whatever was staged ahead on the DEVICE is void (the pinned raw bytes are not)
-        if (ds_name) cp->idle(); else cp->settle();
-        for (int i = 0; i < RING; i++) { if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]); dev_bid[i] = -1; }
-        mark_bid = -1;
+        // the end-of-epoch rewind of a training loop finds batch 0 staged ahead by the last fetch of the epoch: nothing to wait for, the ring goes on
+        const bool keep = !ds_name && !norm_dirty && done && ring_numel == numel && dev_bid[seq % RING] == 0;
+        if (!keep) {
+            if (ds_name) cp->idle(); else cp->settle();
+            for (int i = 0; i < RING; i++) { if (staged[i] && dev_bid[i] >= 0) t4k_event_sync(staged[i]); dev_bid[i] = -1; }
+            mark_bid = -1;
+        }
+        norm_dirty = false;
         batch_id = done = 0;
     }
     const int b = batch_id, nb = cp->n_batches();
@@ -202,7 +207,7 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
     const long cell = HWC();
     t4k_stream_t side = g_prefetch ? feed_stream() : nullptr;     // none on a backend without streams (the oracle's): every batch then takes the in-stream path
     // ---- batch b becomes current
-    const int r = b % RING;
+    const int r = seq % RING;
     if (dev_bid[r] == b) t4k_event_sync(staged[r]);      // staged ahead (issued a step ago)
     else {
         const int n = cp->wait_batch(b);
@@ -210,7 +215,7 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
         chk(t4k_stage_batch(cp->pix[b & 1], dbuf[r], (long)n * cell, mean, scale, cp->lab[b & 1], lbuf[r], n, stream()), "dataset#load");   // (x - mean) * scale and the labels, one launch
         t4k_event_record(cp->pin_done[b & 1], stream()); cp->pin_ev[b & 1] = cp->pin_done[b & 1]; cp->pin_wait[b & 1] = true;
         // a short last batch leaves the previous batch's samples behind it (Dataset::_load copies batch_sz samples into ONE buffer, dataset.cu:142-158)
-        if (n < cp->N && b > 0) t4k_memcpy_d2d(dbuf[r] + (long)n * cell, dbuf[(b - 1) % RING] + (long)n * cell, sizeof(float) * (size_t)(cp->N - n) * cell, stream());
+        if (n < cp->N && b > 0) t4k_memcpy_d2d(dbuf[r] + (long)n * cell, dbuf[(seq + RING - 1) % RING] + (long)n * cell, sizeof(float) * (size_t)(cp->N - n) * cell, stream());
         dev_bid[r] = b; dev_n[r] = n;
     }
     data = dbuf[r]; label = lbuf[r]; batch_sz = dev_n[r];
@@ -230,14 +235,17 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
         if (done) hprintf("completed, no more data.\n"); else hprintf("%d record(s) loaded\n", batch_sz);
     }
     cp->names_shown_latch = true;
-    if (!done) {
-        // ---- batch b + 1 goes to its buffer on the side stream if the reader already holds it (full batches only); a cold start just asks for it
-        const int b1 = b + 1, r1 = b1 % RING;
+    // ---- the batch of the NEXT fetch goes to its buffer on the side stream if the reader already holds it (full batches only); a cold start just asks for
+    // it.  Behind the last batch of an epoch that is batch 0 again (the training loops rewind next): with an even number of batches it sits in the pinned slot
+    // batch nb - 2 left (asked for below, one fetch earlier), so the rewind finds it staged like any other batch and waits for nothing.
+    const bool wrap = nb >= 4 && !(nb & 1);
+    if (!done || wrap) {
+        const int b1 = done ? 0 : b + 1, r1 = (seq + 1) % RING;
         if (side && dev_bid[r1] != b1 && cp->slot_bid[b1 & 1] == b1 && (long)(b1 + 1) * cp->N <= cp->corpus_sz) {
             const int n1 = cp->wait_batch(b1);
             if (n1 == cp->N) {
-                if (mark_bid < 0 || b - mark_bid >= MARK_EVERY) {          // a fresh mark: behind everything issued so far; the side stream waits for it once
-                    t4k_event_record(mark, stream()); mark_bid = b;
+                if (mark_bid < 0 || seq - mark_bid >= MARK_EVERY) {        // a fresh mark: behind everything issued so far; the side stream waits for it once
+                    t4k_event_record(mark, stream()); mark_bid = seq;
                     t4k_stream_wait_event(side, mark);
                 }
                 chk(t4k_stage_batch(cp->pix[b1 & 1], dbuf[r1], (long)n1 * cell, mean, scale, cp->lab[b1 & 1], lbuf[r1], n1, side), "dataset#prefetch");
@@ -246,11 +254,14 @@ int Dataset::fetch(const char *ds_name, bool rewind) {   // dataset.cu:64-121
                 dev_bid[r1] = b1; dev_n[r1] = n1;
             }
         }
-        cp->request(b1);                                 // no-op when the slot holds (or is being filled with) that batch
-        cp->request(b + 2);                              // slot b & 1: batch b's staging launch has been issued, the reader waits for its event
+    }
+    if (!done) {
+        cp->request(b + 1);                              // no-op when the slot holds (or is being filled with) that batch
+        cp->request(b + 2 == nb && wrap ? 0 : b + 2);    // slot b & 1: batch b's staging launch has been issued, the reader waits for its event
     } else {                                             // last batch of the epoch: the training loops rewind next - the reader wraps around ahead of them (it waits for
         cp->request(0); cp->request(1);                  // the staging launches of the batches the slots held), so the rewind costs no synchronous read
     }
+    seq++;
     batch_id++;
     return 0;
 }

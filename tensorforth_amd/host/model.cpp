@@ -413,10 +413,16 @@ void Model::run_forward(Tensor &input) {
                             if (!hot) hot = &T4(prob.N(), 1, E, 1);
                             if ((uint32_t)ds.batch_sz < prob.N()) hot->zeros();     // short last batch: the rows past it stay zero and count nothing
                             if (!hit_flags_ || hit_flags_n_ < (int)prob.N()) {
-                                if (hit_flags_) { t4k_sync(stream()); t4k_host_free(hit_flags_); }
+                                if (hit_flags_) { t4k_sync(stream()); t4k_host_free(hit_flags_); t4k_free(hit_flags_dev_); }
                                 void *pp; chk(t4k_host_alloc(&pp, prob.N()), "nn#hit flags"); hit_flags_ = (unsigned char *)pp; hit_flags_n_ = (int)prob.N();
+                                chk(t4k_malloc(&pp, prob.N()), "nn#hit flags"); hit_flags_dev_ = (unsigned char *)pp;
                             }
-                            hd.label = ds.label; hd.hot = hot->data; hd.hit_flag = hit_flags_; hd.n_label = ds.batch_sz; rider = true;
+                            // where the flags go: a loop that reads `nn.hit` every batch (the reference's demos, t4_30e.4th:68-76) gets them in pinned host memory -
+                            // its device sync makes them readable, no copy; a loop that does not keeps them on the device, where the store does not hold the
+                            // kernel's end behind a PCIe round trip, and the rare `nn.hit` copies them out
+                            hit_flags_on_dev_ = !hit_read_;
+                            hit_read_ = false;
+                            hd.label = ds.label; hd.hot = hot->data; hd.hit_flag = hit_flags_on_dev_ ? hit_flags_dev_ : hit_flags_; hd.n_label = ds.batch_sz; rider = true;
                         }
                     }
                     if (t4k_conv_stack_head_ok(stg, ns, in.N(), &hd)) {
@@ -596,10 +602,14 @@ DU Model::dp_sum(DU v) {
 }
 int Model::hit(bool recalc) {                           // loss.cpp:75-107
     if (recalc) { hit_flags_pending_ = false; hit_lazy(); }
-    if (hit_flags_pending_) {                             // the forward left one byte per image in pinned memory: add them up here
+    hit_read_ = true;
+    if (hit_flags_pending_) {                             // the forward left one byte per image, in pinned host memory or on the device (see forward): add them up here
+        int c = 0; const int n = std::min((int)at(-1).N(), hit_flags_n_);
+        std::vector<unsigned char> fl((size_t)std::max(n, 1));
+        if (hit_flags_on_dev_) t4k_memcpy_d2h(fl.data(), hit_flags_dev_, (size_t)n, stream());
         t4k_sync(stream());
-        int c = 0; const int n = (int)at(-1).N();
-        for (int i = 0; i < n && i < hit_flags_n_; i++) c += ((volatile unsigned char *)hit_flags_)[i] ? 1 : 0;
+        if (!hit_flags_on_dev_) memcpy(fl.data(), hit_flags_, (size_t)n);
+        for (int i = 0; i < n; i++) c += fl[i] ? 1 : 0;
         hit_ = (int)dp_sum((DU)c); hit_flags_pending_ = false; hit_pending_ = false;
         return hit_;
     }
@@ -1145,7 +1155,7 @@ void Model::free_all() {
     if (tab_dev) { t4k_free(tab_dev); tab_dev = nullptr; }
     if (hit_dev) { t4k_free(hit_dev); hit_dev = nullptr; }
     if (hit_pin) { t4k_sync(stream()); t4k_host_free(hit_pin); hit_pin = nullptr; }
-    if (hit_flags_) { t4k_sync(stream()); t4k_host_free(hit_flags_); hit_flags_ = nullptr; hit_flags_n_ = 0; }
+    if (hit_flags_) { t4k_sync(stream()); t4k_host_free(hit_flags_); t4k_free(hit_flags_dev_); hit_flags_ = hit_flags_dev_ = nullptr; hit_flags_n_ = 0; }
 }
 
 Model &Store::model(int *trace) { Model *m = new Model(); m->type = T_MODEL; m->trace = trace; put(m); return *m; }

@@ -219,10 +219,12 @@ struct Dataset : Tensor {
     int       dev_bid[RING], dev_n[RING] = {};
     t4k_event_t staged[RING] = {};             // side stream: batch is in its buffer (also what the reader waits for before refilling the pinned slot)
     t4k_event_t mark = nullptr;                // main stream: recorded every MARK_EVERY fetches, behind everything that read earlier batches
-    int  mark_bid = -1;                        // the fetch it was recorded at (-1: none)
+    int  mark_bid = -1;                        // the fetch (seq) it was recorded at (-1: none)
+    int  seq = 0;                              // fetches since the ring was built: the ring slot of a fetch is seq % RING, ACROSS rewinds (batch 0 of the next epoch is staged at the last batch of this one)
+    bool norm_dirty = false;                   // `normalize` since the last fetch: what the ring holds was scaled with the old constants
     uint64_t ring_numel = 0;
     Dataset() { for (int i = 0; i < RING; i++) dev_bid[i] = -1; }
-    void set_norm(DU m, DU s) { mean = m; scale = 1.0f / s; }
+    void set_norm(DU m, DU s) { mean = m; scale = 1.0f / s; norm_dirty = true; }
     int  fetch(const char *ds_name, bool rewind);
     static int *trace;                         // the VM's trace level (null: off): Dataset::fetch prints the reference's text at level >= 1
     void release_ring();
@@ -237,7 +239,7 @@ struct Model : Obj {
     DU   max_norm = 0;
     int *trace = nullptr;
     Tensor *hot = nullptr, *loss_t = nullptr;
-    unsigned char *hit_flags_ = nullptr; int hit_flags_n_ = 0; bool hit_flags_pending_ = false;   // per-image hit flags the conv stack's head forward wrote (pinned host bytes): `nn.hit` adds them up
+    unsigned char *hit_flags_ = nullptr, *hit_flags_dev_ = nullptr; int hit_flags_n_ = 0; bool hit_flags_pending_ = false, hit_flags_on_dev_ = false, hit_read_ = true;   // per-image hit flags the conv stack's head forward wrote (pinned host bytes when the loop reads `nn.hit` every batch, else device bytes): `nn.hit` adds them up
     int  *hit_dev = nullptr, *hit_pin = nullptr;          // scalar all-reduce scratch (HBM); hit counter (pinned host, written by k_hit)
 
     Tensor &at(int i) { return *layer[i < 0 ? (int)layer.size() + i : i]; }
