@@ -48,7 +48,7 @@ long ten4_store(ten4_vm *vm, const float *src, long n);
 typedef void (*ten4_grad_hook_fn)(int layer, long off, long n, void *user);
 void ten4_set_grad_hook(ten4_vm *vm, ten4_grad_hook_fn fn, void *user);
 /* Launch plan switch of the process (the run-time form of T4_LAZY_DX0): 1 = the first layer's dX is produced when a word reads it (default), 0 = stored by every
- * backprop as the reference does.  Takes effect for models finalized afterwards; returns the previous setting.  bench.py times its headline step with 0. */
+ * backprop as the reference does.  Read at every backprop; returns the previous setting.  bench.py times its headline step with 0, its other legs with 1. */
 int ten4_set_lazy_dx0(int on);
 
 #ifdef __cplusplus
